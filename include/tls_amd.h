@@ -1,0 +1,126 @@
+/*
+ * tls_amd.h -- C ABI of the MI355X transit-least-squares search engine (libtls_amd.so).
+ *
+ * The reference (hippke/tls v1.0.31) has no FFI layer: its seam for this path is the
+ * Python function
+ *     search_period(period, t, y, dy, transit_depth_min, R_star_min, R_star_max,
+ *                   M_star_min, M_star_max, lc_arr, lc_cache_overview, T0_fit_margin)
+ *         -> [period, chi2, row, depth]                 (transitleastsquares/core.py:96-188)
+ * mapped over all trial periods by power()              (transitleastsquares/main.py:140-185)
+ * and re-sorted by period                               (transitleastsquares/main.py:190-196).
+ * This library replaces exactly that: ONE batched call searches every period of one
+ * light curve on the GPU and returns chi2/row/depth per period in the order of `periods`.
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types; every array is contiguous float64 / int64, owned by the caller;
+ *     the library copies host->device->host internally and keeps no caller pointer.
+ *   - every function returning int returns TLS_OK (0) or a negative TLS_E_* code; the
+ *     message is available from tls_last_error(ctx) (ctx may be NULL for create errors).
+ *   - a tls_ctx is bound to one GPU and one HIP stream; it is not re-entrant.  Use one
+ *     context per GPU (one process per GPU in multi-GPU runs).
+ *   - there is NO CPU fallback: without a usable GPU tls_ctx_create fails.
+ */
+#ifndef TLS_AMD_H
+#define TLS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TLS_OK 0
+#define TLS_E_ARG (-1)      /* invalid argument */
+#define TLS_E_HIP (-2)      /* HIP runtime error (message has the HIP error string) */
+#define TLS_E_NOMEM (-3)    /* host or device allocation failed */
+#define TLS_E_STATE (-4)    /* call order violated (e.g. execute before prepare) */
+#define TLS_E_RCCL (-5)     /* RCCL error */
+
+typedef struct tls_ctx tls_ctx;
+
+/* Optional work counters of one search (all per light curve). */
+typedef struct tls_counters {
+    int64_t grid_cells;      /* (period, duration, T0) cells enumerated: data independent */
+    int64_t evaluated_cells; /* cells that passed mean > transit_depth_min (core.py:58) */
+    int64_t inner_steps;     /* template samples multiplied (core.py:67-69) */
+    int64_t pd_pairs;        /* (period, duration) pairs searched */
+} tls_counters;
+
+/* Template table = the reference's (lc_cache_overview, lc_arr) of transit.py:98-160,
+ * flattened: row r is values[offset[r] .. offset[r]+length[r]), trial width width[r]
+ * samples, depth-normalisation factor overshoot[r]. */
+typedef struct tls_template {
+    const double *values;
+    const int64_t *offset;
+    const int64_t *length;
+    const int64_t *width;
+    const double *overshoot;
+    int64_t n_rows;
+} tls_template;
+
+/* Scalar parameters of search_period (core.py:96-109). */
+typedef struct tls_params {
+    double transit_depth_min;
+    double R_star_min, R_star_max, M_star_min, M_star_max;
+    double T0_fit_margin;
+} tls_params;
+
+/* ---- context ------------------------------------------------------------------- */
+int tls_device_count(void);                 /* number of visible GPUs, <0 on error */
+tls_ctx *tls_ctx_create(int device_id);     /* NULL on failure, see tls_last_error(NULL) */
+void tls_ctx_destroy(tls_ctx *ctx);
+const char *tls_last_error(const tls_ctx *ctx);
+const char *tls_version(void);
+/* "gfx950 ..." style description of the context's device (valid until ctx destroy) */
+const char *tls_device_name(const tls_ctx *ctx);
+
+/* ---- one-shot search: replaces main.py:140-196 for one light curve -------------- */
+/* out_chi2/out_row/out_depth have n_periods entries, index i belongs to periods[i].
+ * counters may be NULL. */
+int tls_search(tls_ctx *ctx, const double *t, const double *y, const double *dy, int64_t n,
+               const double *periods, int64_t n_periods, const tls_template *tmpl,
+               const tls_params *params, double *out_chi2, int64_t *out_row,
+               double *out_depth, tls_counters *counters);
+
+/* ---- staged search: same result, inputs resident in HBM between the stages ------ */
+/* prepare: validate, build the device-side work list, upload everything. */
+int tls_prepare(tls_ctx *ctx, const double *t, const double *y, const double *dy, int64_t n,
+                const double *periods, int64_t n_periods, const tls_template *tmpl,
+                const tls_params *params);
+/* replace only the light-curve values of a prepared search (same t, n, grids, template):
+ * survey mode streams many light curves through one prepared plan. */
+int tls_update_flux(tls_ctx *ctx, const double *y, const double *dy);
+/* execute: enqueue the search kernels on the context's stream (asynchronous).
+ * count_work != 0 also accumulates evaluated_cells/inner_steps (slower). */
+int tls_execute(tls_ctx *ctx, int count_work);
+/* block until the stream is idle */
+int tls_synchronize(tls_ctx *ctx);
+/* fetch: copy results (and counters, may be NULL) back; synchronises. */
+int tls_fetch(tls_ctx *ctx, double *out_chi2, int64_t *out_row, double *out_depth,
+              tls_counters *counters);
+/* run `reps` executes back to back and report the mean duration of ONE execute in
+ * milliseconds, measured with HIP events on the context's stream. */
+int tls_execute_timed(tls_ctx *ctx, int reps, double *ms_per_execute);
+/* data-independent work of the prepared search (no device work needed). */
+int tls_plan_info(const tls_ctx *ctx, tls_counters *counters, int64_t *lds_bytes,
+                  int64_t *n_blocks, int64_t *resident /* 1: folded series kept in LDS */);
+
+/* ---- multi-GPU: period grid sharded over ranks, one RCCL all-gather at the end --- */
+/* rank 0 creates the 128-byte id and hands it to the other ranks by any host channel */
+int tls_comm_unique_id(char id_out[128]);
+int tls_comm_init(tls_ctx *ctx, int n_ranks, int rank, const char id[128]);
+int tls_comm_destroy(tls_ctx *ctx);
+/* All-gather of the prepared search's device-resident results: every rank contributes its
+ * shard (count_per_rank entries, zero padded) and receives n_ranks*count_per_rank entries of
+ * chi2/row/depth in rank order.  One ncclAllGather over a packed 24 B/period buffer. */
+int tls_comm_allgather_results(tls_ctx *ctx, int64_t count_per_rank, double *all_chi2,
+                               int64_t *all_row, double *all_depth);
+/* small host-value collectives used by the bench harness (barrier, max over ranks) */
+int tls_comm_barrier(tls_ctx *ctx);
+int tls_comm_max(tls_ctx *ctx, double *value_inout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLS_AMD_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of oracle/libtls_oracle.so (TEST INFRASTRUCTURE, see __init__)."""
+import ctypes
+import os
+import subprocess
+
+import numpy
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_F8 = numpy.ctypeslib.ndpointer(dtype=numpy.float64, flags="C_CONTIGUOUS")
+_I8 = numpy.ctypeslib.ndpointer(dtype=numpy.int64, flags="C_CONTIGUOUS")
+
+
+def build(fast=False, force=False):
+    """Compile the oracle with gcc (idempotent). Returns the .so path."""
+    name = "libtls_oracle_fast.so" if fast else "libtls_oracle.so"
+    path = os.path.join(_HERE, name)
+    src = os.path.join(_HERE, "tls_oracle.c")
+    if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "fast" if fast else "all"],
+                              stdout=subprocess.DEVNULL)
+    return path
+
+
+class OracleLibrary(object):
+    def __init__(self, fast=False):
+        self.lib = ctypes.CDLL(build(fast=fast))
+        f = self.lib.tls_oracle_search
+        f.restype = ctypes.c_int
+        f.argtypes = [_F8, _F8, _F8, ctypes.c_int64, _F8, ctypes.c_int64,
+                      _F8, _I8, _I8, _I8, _F8, ctypes.c_int64,
+                      ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                      ctypes.c_double, ctypes.c_double,
+                      _F8, _I8, _F8, _I8, ctypes.c_int]
+        self.lib.tls_oracle_t14.restype = ctypes.c_double
+        self.lib.tls_oracle_t14.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                            ctypes.c_int]
+        self.lib.tls_oracle_fold_sort.restype = None
+        self.lib.tls_oracle_fold_sort.argtypes = [_F8, ctypes.c_int64, ctypes.c_double, _F8, _I8]
+
+    def search(self, t, y, dy, periods, table, transit_depth_min, R_star_min, R_star_max,
+               M_star_min, M_star_max, T0_fit_margin, n_threads=0):
+        """table: tls_amd.template.TemplateTable (or anything with values/offset/
+        length/width/overshoot).  Returns chi2, row, depth, counters (len(periods))."""
+        c = lambda a, d: numpy.ascontiguousarray(a, dtype=d)
+        t, y, dy = c(t, numpy.float64), c(y, numpy.float64), c(dy, numpy.float64)
+        periods = c(periods, numpy.float64)
+        n_p = len(periods)
+        chi2 = numpy.empty(n_p, dtype=numpy.float64)
+        row = numpy.empty(n_p, dtype=numpy.int64)
+        depth = numpy.empty(n_p, dtype=numpy.float64)
+        counters = numpy.zeros(3, dtype=numpy.int64)
+        rc = self.lib.tls_oracle_search(
+            t, y, dy, len(t), periods, n_p,
+            c(table.values, numpy.float64), c(table.offset, numpy.int64),
+            c(table.length, numpy.int64), c(table.width, numpy.int64),
+            c(table.overshoot, numpy.float64), len(table.width),
+            transit_depth_min, R_star_min, R_star_max, M_star_min, M_star_max, T0_fit_margin,
+            chi2, row, depth, counters, int(n_threads))
+        if rc != 0:
+            raise RuntimeError("tls_oracle_search failed with code %d" % rc)
+        return chi2, row, depth, counters
+
+    def t14(self, R_s, M_s, P, small):
+        return self.lib.tls_oracle_t14(R_s, M_s, P, 1 if small else 0)
+
+    def fold_sort(self, t, period):
+        t = numpy.ascontiguousarray(t, dtype=numpy.float64)
+        ph = numpy.empty(len(t))
+        idx = numpy.empty(len(t), dtype=numpy.int64)
+        self.lib.tls_oracle_fold_sort(t, len(t), period, ph, idx)
+        return ph, idx
+
+
+_default = {}
+
+
+def search(*args, **kwargs):
+    """Module-level convenience: search with the strict-IEEE oracle build."""
+    fast = kwargs.pop("fast", False)
+    if fast not in _default:
+        _default[fast] = OracleLibrary(fast=fast)
+    return _default[fast].search(*args, **kwargs)

@@ -1,0 +1,259 @@
+"""ctypes binding of libtls_amd.so -- the C ABI declared in include/tls_amd.h.
+
+Thin by design: numpy arrays in, numpy arrays out, every non-zero return code
+raised as RuntimeError with the library's message.  No torch, no fallback: if the
+shared library is missing, or no GPU is usable, the error surfaces here.
+"""
+import ctypes
+import os
+
+import numpy
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtls_amd.so")
+
+# every symbol include/tls_amd.h declares (tests check the export list against the header)
+SYMBOLS = (
+    "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
+    "tls_device_name", "tls_search", "tls_prepare", "tls_update_flux", "tls_execute",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info",
+    "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results",
+    "tls_comm_barrier", "tls_comm_max",
+)
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+class _Template(ctypes.Structure):
+    _fields_ = [("values", _c_double_p), ("offset", _c_int64_p), ("length", _c_int64_p),
+                ("width", _c_int64_p), ("overshoot", _c_double_p), ("n_rows", ctypes.c_int64)]
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [("transit_depth_min", ctypes.c_double), ("R_star_min", ctypes.c_double),
+                ("R_star_max", ctypes.c_double), ("M_star_min", ctypes.c_double),
+                ("M_star_max", ctypes.c_double), ("T0_fit_margin", ctypes.c_double)]
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [("grid_cells", ctypes.c_int64), ("evaluated_cells", ctypes.c_int64),
+                ("inner_steps", ctypes.c_int64), ("pd_pairs", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """Load libtls_amd.so once; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "tls_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C tls_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+    lib.tls_device_count.restype = ci
+    lib.tls_ctx_create.restype = vp
+    lib.tls_ctx_create.argtypes = [ci]
+    lib.tls_ctx_destroy.restype = None
+    lib.tls_ctx_destroy.argtypes = [vp]
+    lib.tls_last_error.restype = ctypes.c_char_p
+    lib.tls_last_error.argtypes = [vp]
+    lib.tls_version.restype = ctypes.c_char_p
+    lib.tls_device_name.restype = ctypes.c_char_p
+    lib.tls_device_name.argtypes = [vp]
+    tp, pp = ctypes.POINTER(_Template), ctypes.POINTER(_Params)
+    cp = ctypes.POINTER(Counters)
+    lib.tls_search.restype = ci
+    lib.tls_search.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, _c_double_p, i64,
+                               tp, pp, _c_double_p, _c_int64_p, _c_double_p, cp]
+    lib.tls_prepare.restype = ci
+    lib.tls_prepare.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, _c_double_p, i64,
+                                tp, pp]
+    lib.tls_update_flux.restype = ci
+    lib.tls_update_flux.argtypes = [vp, _c_double_p, _c_double_p]
+    lib.tls_execute.restype = ci
+    lib.tls_execute.argtypes = [vp, ci]
+    lib.tls_synchronize.restype = ci
+    lib.tls_synchronize.argtypes = [vp]
+    lib.tls_fetch.restype = ci
+    lib.tls_fetch.argtypes = [vp, _c_double_p, _c_int64_p, _c_double_p, cp]
+    lib.tls_execute_timed.restype = ci
+    lib.tls_execute_timed.argtypes = [vp, ci, _c_double_p]
+    lib.tls_plan_info.restype = ci
+    lib.tls_plan_info.argtypes = [vp, cp, _c_int64_p, _c_int64_p, _c_int64_p]
+    lib.tls_comm_unique_id.restype = ci
+    lib.tls_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.tls_comm_init.restype = ci
+    lib.tls_comm_init.argtypes = [vp, ci, ci, ctypes.c_char_p]
+    lib.tls_comm_destroy.restype = ci
+    lib.tls_comm_destroy.argtypes = [vp]
+    lib.tls_comm_allgather_results.restype = ci
+    lib.tls_comm_allgather_results.argtypes = [vp, i64, _c_double_p, _c_int64_p, _c_double_p]
+    lib.tls_comm_barrier.restype = ci
+    lib.tls_comm_barrier.argtypes = [vp]
+    lib.tls_comm_max.restype = ci
+    lib.tls_comm_max.argtypes = [vp, _c_double_p]
+    _lib = lib
+    return lib
+
+
+def _f8(a):
+    return numpy.ascontiguousarray(a, dtype=numpy.float64)
+
+
+def _i8(a):
+    return numpy.ascontiguousarray(a, dtype=numpy.int64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_c_int64_p)
+
+
+class Context(object):
+    """One GPU + one HIP stream (tls_ctx).  Not re-entrant."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = self._lib.tls_ctx_create(int(device))
+        if not self._h:
+            raise RuntimeError("tls_amd: cannot create a GPU context: "
+                               + self._lib.tls_last_error(None).decode())
+        self.device = int(device)
+        self._keep = None
+        self._n_periods = 0
+
+    # -- plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tls_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("tls_amd error %d: %s"
+                               % (rc, self._lib.tls_last_error(self._h).decode()))
+
+    @property
+    def name(self):
+        return self._lib.tls_device_name(self._h).decode()
+
+    @staticmethod
+    def _pack(table, params):
+        arrays = (_f8(table.values), _i8(table.offset), _i8(table.length), _i8(table.width),
+                  _f8(table.overshoot))
+        tm = _Template(_dp(arrays[0]), _ip(arrays[1]), _ip(arrays[2]), _ip(arrays[3]),
+                       _dp(arrays[4]), len(arrays[3]))
+        pr = _Params(*[float(params[k]) for k in (
+            "transit_depth_min", "R_star_min", "R_star_max", "M_star_min", "M_star_max",
+            "T0_fit_margin")])
+        return arrays, tm, pr
+
+    # -- one-shot
+    def search(self, t, y, dy, periods, table, params, count_work=False):
+        """chi2, row, depth (and counters dict) for every period, in `periods` order."""
+        self.prepare(t, y, dy, periods, table, params)
+        self.execute(count_work=count_work)
+        return self.fetch(with_counters=True)
+
+    # -- staged
+    def prepare(self, t, y, dy, periods, table, params):
+        t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)
+        if not (t.ndim == y.ndim == dy.ndim == 1 and len(t) == len(y) == len(dy)):
+            raise ValueError("t, y, dy must be 1-dimensional and of equal length")
+        arrays, tm, pr = self._pack(table, params)
+        self._check(self._lib.tls_prepare(self._h, _dp(t), _dp(y), _dp(dy), len(t), _dp(periods),
+                                          len(periods), ctypes.byref(tm), ctypes.byref(pr)))
+        self._n_periods = len(periods)
+
+    def update_flux(self, y, dy):
+        y, dy = _f8(y), _f8(dy)
+        self._check(self._lib.tls_update_flux(self._h, _dp(y), _dp(dy)))
+
+    def execute(self, count_work=False):
+        self._check(self._lib.tls_execute(self._h, 1 if count_work else 0))
+
+    def synchronize(self):
+        self._check(self._lib.tls_synchronize(self._h))
+
+    def execute_timed(self, reps=1):
+        ms = ctypes.c_double(0.0)
+        self._check(self._lib.tls_execute_timed(self._h, int(reps), ctypes.byref(ms)))
+        return ms.value
+
+    def fetch(self, with_counters=False):
+        n = self._n_periods
+        chi2 = numpy.empty(n, dtype=numpy.float64)
+        row = numpy.empty(n, dtype=numpy.int64)
+        depth = numpy.empty(n, dtype=numpy.float64)
+        c = Counters()
+        self._check(self._lib.tls_fetch(self._h, _dp(chi2), _ip(row), _dp(depth), ctypes.byref(c)))
+        if with_counters:
+            return chi2, row, depth, c.as_dict()
+        return chi2, row, depth
+
+    def plan_info(self):
+        c = Counters()
+        lds, blocks, res = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.tls_plan_info(self._h, ctypes.byref(c), ctypes.byref(lds),
+                                            ctypes.byref(blocks), ctypes.byref(res)))
+        d = c.as_dict()
+        d.update(lds_bytes=lds.value, n_blocks=blocks.value, resident=bool(res.value))
+        return d
+
+    # -- RCCL
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        rc = self._lib.tls_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("tls_amd: ncclGetUniqueId failed: "
+                               + self._lib.tls_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        assert len(unique_id) == 128
+        self._check(self._lib.tls_comm_init(self._h, int(n_ranks), int(rank), unique_id))
+
+    def comm_destroy(self):
+        self._check(self._lib.tls_comm_destroy(self._h))
+
+    def comm_allgather_results(self, count_per_rank, n_ranks):
+        total = int(count_per_rank) * int(n_ranks)
+        chi2 = numpy.empty(total, dtype=numpy.float64)
+        row = numpy.empty(total, dtype=numpy.int64)
+        depth = numpy.empty(total, dtype=numpy.float64)
+        self._check(self._lib.tls_comm_allgather_results(self._h, int(count_per_rank), _dp(chi2),
+                                                         _ip(row), _dp(depth)))
+        return chi2, row, depth
+
+    def comm_barrier(self):
+        self._check(self._lib.tls_comm_barrier(self._h))
+
+    def comm_max(self, value):
+        v = ctypes.c_double(float(value))
+        self._check(self._lib.tls_comm_max(self._h, ctypes.byref(v)))
+        return v.value
+
+
+def device_count():
+    lib = load()
+    n = lib.tls_device_count()
+    if n < 0:
+        raise RuntimeError("tls_amd: " + lib.tls_last_error(None).decode())
+    return n

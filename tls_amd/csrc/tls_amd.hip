@@ -1,0 +1,552 @@
+// tls_amd.hip -- host side of libtls_amd.so: the C ABI of include/tls_amd.h.
+//
+// Builds the device work list for one light curve (distinct trial widths, per-period
+// duration windows, cost-ordered period queue), keeps every buffer resident in HBM between
+// calls, launches the search kernel of tls_kernels.hip.h and gathers results; optional RCCL
+// all-gather for the period-sharded multi-GPU mode.
+//
+// Reference mapping: main.py:140-196 (dispatch + ordered gather), core.py:113-116,143-156
+// (width list, duration window per period), grid.py:9-32 (T14).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/tls_amd.h"
+#include "tls_kernels.hip.h"
+
+namespace {
+
+// physical constants of the duration window (reference tls_constants.py:20-25,78)
+constexpr double kG = 6.673e-11;
+constexpr double kRsun = 695508000.0;
+constexpr double kRjup = 69911000.0;
+constexpr double kMsun = 1.989 * 1e30;
+constexpr double kSecondsPerDay = 86400.0;
+constexpr double kFracDurationMax = 0.12;
+constexpr double kPi = 3.141592653589793;
+
+constexpr size_t kLdsPerCU = 160 * 1024;
+constexpr int kHeaderBytes = 528;  // must match kHeader in tls_kernels.hip.h
+
+std::string g_create_error;  // tls_last_error(NULL)
+
+// grid.py:9-32 with the reference's operation order (libm pow, as CPython does)
+double t14(double R_s, double M_s, double P, bool small) {
+    P = P * kSecondsPerDay;
+    R_s = kRsun * R_s;
+    M_s = kMsun * M_s;
+    const double chord = std::pow((4 * P) / (kPi * kG * M_s), 1.0 / 3);
+    const double T14max = small ? R_s * chord : (R_s + 2 * kRjup) * chord;
+    double result = T14max / P;
+    if (result > kFracDurationMax) result = kFracDurationMax;
+    return result;
+}
+
+template <typename T>
+struct DevBuf {
+    T* ptr = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n_elem) {
+        if (n_elem <= cap) return hipSuccess;
+        if (ptr) { hipError_t e = hipFree(ptr); ptr = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), std::max<size_t>(n_elem, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n_elem;
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct tls_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    std::string name;
+    int n_cu = 0;
+
+    // device-resident plan
+    DevBuf<double> d_t, d_y, d_w, d_periods, d_q, d_chi2, d_depth, d_scratch, d_pack, d_gather, d_scalar;
+    DevBuf<long long> d_row;
+    DevBuf<int> d_order, d_dlo, d_dhi;
+    DevBuf<tlsdev::WidthEntry> d_widths;
+    DevBuf<unsigned long long> d_counters;
+    DevBuf<unsigned int> d_queue;
+
+    // host-side plan
+    bool prepared = false, executed = false;
+    bool uniform_w = true, resident = true;
+    int n = 0, W = 0, M = 0, n_periods = 0, n_widths = 0, nb = 0;
+    int threads = 512, blocks = 0;
+    size_t lds_bytes = 0;
+    double S0 = 0, w0 = 1, depth_min = 0;
+    tls_counters plan_counters = {0, 0, 0, 0};
+    bool counted = false;
+    std::vector<double> h_t;  // kept for tls_update_flux validation (size only)
+
+    // RCCL
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+};
+
+namespace {
+
+int fail(tls_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define TLS_HIP(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(ctx, TLS_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define TLS_NCCL(ctx, call)                                                             \
+    do {                                                                                \
+        ncclResult_t r_ = (call);                                                       \
+        if (r_ != ncclSuccess)                                                          \
+            return fail(ctx, TLS_E_RCCL, std::string(#call) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+
+template <typename T>
+int upload(tls_ctx* ctx, DevBuf<T>& buf, const T* host, size_t count) {
+    TLS_HIP(ctx, buf.reserve(count));
+    if (count)
+        TLS_HIP(ctx, hipMemcpyAsync(buf.ptr, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return TLS_OK;
+}
+
+// weights and the period-independent constant S0 = sum (1-y)^2 / dy^2
+void weights_from(const double* y, const double* dy, int64_t n, bool& uniform, double& w0,
+                  std::vector<double>& w, double& S0) {
+    uniform = true;
+    for (int64_t i = 1; i < n; ++i)
+        if (dy[i] != dy[0]) { uniform = false; break; }
+    long double acc = 0.0L;
+    if (uniform) {
+        w0 = 1 / (dy[0] * dy[0]);  // core.py:127
+        w.clear();
+        for (int64_t i = 0; i < n; ++i) acc += (long double)((1 - y[i]) * (1 - y[i])) * w0;
+    } else {
+        w0 = 1.0;
+        w.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            w[(size_t)i] = 1 / (dy[i] * dy[i]);
+            acc += (long double)((1 - y[i]) * (1 - y[i])) * w[(size_t)i];
+        }
+    }
+    S0 = (double)acc;
+}
+
+template <bool RES, bool UNI, typename IdxT>
+hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
+    auto kernel = tlsdev::tls_search_kernel<RES, UNI, IdxT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->blocks), dim3((unsigned)ctx->threads), ctx->lds_bytes,
+                       ctx->stream, args);
+    return hipGetLastError();
+}
+
+int enqueue(tls_ctx* ctx, bool count_work) {
+    TLS_HIP(ctx, hipMemsetAsync(ctx->d_queue.ptr, 0, sizeof(unsigned int), ctx->stream));
+    if (count_work)
+        TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    tlsdev::SearchArgs a;
+    a.t = ctx->d_t.ptr; a.y = ctx->d_y.ptr; a.w = ctx->uniform_w ? nullptr : ctx->d_w.ptr;
+    a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.dlo = ctx->d_dlo.ptr; a.dhi = ctx->d_dhi.ptr;
+    a.widths = ctx->d_widths.ptr; a.q = ctx->d_q.ptr;
+    a.out_chi2 = ctx->d_chi2.ptr; a.out_row = ctx->d_row.ptr; a.out_depth = ctx->d_depth.ptr;
+    a.counters = count_work ? ctx->d_counters.ptr : nullptr;
+    a.queue = ctx->d_queue.ptr;
+    a.scratch = ctx->d_scratch.ptr;
+    a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1);
+    a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
+    a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
+    a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
+    hipError_t e;
+    if (ctx->resident)
+        e = ctx->uniform_w ? launch_variant<true, true, unsigned short>(ctx, a)
+                           : launch_variant<true, false, unsigned short>(ctx, a);
+    else
+        e = ctx->uniform_w ? launch_variant<false, true, unsigned int>(ctx, a)
+                           : launch_variant<false, false, unsigned int>(ctx, a);
+    if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    ctx->executed = true;
+    ctx->counted = count_work;
+    return TLS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tls_version(void) { return "tls_amd 0.1 (gfx950)"; }
+
+int tls_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return TLS_E_HIP; }
+    return n;
+}
+
+const char* tls_last_error(const tls_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+const char* tls_device_name(const tls_ctx* ctx) { return ctx ? ctx->name.c_str() : ""; }
+
+tls_ctx* tls_ctx_create(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no usable GPU (hipGetDeviceCount: ") + hipGetErrorString(e) +
+                         "); this library has no CPU fallback";
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= n) {
+        g_create_error = "device_id " + std::to_string(device_id) + " out of range (" + std::to_string(n) + " GPUs)";
+        return nullptr;
+    }
+    tls_ctx* ctx = new (std::nothrow) tls_ctx();
+    if (!ctx) { g_create_error = "out of host memory"; return nullptr; }
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+        g_create_error = std::string("context setup: ") + hipGetErrorString(e);
+        delete ctx;
+        return nullptr;
+    }
+    ctx->n_cu = prop.multiProcessorCount;
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s %s, %d CUs, %.0f GiB", prop.gcnArchName, prop.name, ctx->n_cu,
+                  (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    ctx->name = buf;
+    return ctx;
+}
+
+void tls_ctx_destroy(tls_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->d_t.release(); ctx->d_y.release(); ctx->d_w.release(); ctx->d_periods.release(); ctx->d_q.release();
+    ctx->d_chi2.release(); ctx->d_depth.release(); ctx->d_scratch.release(); ctx->d_pack.release();
+    ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_row.release(); ctx->d_order.release();
+    ctx->d_dlo.release(); ctx->d_dhi.release(); ctx->d_widths.release(); ctx->d_counters.release();
+    ctx->d_queue.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n,
+                const double* periods, int64_t n_periods, const tls_template* tmpl, const tls_params* params) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    ctx->prepared = false; ctx->executed = false;
+    if (!t || !y || !dy || !periods || !tmpl || !params) return fail(ctx, TLS_E_ARG, "null argument");
+    if (n < 3 || n > 50000000) return fail(ctx, TLS_E_ARG, "n out of range (need 3 <= n <= 5e7)");
+    if (n_periods < 0 || n_periods > 100000000) return fail(ctx, TLS_E_ARG, "n_periods out of range");
+    if (tmpl->n_rows < 1 || !tmpl->values || !tmpl->offset || !tmpl->length || !tmpl->width || !tmpl->overshoot)
+        return fail(ctx, TLS_E_ARG, "empty template table");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+
+    // distinct widths ascending, first row per width (core.py:113, 163-165)
+    std::vector<int64_t> rows((size_t)tmpl->n_rows);
+    std::iota(rows.begin(), rows.end(), 0);
+    std::stable_sort(rows.begin(), rows.end(), [&](int64_t a, int64_t b) { return tmpl->width[a] < tmpl->width[b]; });
+    std::vector<tlsdev::WidthEntry> widths;
+    std::vector<double> q;
+    double margin = params->T0_fit_margin;
+    for (int64_t r : rows) {
+        const int64_t wd = tmpl->width[r];
+        if (!widths.empty() && widths.back().width == wd) continue;  // later duplicates never used
+        if (wd < 1 || wd > n) return fail(ctx, TLS_E_ARG, "template width out of range [1, n]");
+        const int64_t len = tmpl->length[r];
+        if (len < 1 || len > wd) return fail(ctx, TLS_E_ARG, "template row longer than its width");
+        tlsdev::WidthEntry we;
+        we.width = (int)wd; we.row = (int)r; we.q_offset = (int)q.size(); we.q_len = (int)len; we.pad = 0;
+        we.xth = 1;
+        if (margin > 0 && (double)wd > margin) {  // core.py:50-55
+            const double inv = 1 / margin;
+            int xth = (int)((double)wd / inv);
+            we.xth = xth < 1 ? 1 : xth;
+        }
+        we.overshoot = tmpl->overshoot[r];
+        double s2 = 0.0;
+        for (int64_t j = 0; j < len; ++j) {
+            const double qj = 1 - tmpl->values[tmpl->offset[r] + j];  // core.py:68
+            q.push_back(qj);
+            s2 += qj * qj;
+        }
+        we.sum_q2 = s2;
+        widths.push_back(we);
+    }
+    int64_t W = widths.back().width;  // core.py:114-116
+    if (W % 2 != 0) W += 1;
+    const int64_t M = n + W;
+    if (M + 1 > 0x7fffffff / 4) return fail(ctx, TLS_E_ARG, "series too long");
+
+    // per-period duration window (core.py:143-156) and cost
+    double t_min = t[0], t_max = t[0];
+    for (int64_t i = 1; i < n; ++i) { t_min = std::min(t_min, t[i]); t_max = std::max(t_max, t[i]); }
+    std::vector<int> dlo((size_t)n_periods), dhi((size_t)n_periods), order((size_t)n_periods);
+    std::vector<int64_t> cost((size_t)n_periods);
+    tls_counters pc = {0, 0, 0, 0};
+    const double length = t_max - t_min;
+    for (int64_t p = 0; p < n_periods; ++p) {
+        const double P = periods[p];
+        if (!(P > 0) || !std::isfinite(P)) return fail(ctx, TLS_E_ARG, "periods must be positive and finite");
+        const double duration_max = t14(params->R_star_max, params->M_star_max, P, false);
+        const double duration_min = t14(params->R_star_min, params->M_star_min, P, true);
+        const double naive = length / P;
+        const double correction = (naive + 1) / naive;
+        const double lo = std::floor(duration_min * (double)n);
+        const double hi = std::ceil(duration_max * (double)n * correction);
+        dlo[(size_t)p] = (int)std::max(-2.0e9, std::min(2.0e9, lo));
+        dhi[(size_t)p] = (int)std::max(-2.0e9, std::min(2.0e9, hi));
+        int64_t c = 0;
+        for (const auto& we : widths)
+            if (we.width >= dlo[(size_t)p] && we.width <= dhi[(size_t)p]) {
+                c += (M - we.width) / we.xth + 1;
+                pc.pd_pairs += 1;
+            }
+        cost[(size_t)p] = c;
+        pc.grid_cells += c;
+    }
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+
+    // weights
+    std::vector<double> w;
+    bool uniform; double w0, S0;
+    weights_from(y, dy, n, uniform, w0, w, S0);
+
+    // launch geometry
+    const size_t regions = uniform ? 2 : 3;
+    const size_t resident_bytes = kHeaderBytes + regions * 8 * (size_t)(M + 1);
+    ctx->resident = resident_bytes <= kLdsPerCU && n <= 65535;
+    if (ctx->resident) {
+        ctx->nb = (int)n;
+        ctx->lds_bytes = resident_bytes;
+        const size_t per_cu = kLdsPerCU / resident_bytes;
+        ctx->threads = per_cu >= 2 ? 512 : 1024;
+        const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)ctx->threads);
+        ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)wg_per_cu * ctx->n_cu);
+    } else {
+        ctx->nb = (int)std::min<int64_t>(n, 16384);
+        ctx->lds_bytes = kHeaderBytes + 4 * (size_t)ctx->nb;
+        ctx->threads = 512;
+        ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)2 * ctx->n_cu);
+        TLS_HIP(ctx, ctx->d_scratch.reserve((size_t)ctx->blocks * regions * (size_t)(M + 1)));
+    }
+
+    ctx->n = (int)n; ctx->W = (int)W; ctx->M = (int)M; ctx->n_periods = (int)n_periods;
+    ctx->n_widths = (int)widths.size();
+    ctx->uniform_w = uniform; ctx->w0 = w0; ctx->S0 = S0; ctx->depth_min = params->transit_depth_min;
+    ctx->plan_counters = pc;
+
+    int rc;
+    if ((rc = upload(ctx, ctx->d_t, t, (size_t)n))) return rc;
+    if ((rc = upload(ctx, ctx->d_y, y, (size_t)n))) return rc;
+    if (!uniform && (rc = upload(ctx, ctx->d_w, w.data(), (size_t)n))) return rc;
+    if ((rc = upload(ctx, ctx->d_periods, periods, (size_t)n_periods))) return rc;
+    if ((rc = upload(ctx, ctx->d_order, order.data(), (size_t)n_periods))) return rc;
+    if ((rc = upload(ctx, ctx->d_dlo, dlo.data(), (size_t)n_periods))) return rc;
+    if ((rc = upload(ctx, ctx->d_dhi, dhi.data(), (size_t)n_periods))) return rc;
+    if ((rc = upload(ctx, ctx->d_widths, widths.data(), widths.size()))) return rc;
+    if ((rc = upload(ctx, ctx->d_q, q.data(), q.size()))) return rc;
+    TLS_HIP(ctx, ctx->d_chi2.reserve((size_t)n_periods));
+    TLS_HIP(ctx, ctx->d_row.reserve((size_t)n_periods));
+    TLS_HIP(ctx, ctx->d_depth.reserve((size_t)n_periods));
+    TLS_HIP(ctx, ctx->d_counters.reserve(2));
+    TLS_HIP(ctx, ctx->d_queue.reserve(1));
+    // the host staging vectors die at return: wait for the copies
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prepared = true;
+    return TLS_OK;
+}
+
+int tls_update_flux(tls_ctx* ctx, const double* y, const double* dy) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->prepared) return fail(ctx, TLS_E_STATE, "tls_update_flux before tls_prepare");
+    if (!y || !dy) return fail(ctx, TLS_E_ARG, "null argument");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> w;
+    bool uniform; double w0, S0;
+    weights_from(y, dy, ctx->n, uniform, w0, w, S0);
+    if (uniform != ctx->uniform_w)
+        return fail(ctx, TLS_E_STATE, "weight structure (uniform / per-point dy) differs from the prepared search");
+    ctx->w0 = w0; ctx->S0 = S0;
+    int rc;
+    if ((rc = upload(ctx, ctx->d_y, y, (size_t)ctx->n))) return rc;
+    if (!uniform && (rc = upload(ctx, ctx->d_w, w.data(), (size_t)ctx->n))) return rc;
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->executed = false;
+    return TLS_OK;
+}
+
+int tls_execute(tls_ctx* ctx, int count_work) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->prepared) return fail(ctx, TLS_E_STATE, "tls_execute before tls_prepare");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->n_periods == 0) { ctx->executed = true; return TLS_OK; }
+    return enqueue(ctx, count_work != 0);
+}
+
+int tls_synchronize(tls_ctx* ctx) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TLS_OK;
+}
+
+int tls_execute_timed(tls_ctx* ctx, int reps, double* ms_per_execute) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->prepared) return fail(ctx, TLS_E_STATE, "tls_execute_timed before tls_prepare");
+    if (reps < 1 || !ms_per_execute) return fail(ctx, TLS_E_ARG, "reps must be >= 1");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->n_periods == 0) { *ms_per_execute = 0; return TLS_OK; }
+    TLS_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r) {
+        int rc = enqueue(ctx, false);
+        if (rc) return rc;
+    }
+    TLS_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    TLS_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    TLS_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_per_execute = (double)ms / reps;
+    return TLS_OK;
+}
+
+int tls_fetch(tls_ctx* ctx, double* out_chi2, int64_t* out_row, double* out_depth, tls_counters* counters) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->executed) return fail(ctx, TLS_E_STATE, "tls_fetch before tls_execute");
+    if (!out_chi2 || !out_row || !out_depth) return fail(ctx, TLS_E_ARG, "null output");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t np = (size_t)ctx->n_periods;
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64 layout");
+    if (np) {
+        TLS_HIP(ctx, hipMemcpyAsync(out_chi2, ctx->d_chi2.ptr, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(out_row, ctx->d_row.ptr, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(out_depth, ctx->d_depth.ptr, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    unsigned long long dev_counts[2] = {0, 0};
+    if (counters && ctx->counted && np)
+        TLS_HIP(ctx, hipMemcpyAsync(dev_counts, ctx->d_counters.ptr, sizeof dev_counts, hipMemcpyDeviceToHost, ctx->stream));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (counters) {
+        *counters = ctx->plan_counters;
+        counters->evaluated_cells = ctx->counted ? (int64_t)dev_counts[0] : -1;
+        counters->inner_steps = ctx->counted ? (int64_t)dev_counts[1] : -1;
+    }
+    return TLS_OK;
+}
+
+int tls_plan_info(const tls_ctx* ctx, tls_counters* counters, int64_t* lds_bytes, int64_t* n_blocks, int64_t* resident) {
+    if (!ctx || !ctx->prepared) return TLS_E_STATE;
+    if (counters) { *counters = ctx->plan_counters; counters->evaluated_cells = -1; counters->inner_steps = -1; }
+    if (lds_bytes) *lds_bytes = (int64_t)ctx->lds_bytes;
+    if (n_blocks) *n_blocks = ctx->blocks;
+    if (resident) *resident = ctx->resident ? 1 : 0;
+    return TLS_OK;
+}
+
+int tls_search(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n, const double* periods,
+               int64_t n_periods, const tls_template* tmpl, const tls_params* params, double* out_chi2,
+               int64_t* out_row, double* out_depth, tls_counters* counters) {
+    int rc = tls_prepare(ctx, t, y, dy, n, periods, n_periods, tmpl, params);
+    if (rc) return rc;
+    if ((rc = tls_execute(ctx, counters != nullptr))) return rc;
+    return tls_fetch(ctx, out_chi2, out_row, out_depth, counters);
+}
+
+// ---- RCCL ---------------------------------------------------------------------------
+int tls_comm_unique_id(char id_out[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r); return TLS_E_RCCL; }
+    std::memcpy(id_out, &id, 128);
+    return TLS_OK;
+}
+
+int tls_comm_init(tls_ctx* ctx, int n_ranks, int rank, const char id[128]) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || !id) return fail(ctx, TLS_E_ARG, "bad rank layout");
+    if (ctx->comm) return fail(ctx, TLS_E_STATE, "communicator already initialised");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, 128);
+    TLS_NCCL(ctx, ncclCommInitRank(&ctx->comm, n_ranks, uid, rank));
+    ctx->n_ranks = n_ranks; ctx->rank = rank;
+    TLS_HIP(ctx, ctx->d_scalar.reserve(2));
+    return TLS_OK;
+}
+
+int tls_comm_destroy(tls_ctx* ctx) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (ctx->comm) { TLS_NCCL(ctx, ncclCommDestroy(ctx->comm)); ctx->comm = nullptr; }
+    ctx->n_ranks = 1; ctx->rank = 0;
+    return TLS_OK;
+}
+
+int tls_comm_allgather_results(tls_ctx* ctx, int64_t count_per_rank, double* all_chi2, int64_t* all_row, double* all_depth) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->comm) return fail(ctx, TLS_E_STATE, "tls_comm_init first");
+    if (!ctx->executed) return fail(ctx, TLS_E_STATE, "all-gather before tls_execute");
+    if (count_per_rank < ctx->n_periods || count_per_rank < 1) return fail(ctx, TLS_E_ARG, "count_per_rank smaller than this rank's shard");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t c = (size_t)count_per_rank, np = (size_t)ctx->n_periods, R = (size_t)ctx->n_ranks;
+    // pack [chi2 | row | depth] of this shard, zero padded: 24 B per period
+    TLS_HIP(ctx, ctx->d_pack.reserve(3 * c));
+    TLS_HIP(ctx, ctx->d_gather.reserve(3 * c * R));
+    TLS_HIP(ctx, hipMemsetAsync(ctx->d_pack.ptr, 0, 3 * c * 8, ctx->stream));
+    if (np) {
+        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_pack.ptr, ctx->d_chi2.ptr, np * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_pack.ptr + c, ctx->d_row.ptr, np * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_pack.ptr + 2 * c, ctx->d_depth.ptr, np * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    TLS_NCCL(ctx, ncclAllGather(ctx->d_pack.ptr, ctx->d_gather.ptr, 3 * c, ncclDouble, ctx->comm, ctx->stream));
+    std::vector<double> host(3 * c * R);
+    TLS_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_gather.ptr, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t r = 0; r < R; ++r) {
+        const double* blk = host.data() + r * 3 * c;
+        std::memcpy(all_chi2 + r * c, blk, c * 8);
+        std::memcpy(all_row + r * c, blk + c, c * 8);  // int64 bit patterns travel as 8-byte words
+        std::memcpy(all_depth + r * c, blk + 2 * c, c * 8);
+    }
+    return TLS_OK;
+}
+
+int tls_comm_max(tls_ctx* ctx, double* value_inout) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->comm) return fail(ctx, TLS_E_STATE, "tls_comm_init first");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    TLS_HIP(ctx, hipMemcpyAsync(ctx->d_scalar.ptr, value_inout, 8, hipMemcpyHostToDevice, ctx->stream));
+    TLS_NCCL(ctx, ncclAllReduce(ctx->d_scalar.ptr, ctx->d_scalar.ptr + 1, 1, ncclDouble, ncclMax, ctx->comm, ctx->stream));
+    TLS_HIP(ctx, hipMemcpyAsync(value_inout, ctx->d_scalar.ptr + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TLS_OK;
+}
+
+int tls_comm_barrier(tls_ctx* ctx) {
+    double v = 0;
+    return tls_comm_max(ctx, &v);
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+"""Synthetic light curves of the benchmark configurations (SURVEY.md section 8d,
+BASELINE.json `configs`): Tutorial-01 planet injected into white noise.
+
+Generator: numpy.random.seed(seed) (legacy RandomState stream), t = linspace(3.14,
+3.14 + span, int(span * cadence_per_day)), planet t0 = 3.14, per = 10.123 d,
+rp = 6371/696342, a = 19, inc = 90, quadratic limb darkening [0.4, 0.4]
+(reference tutorials/01 Quick start with synthetic data.ipynb:23-48).
+"""
+import numpy
+
+from . import transit_model
+
+TIME_START = 3.14
+
+CONFIGS = {
+    # name: (span [d], cadences per day, noise sigma, power() kwargs)
+    "tutorial01": (100.0, 48, 50e-6, {}),
+    "k2_90d": (90.0, 48, 50e-6, {}),
+    "kepler_4yr": (1461.0, 48, 50e-6, {"period_min": 0.5, "period_max": 400}),
+    "tess_27d": (27.0, 720, 200e-6, {}),
+}
+
+
+def light_curve(span_days, cadence_per_day, sigma, seed=0, per=10.123, rp=6371 / 696342,
+                a=19, inc=90, u=(0.4, 0.4)):
+    """(t, flux) with the planet injected and Gaussian noise of std `sigma`."""
+    numpy.random.seed(seed)
+    n = int(span_days * cadence_per_day)
+    t = numpy.linspace(TIME_START, TIME_START + span_days, n)
+    signal = transit_model.light_curve(t, TIME_START, per, rp, a, inc, 0, 90, list(u), "quadratic")
+    flux = signal + numpy.random.normal(0, sigma, n)
+    return t, flux
+
+
+def config(name, seed=0, sigma=None):
+    """(t, flux, power_kwargs) of a named benchmark configuration."""
+    span, cadence, sig, kwargs = CONFIGS[name]
+    t, flux = light_curve(span, cadence, sig if sigma is None else sigma, seed=seed)
+    return t, flux, dict(kwargs)
+
+
+def search_inputs(t, flux, dy=None, **kwargs):
+    """Everything the batched search takes for (t, flux[, dy]) under power(**kwargs):
+    returns dict(t, y, dy, periods (ascending), table, params).  Host-side only."""
+    from .api import transitleastsquares
+    from .template import TemplateTable
+    from .validate import validate_args
+
+    model = transitleastsquares(t, flux, dy, verbose=False)
+    kwargs = dict(kwargs)
+    kwargs.setdefault("verbose", False)
+    validate_args(model, kwargs)
+    periods, durations, overview, rows = model._build_grids()
+    params = dict(transit_depth_min=model.transit_depth_min, R_star_min=model.R_star_min,
+                  R_star_max=model.R_star_max, M_star_min=model.M_star_min,
+                  M_star_max=model.M_star_max, T0_fit_margin=model.T0_fit_margin)
+    return dict(t=model.t, y=model.y, dy=model.dy, periods=numpy.sort(periods),
+                table=TemplateTable(overview, rows), params=params, overview=overview,
+                rows=rows, durations=durations)
