@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Benchmark of the TLS grid-search hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config k2_90d] [--mode survey|shard]
+
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Rank 0
+prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM: the full period x duration x T0 grid search of BASELINE.json's config 2 (90 d,
+30-min cadence, default grids: 9679 periods, 8.77e8 trial cells).
+  * survey mode (default; BASELINE config 5): every GPU searches one light curve per step
+    (its own seed) and the per-period (chi2, row, depth) triples are all-gathered over RCCL so
+    that every rank holds the whole batch -> per-GPU work is fixed, "scaling": "weak".
+  * shard mode (BASELINE config 4 layout): ONE light curve per step, its period grid block-
+    partitioned over the GPUs by cumulative cell cost, one RCCL all-gather at the end
+    -> "scaling": "strong".
+value = trial cells of the whole job / wall time of the K timed steps (barrier + device sync on
+both sides, max over ranks).  `roofline` prices the search kernel against HBM with the
+algorithmic bytes of SURVEY.md 8(d) (24*N + 24 B per period) and its HIP-event duration, and
+also reports the fp64 vector rate -- this path is compute/LDS bound, not HBM bound.
+`cpu_baseline` is the C oracle (a port of core.py, OpenMP over periods) timed on this box's
+host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from tls_amd import _lib, rendezvous, shard, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TF = 78.6   # SURVEY.md section 7 (vector fp64, no MFMA on this path)
+
+
+def cpu_baseline(inp, grid_cells, budget_s=20.0):
+    """Oracle (port of the reference path) on the host cores, bounded sample."""
+    import oracle
+    lib = oracle.OracleLibrary()
+    p = inp["params"]
+    cores = os.cpu_count() or 1
+
+    def run(periods):
+        t0 = time.perf_counter()
+        out = lib.search(inp["t"], inp["y"], inp["dy"], periods, inp["table"],
+                         p["transit_depth_min"], p["R_star_min"], p["R_star_max"],
+                         p["M_star_min"], p["M_star_max"], p["T0_fit_margin"], n_threads=0)
+        return time.perf_counter() - t0, int(out[3][0])
+
+    periods = inp["periods"]
+    probe = periods[:: max(1, len(periods) // (4 * cores))]
+    dt, cells = run(probe)           # also warms the OpenMP pool
+    dt, cells = run(probe)
+    est_full = dt * grid_cells / max(cells, 1)
+    stride = max(1, int(numpy.ceil(est_full / budget_s)))
+    sample = periods[::stride]
+    dt, cells = run(sample)
+    return {"value": cells / dt, "unit": "trial cells/s", "cores": cores, "kind": "port",
+            "sample": "%d of %d periods (every %d%s) of the same light curve, %.1f s, "
+                      "oracle/tls_oracle.c -O2 OpenMP dynamic over periods"
+                      % (len(sample), len(periods), stride, "th" if stride > 1 else "st", dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="k2_90d", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--sigma", type=float, default=None, help="noise override (e.g. 500e-6)")
+    ap.add_argument("--mode", default="survey", choices=["survey", "shard"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local_rank, addr, port = rendezvous.env_layout()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "(--nproc-per-node %d)" % (args.gpus, args.gpus))
+        args.gpus = world
+    n_dev = _lib.device_count()
+    ctx = _lib.Context(local_rank % max(n_dev, 1))
+    if world > 1:
+        uid = rendezvous.share_unique_id(rank, world, addr, port, ctx.comm_unique_id)
+        ctx.comm_init(world, rank, uid)
+
+    # ---- synthetic input, resident in HBM before the timed region --------------------
+    seed = rank if args.mode == "survey" else 0
+    t, flux, kw = synthetic.config(args.config, seed=seed, sigma=args.sigma)
+    inp = synthetic.search_inputs(t, flux, **kw)
+    periods = inp["periods"]
+    if args.mode == "shard" and world > 1:
+        job = shard.ShardedSearch(rank, world)
+        lo, hi = job.plan(inp["t"], periods, inp["table"], inp["params"])
+        my_periods = periods[lo:hi]
+        count_per_rank = job.count_per_rank
+        job_cells = int(numpy.sum(job.costs))
+    else:
+        my_periods = periods
+        count_per_rank = len(periods)
+        job_cells = None
+    ctx.prepare(inp["t"], inp["y"], inp["dy"], my_periods, inp["table"], inp["params"])
+    info = ctx.plan_info()
+    if job_cells is None:
+        job_cells = info["grid_cells"] * world  # survey: one full grid per GPU per step
+
+    def step():
+        ctx.execute()
+        if world > 1:
+            ctx.comm_allgather_results(count_per_rank, world)  # results on every rank
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    ctx.kernel_timing(reset=True)
+    if world > 1:
+        ctx.comm_barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    if world > 1:
+        ctx.comm_barrier()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.kernel_timing(reset=True)
+    if world > 1:
+        elapsed = ctx.comm_max(elapsed)
+        kernel_ms = ctx.comm_max(kernel_ms)
+
+    # one counted pass (outside the timed region) for the work statistics
+    ctx.execute(count_work=True)
+    chi2, row, depth, counters = ctx.fetch(with_counters=True)
+
+    if rank == 0:
+        n = len(inp["t"])
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = job_cells * args.steps / elapsed
+        kernel_s = 1e-3 * kernel_ms / max(launches, 1)
+        algo_bytes = len(my_periods) * (24 * n + 24)       # B_period per period
+        achieved = algo_bytes / kernel_s / 1e9
+        flops = 6.0 * counters["inner_steps"]               # reference flop count, core.py:68-69
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            rec = json.load(open(tpath))
+            if rec.get("config") == args.config and rec.get("n_periods") == len(my_periods):
+                traffic = rec.get("bytes_per_launch")
+        out = {
+            "metric": "trial cells/sec (period x duration x T0)",
+            "value": value, "unit": "trial cells/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak" if args.mode == "survey" else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d points, %d periods x %d durations, %.3e trial cells per "
+                                   "light curve; %s" % (
+                                       args.config, n, len(periods), inp["table"].n_rows,
+                                       info["grid_cells"] if args.mode == "survey" else job_cells,
+                                       "survey mode, one light curve per GPU per step + RCCL "
+                                       "all-gather" if args.mode == "survey" else
+                                       "period grid sharded over the GPUs + RCCL all-gather"),
+                       "mode": args.mode, "sigma_ppm": 1e6 * (args.sigma or synthetic.CONFIGS[args.config][2]),
+                       "light_curves_per_step": world if args.mode == "survey" else 1,
+                       "wall_ms_per_light_curve": ms_per_step / (world if args.mode == "survey" else 1),
+                       "evaluated_cells": counters["evaluated_cells"],
+                       "inner_steps": counters["inner_steps"], "device": ctx.name,
+                       "lds_bytes_per_workgroup": info["lds_bytes"], "workgroups": info["n_blocks"],
+                       "lds_resident": info["resident"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "tls_search_kernel", "kernel_ms": 1e3 * kernel_s,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "compute/LDS-bound path: HBM floor is 24*N+24 B per period; see fp64",
+                         "fp64": {"achieved": flops / kernel_s / 1e12, "peak": FP64_VECTOR_PEAK_TF,
+                                  "unit": "TFLOP/s", "frac": flops / kernel_s / 1e12 / FP64_VECTOR_PEAK_TF,
+                                  "flops_per_launch": flops}},
+            "argmin_period_index": int(numpy.argmin(chi2)), "chi2_min": float(numpy.min(chi2)),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(inp, info["grid_cells"])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        ctx.comm_barrier()
+        ctx.comm_destroy()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,9 +102,20 @@ int tls_fetch(tls_ctx *ctx, double *out_chi2, int64_t *out_row, double *out_dept
 /* run `reps` executes back to back and report the mean duration of ONE execute in
  * milliseconds, measured with HIP events on the context's stream. */
 int tls_execute_timed(tls_ctx *ctx, int reps, double *ms_per_execute);
+/* Sum of the search-kernel durations of all executes since the last reset, from HIP
+ * events recorded around each launch on the context's stream; synchronises.  The event
+ * pool grows by one pair per execute until reset: reset regularly. */
+int tls_kernel_timing(tls_ctx *ctx, int reset, double *total_ms, int64_t *launches);
 /* data-independent work of the prepared search (no device work needed). */
 int tls_plan_info(const tls_ctx *ctx, tls_counters *counters, int64_t *lds_bytes,
                   int64_t *n_blocks, int64_t *resident /* 1: folded series kept in LDS */);
+
+/* ---- host-only planning (no GPU needed) ------------------------------------------ */
+/* Trial cells (duration x T0 positions) each period will enumerate: the data-independent
+ * cost used to place shard boundaries and to report cells/s.  Mirrors core.py:50-57,143-156. */
+int tls_grid_cells(const double *t, int64_t n, const double *periods, int64_t n_periods,
+                   const tls_template *tmpl, const tls_params *params,
+                   int64_t *cells_per_period);
 
 /* ---- multi-GPU: period grid sharded over ranks, one RCCL all-gather at the end --- */
 /* rank 0 creates the 128-byte id and hands it to the other ranks by any host channel */

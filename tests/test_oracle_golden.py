@@ -1,0 +1,51 @@
+"""The CPU oracle (oracle/tls_oracle.c) against outputs of the UNMODIFIED reference.
+
+tests/golden/search_*.npz hold inputs and outputs of the reference's
+transitleastsquares.core.search_period (core.py:96-188), generated in the build
+container by tools/gen_golden.py.  This is what pins the oracle.
+"""
+import numpy
+import pytest
+
+from conftest import SEARCH_GOLDENS, load_search_golden
+
+
+@pytest.mark.parametrize("name", SEARCH_GOLDENS)
+def test_oracle_matches_reference_search_period(oracle_lib, name):
+    g, table, params = load_search_golden(name)
+    chi2, row, depth, counters = oracle_lib.search(
+        g["t"], g["y"], g["dy"], g["periods"], table, params["transit_depth_min"],
+        params["R_star_min"], params["R_star_max"], params["M_star_min"], params["M_star_max"],
+        params["T0_fit_margin"])
+    # sequential C sums vs numpy's pairwise sums in the shimmed reference: ~1e-13
+    numpy.testing.assert_allclose(chi2, g["chi2"], rtol=1e-11, atol=0)
+    numpy.testing.assert_array_equal(row, g["row"])
+    numpy.testing.assert_allclose(depth, g["depth"], rtol=0, atol=1e-13)
+    assert counters[0] > 0
+
+
+def test_nofit_golden_is_flat():
+    g, _, _ = load_search_golden("nofit")
+    assert numpy.all(g["chi2"] == len(g["t"]))  # core.py:46 baseline, test_transit_depth_min.py:62
+    assert numpy.all(g["depth"] == 0)
+
+
+def test_oracle_t14_matches_host_python(oracle_lib):
+    from tls_amd.grid import T14
+    for P in (0.6, 3.3, 45.0, 399.0):
+        for small, R, M in ((True, 0.13, 0.1), (False, 3.5, 1.0)):
+            assert oracle_lib.t14(R, M, P, small) == T14(R_s=R, M_s=M, P=P, small=small)
+
+
+def test_oracle_fold_is_stable_argsort(oracle_lib):
+    rng = numpy.random.RandomState(3)
+    t = numpy.sort(rng.uniform(0, 50, 500))
+    t[100] = t[99]
+    t[200:204] = t[200]
+    for period in (0.7, 2.5, 13.0):
+        ph, idx = oracle_lib.fold_sort(t, period)
+        x = t / period
+        phases = x - numpy.floor(x)
+        ref = numpy.argsort(phases, kind="mergesort")  # core.py:120
+        numpy.testing.assert_array_equal(idx, ref)
+        numpy.testing.assert_array_equal(ph, phases[ref])

@@ -1,0 +1,101 @@
+"""Multi-GPU host logic on CPU: world_size-2 `gloo` process group.  Each rank plans
+the same cost-balanced period blocks, searches ITS block (with the CPU oracle
+standing in for the GPU -- test infrastructure only), all-gathers padded shards and
+assembles; every rank must end up with the single-process result."""
+import os
+import socket
+import sys
+
+import numpy
+import pytest
+
+from tls_amd import shard
+from conftest import REPO
+
+
+def test_partition_by_cost_properties():
+    rng = numpy.random.RandomState(0)
+    costs = rng.randint(1, 1000, size=997)
+    for n_ranks in (1, 2, 3, 4, 8):
+        b = shard.partition_by_cost(costs, n_ranks)
+        assert b[0] == 0 and b[-1] == len(costs) and len(b) == n_ranks + 1
+        assert numpy.all(numpy.diff(b) >= 0)
+        block = [costs[b[r]:b[r + 1]].sum() for r in range(n_ranks)]
+        assert max(block) <= costs.sum() / n_ranks + costs.max()
+    # degenerate: more ranks than periods, empty shards allowed
+    b = shard.partition_by_cost(numpy.array([5, 5, 5]), 8)
+    assert b[0] == 0 and b[-1] == 3 and numpy.all(numpy.diff(b) >= 0)
+    # assemble undoes the padding
+    bounds = numpy.array([0, 2, 2, 5])
+    padded = numpy.array([1, 2, 0, 0, 0, 0, 3, 4, 5])
+    numpy.testing.assert_array_equal(shard.assemble(padded, bounds, 3), [1, 2, 3, 4, 5])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from tls_amd import synthetic, shard as sh
+    import oracle
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t, f = synthetic.light_curve(20.0, 24, 3e-4, per=3.3, rp=0.05, a=10)
+    inp = synthetic.search_inputs(t, f, period_min=1.0, period_max=6.0)
+    periods, p = inp["periods"], inp["params"]
+    job = sh.ShardedSearch(rank, world)
+    lo, hi = job.plan(inp["t"], periods, inp["table"], p)
+    chi2, row, depth, _ = oracle.search(inp["t"], inp["y"], inp["dy"], periods[lo:hi], inp["table"],
+                                        p["transit_depth_min"], p["R_star_min"], p["R_star_max"],
+                                        p["M_star_min"], p["M_star_max"], p["T0_fit_margin"],
+                                        n_threads=2)
+
+    def gloo_allgather(count_per_rank):
+        out = []
+        for arr, dt in ((chi2, torch.float64), (row, torch.int64), (depth, torch.float64)):
+            mine = torch.zeros(count_per_rank, dtype=dt)
+            mine[: len(arr)] = torch.from_numpy(arr)
+            parts = [torch.zeros(count_per_rank, dtype=dt) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            out.append(torch.cat(parts).numpy())
+        return tuple(out)
+
+    full = job.gather(gloo_allgather)
+    numpy.savez(os.path.join(out_dir, "rank%d.npz" % rank), chi2=full[0], row=full[1],
+                depth=full[2], lo=lo, hi=hi, cells=job.my_cells())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_equals_single_process(tmp_path, oracle_lib, world):
+    import torch.multiprocessing as mp
+    from tls_amd import synthetic
+    from conftest import oracle_search
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+
+    t, f = synthetic.light_curve(20.0, 24, 3e-4, per=3.3, rp=0.05, a=10)
+    inp = synthetic.search_inputs(t, f, period_min=1.0, period_max=6.0)
+    want = oracle_search(oracle_lib, inp)
+    ranks = [numpy.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in ranks:  # every rank holds the complete, ordered result
+        numpy.testing.assert_array_equal(r["chi2"], want[0])
+        numpy.testing.assert_array_equal(r["row"], want[1])
+        numpy.testing.assert_array_equal(r["depth"], want[2])
+    # blocks tile the grid and are cost balanced
+    assert ranks[0]["lo"] == 0 and ranks[-1]["hi"] == len(inp["periods"])
+    for a, b in zip(ranks[:-1], ranks[1:]):
+        assert a["hi"] == b["lo"]
+    cells = numpy.array([int(r["cells"]) for r in ranks])
+    assert cells.max() / cells.mean() < 1.05

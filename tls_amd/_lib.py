@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libtls_amd.so")
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
     "tls_device_name", "tls_search", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_kernel_timing",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results",
     "tls_comm_barrier", "tls_comm_max",
 )
@@ -88,6 +88,10 @@ def load():
     lib.tls_execute_timed.argtypes = [vp, ci, _c_double_p]
     lib.tls_plan_info.restype = ci
     lib.tls_plan_info.argtypes = [vp, cp, _c_int64_p, _c_int64_p, _c_int64_p]
+    lib.tls_kernel_timing.restype = ci
+    lib.tls_kernel_timing.argtypes = [vp, ci, _c_double_p, _c_int64_p]
+    lib.tls_grid_cells.restype = ci
+    lib.tls_grid_cells.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, _c_int64_p]
     lib.tls_comm_unique_id.restype = ci
     lib.tls_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.tls_comm_init.restype = ci
@@ -208,6 +212,13 @@ class Context(object):
             return chi2, row, depth, c.as_dict()
         return chi2, row, depth
 
+    def kernel_timing(self, reset=True):
+        """(total ms, launches) of the search kernel since the last reset (HIP events)."""
+        ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+        self._check(self._lib.tls_kernel_timing(self._h, 1 if reset else 0, ctypes.byref(ms),
+                                                ctypes.byref(n)))
+        return ms.value, n.value
+
     def plan_info(self):
         c = Counters()
         lds, blocks, res = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
@@ -249,6 +260,19 @@ class Context(object):
         v = ctypes.c_double(float(value))
         self._check(self._lib.tls_comm_max(self._h, ctypes.byref(v)))
         return v.value
+
+
+def grid_cells(t, periods, table, params):
+    """Trial cells each period enumerates (host-only planning call, needs no GPU)."""
+    lib = load()
+    t, periods = _f8(t), _f8(periods)
+    arrays, tm, pr = Context._pack(table, params)
+    out = numpy.zeros(len(periods), dtype=numpy.int64)
+    rc = lib.tls_grid_cells(_dp(t), len(t), _dp(periods), len(periods), ctypes.byref(tm),
+                            ctypes.byref(pr), _ip(out))
+    if rc != 0:
+        raise RuntimeError("tls_amd error %d: %s" % (rc, lib.tls_last_error(None).decode()))
+    return out
 
 
 def device_count():

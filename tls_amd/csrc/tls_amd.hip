@@ -92,6 +92,10 @@ struct tls_ctx {
     bool counted = false;
     std::vector<double> h_t;  // kept for tls_update_flux validation (size only)
 
+    // per-launch kernel timing (HIP events on the context's stream)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+
     // RCCL
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
@@ -148,14 +152,82 @@ void weights_from(const double* y, const double* dy, int64_t n, bool& uniform, d
     S0 = (double)acc;
 }
 
+// Distinct trial widths ascending with the first template row of each (core.py:113,163-165),
+// their T0 stride (core.py:50-55) and, optionally, the q_j = 1 - signal_j rows.
+int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* params, int64_t n,
+                 std::vector<tlsdev::WidthEntry>& widths, std::vector<double>* q) {
+    if (!tmpl || !params) return fail(ctx, TLS_E_ARG, "null argument");
+    if (tmpl->n_rows < 1 || !tmpl->values || !tmpl->offset || !tmpl->length || !tmpl->width || !tmpl->overshoot)
+        return fail(ctx, TLS_E_ARG, "empty template table");
+    std::vector<int64_t> rows((size_t)tmpl->n_rows);
+    std::iota(rows.begin(), rows.end(), 0);
+    std::stable_sort(rows.begin(), rows.end(), [&](int64_t a, int64_t b) { return tmpl->width[a] < tmpl->width[b]; });
+    const double margin = params->T0_fit_margin;
+    size_t q_count = 0;
+    for (int64_t r : rows) {
+        const int64_t wd = tmpl->width[r];
+        if (!widths.empty() && widths.back().width == wd) continue;  // later duplicates never used
+        if (wd < 1 || wd > n) return fail(ctx, TLS_E_ARG, "template width out of range [1, n]");
+        const int64_t len = tmpl->length[r];
+        if (len < 1 || len > wd) return fail(ctx, TLS_E_ARG, "template row longer than its width");
+        tlsdev::WidthEntry we;
+        we.width = (int)wd; we.row = (int)r; we.q_offset = (int)q_count; we.q_len = (int)len; we.pad = 0;
+        we.xth = 1;
+        if (margin > 0 && (double)wd > margin) {  // core.py:50-55
+            const double inv = 1 / margin;
+            int xth = (int)((double)wd / inv);
+            we.xth = xth < 1 ? 1 : xth;
+        }
+        we.overshoot = tmpl->overshoot[r];
+        double s2 = 0.0;
+        for (int64_t j = 0; j < len; ++j) {
+            const double qj = 1 - tmpl->values[tmpl->offset[r] + j];  // core.py:68
+            if (q) q->push_back(qj);
+            s2 += qj * qj;
+        }
+        q_count += (size_t)len;
+        we.sum_q2 = s2;
+        widths.push_back(we);
+    }
+    return TLS_OK;
+}
+
+// In-range width window of one period (core.py:143-156) and its trial-cell count.
+int64_t period_window(const std::vector<tlsdev::WidthEntry>& widths, const tls_params* params, double P,
+                      double length, int64_t n, int64_t M, int& lo_out, int& hi_out, int64_t* pairs) {
+    const double duration_max = t14(params->R_star_max, params->M_star_max, P, false);
+    const double duration_min = t14(params->R_star_min, params->M_star_min, P, true);
+    const double naive = length / P;
+    const double correction = (naive + 1) / naive;
+    const double lo = std::floor(duration_min * (double)n);
+    const double hi = std::ceil(duration_max * (double)n * correction);
+    lo_out = (int)std::max(-2.0e9, std::min(2.0e9, lo));
+    hi_out = (int)std::max(-2.0e9, std::min(2.0e9, hi));
+    int64_t c = 0;
+    for (const auto& we : widths)
+        if (we.width >= lo_out && we.width <= hi_out) {
+            c += (M - we.width) / we.xth + 1;
+            if (pairs) *pairs += 1;
+        }
+    return c;
+}
+
 template <bool RES, bool UNI, typename IdxT>
 hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
     auto kernel = tlsdev::tls_search_kernel<RES, UNI, IdxT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t a, b;
+        if ((e = hipEventCreate(&a)) != hipSuccess || (e = hipEventCreate(&b)) != hipSuccess) return e;
+        ctx->ev_pool.emplace_back(a, b);
+    }
+    auto& evp = ctx->ev_pool[ctx->ev_used++];
+    if ((e = hipEventRecord(evp.first, ctx->stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->blocks), dim3((unsigned)ctx->threads), ctx->lds_bytes,
                        ctx->stream, args);
+    if ((e = hipEventRecord(evp.second, ctx->stream)) != hipSuccess) return e;
     return hipGetLastError();
 }
 
@@ -246,6 +318,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_row.release(); ctx->d_order.release();
     ctx->d_dlo.release(); ctx->d_dhi.release(); ctx->d_widths.release(); ctx->d_counters.release();
     ctx->d_queue.release();
+    for (auto& evp : ctx->ev_pool) { (void)hipEventDestroy(evp.first); (void)hipEventDestroy(evp.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -263,37 +336,9 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         return fail(ctx, TLS_E_ARG, "empty template table");
     TLS_HIP(ctx, hipSetDevice(ctx->device));
 
-    // distinct widths ascending, first row per width (core.py:113, 163-165)
-    std::vector<int64_t> rows((size_t)tmpl->n_rows);
-    std::iota(rows.begin(), rows.end(), 0);
-    std::stable_sort(rows.begin(), rows.end(), [&](int64_t a, int64_t b) { return tmpl->width[a] < tmpl->width[b]; });
     std::vector<tlsdev::WidthEntry> widths;
     std::vector<double> q;
-    double margin = params->T0_fit_margin;
-    for (int64_t r : rows) {
-        const int64_t wd = tmpl->width[r];
-        if (!widths.empty() && widths.back().width == wd) continue;  // later duplicates never used
-        if (wd < 1 || wd > n) return fail(ctx, TLS_E_ARG, "template width out of range [1, n]");
-        const int64_t len = tmpl->length[r];
-        if (len < 1 || len > wd) return fail(ctx, TLS_E_ARG, "template row longer than its width");
-        tlsdev::WidthEntry we;
-        we.width = (int)wd; we.row = (int)r; we.q_offset = (int)q.size(); we.q_len = (int)len; we.pad = 0;
-        we.xth = 1;
-        if (margin > 0 && (double)wd > margin) {  // core.py:50-55
-            const double inv = 1 / margin;
-            int xth = (int)((double)wd / inv);
-            we.xth = xth < 1 ? 1 : xth;
-        }
-        we.overshoot = tmpl->overshoot[r];
-        double s2 = 0.0;
-        for (int64_t j = 0; j < len; ++j) {
-            const double qj = 1 - tmpl->values[tmpl->offset[r] + j];  // core.py:68
-            q.push_back(qj);
-            s2 += qj * qj;
-        }
-        we.sum_q2 = s2;
-        widths.push_back(we);
-    }
+    { int rcw = build_widths(ctx, tmpl, params, n, widths, &q); if (rcw) return rcw; }
     int64_t W = widths.back().width;  // core.py:114-116
     if (W % 2 != 0) W += 1;
     const int64_t M = n + W;
@@ -309,20 +354,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     for (int64_t p = 0; p < n_periods; ++p) {
         const double P = periods[p];
         if (!(P > 0) || !std::isfinite(P)) return fail(ctx, TLS_E_ARG, "periods must be positive and finite");
-        const double duration_max = t14(params->R_star_max, params->M_star_max, P, false);
-        const double duration_min = t14(params->R_star_min, params->M_star_min, P, true);
-        const double naive = length / P;
-        const double correction = (naive + 1) / naive;
-        const double lo = std::floor(duration_min * (double)n);
-        const double hi = std::ceil(duration_max * (double)n * correction);
-        dlo[(size_t)p] = (int)std::max(-2.0e9, std::min(2.0e9, lo));
-        dhi[(size_t)p] = (int)std::max(-2.0e9, std::min(2.0e9, hi));
-        int64_t c = 0;
-        for (const auto& we : widths)
-            if (we.width >= dlo[(size_t)p] && we.width <= dhi[(size_t)p]) {
-                c += (M - we.width) / we.xth + 1;
-                pc.pd_pairs += 1;
-            }
+        const int64_t c = period_window(widths, params, P, length, n, M, dlo[(size_t)p], dhi[(size_t)p], &pc.pd_pairs);
         cost[(size_t)p] = c;
         pc.grid_cells += c;
     }
@@ -456,6 +488,22 @@ int tls_fetch(tls_ctx* ctx, double* out_chi2, int64_t* out_row, double* out_dept
     return TLS_OK;
 }
 
+int tls_kernel_timing(tls_ctx* ctx, int reset, double* total_ms, int64_t* launches) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0;
+        TLS_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        sum += ms;
+    }
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = (int64_t)ctx->ev_used;
+    if (reset) ctx->ev_used = 0;
+    return TLS_OK;
+}
+
 int tls_plan_info(const tls_ctx* ctx, tls_counters* counters, int64_t* lds_bytes, int64_t* n_blocks, int64_t* resident) {
     if (!ctx || !ctx->prepared) return TLS_E_STATE;
     if (counters) { *counters = ctx->plan_counters; counters->evaluated_cells = -1; counters->inner_steps = -1; }
@@ -472,6 +520,26 @@ int tls_search(tls_ctx* ctx, const double* t, const double* y, const double* dy,
     if (rc) return rc;
     if ((rc = tls_execute(ctx, counters != nullptr))) return rc;
     return tls_fetch(ctx, out_chi2, out_row, out_depth, counters);
+}
+
+int tls_grid_cells(const double* t, int64_t n, const double* periods, int64_t n_periods, const tls_template* tmpl,
+                   const tls_params* params, int64_t* cells_per_period) {
+    if (!t || !periods || !cells_per_period || n < 3 || n_periods < 0) {
+        g_create_error = "tls_grid_cells: invalid argument";
+        return TLS_E_ARG;
+    }
+    std::vector<tlsdev::WidthEntry> widths;
+    int rc = build_widths(nullptr, tmpl, params, n, widths, nullptr);
+    if (rc) return rc;
+    int64_t W = widths.back().width;
+    if (W % 2 != 0) W += 1;
+    double t_min = t[0], t_max = t[0];
+    for (int64_t i = 1; i < n; ++i) { t_min = std::min(t_min, t[i]); t_max = std::max(t_max, t[i]); }
+    for (int64_t p = 0; p < n_periods; ++p) {
+        int lo, hi;
+        cells_per_period[p] = period_window(widths, params, periods[p], t_max - t_min, n, n + W, lo, hi, nullptr);
+    }
+    return TLS_OK;
 }
 
 // ---- RCCL ---------------------------------------------------------------------------

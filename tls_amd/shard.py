@@ -1,0 +1,87 @@
+"""Multi-GPU mode: the period grid block-partitioned over ranks (one process per
+GPU), each rank searching its contiguous block, ONE all-gather of the per-period
+(chi2, row, depth) triples at the end.
+
+The reference's only parallelism is exactly this data parallelism over periods
+(a multiprocessing pool, main.py:140-163); periods are independent, so there is
+no exchange inside the search.  Block boundaries are placed by cumulative trial-
+cell cost, not by count: cells per period vary 4x across the grid.
+
+The collective is pluggable so the host logic can be exercised without GPUs:
+`RcclGather` (product: ncclAllGather through the C ABI) or any callable with the
+same signature (tests use torch.distributed/gloo).
+"""
+import numpy
+
+from . import _lib
+
+
+def partition_by_cost(costs, n_ranks):
+    """Boundaries b[0..n_ranks] of contiguous blocks with near-equal summed cost:
+    rank r owns periods[b[r]:b[r+1]].  Deterministic, identical on every rank."""
+    costs = numpy.asarray(costs, dtype=numpy.float64)
+    n = len(costs)
+    csum = numpy.concatenate([[0.0], numpy.cumsum(costs)])
+    total = csum[-1]
+    bounds = [0]
+    for r in range(1, n_ranks):
+        target = total * r / n_ranks
+        k = int(numpy.searchsorted(csum, target, side="left"))
+        # pick the neighbour closer to the target, keep blocks non-decreasing
+        if k > 0 and (k > n or abs(csum[k - 1] - target) <= abs(csum[min(k, n)] - target)):
+            k -= 1
+        bounds.append(min(max(k, bounds[-1]), n))
+    bounds.append(n)
+    return numpy.asarray(bounds, dtype=numpy.int64)
+
+
+def assemble(gathered, bounds, count_per_rank):
+    """Undo the padding of an all-gather: `gathered` has n_ranks blocks of
+    count_per_rank entries; block r carries bounds[r+1]-bounds[r] valid ones."""
+    parts = []
+    for r in range(len(bounds) - 1):
+        size = int(bounds[r + 1] - bounds[r])
+        parts.append(gathered[r * count_per_rank: r * count_per_rank + size])
+    return numpy.concatenate(parts) if parts else gathered[:0]
+
+
+class RcclGather(object):
+    """All-gather of device-resident results over RCCL (tls_comm_allgather_results)."""
+
+    def __init__(self, context, n_ranks):
+        self.context, self.n_ranks = context, n_ranks
+
+    def __call__(self, count_per_rank):
+        return self.context.comm_allgather_results(count_per_rank, self.n_ranks)
+
+
+class ShardedSearch(object):
+    """One rank's view of a period-sharded search.
+
+    plan(...)     decide the blocks (same on every rank), prepare this rank's block
+    run()         execute on this rank's GPU (asynchronous)
+    gather(fn)    all-gather + assemble -> full chi2/row/depth on every rank
+    """
+
+    def __init__(self, rank, n_ranks):
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+        self.bounds = None
+        self.count_per_rank = 0
+        self.costs = None
+
+    def plan(self, t, periods, table, params):
+        self.costs = _lib.grid_cells(t, periods, table, params)
+        self.bounds = partition_by_cost(self.costs, self.n_ranks)
+        self.count_per_rank = max(1, int(numpy.max(numpy.diff(self.bounds))))
+        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        return int(lo), int(hi)
+
+    def my_cells(self):
+        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        return int(numpy.sum(self.costs[lo:hi]))
+
+    def gather(self, allgather):
+        chi2, row, depth = allgather(self.count_per_rank)
+        c = self.count_per_rank
+        return (assemble(chi2, self.bounds, c), assemble(row, self.bounds, c),
+                assemble(depth, self.bounds, c))
