@@ -92,8 +92,16 @@ int tls_prepare(tls_ctx *ctx, const double *t, const double *y, const double *dy
  * survey mode streams many light curves through one prepared plan. */
 int tls_update_flux(tls_ctx *ctx, const double *y, const double *dy);
 /* execute: enqueue the search kernels on the context's stream (asynchronous).
- * count_work != 0 also accumulates evaluated_cells/inner_steps (slower). */
+ * count_work & 1 also accumulates evaluated_cells/inner_steps (slower). */
 int tls_execute(tls_ctx *ctx, int count_work);
+/* developer instrumentation: tls_execute(ctx, 2) makes thread 0 of every workgroup stamp
+ * the shader clock at phase boundaries; this returns the per-phase cycle sums (phases:
+ * fold+count, scan, scatter, rank, gather+patch, cumsum, search, reduce). */
+int tls_debug_phase_cycles(tls_ctx *ctx, uint64_t *cycles, int n);
+/* developer/test entry: the kernel's exact parallel evaluation of the sequential fp64 prefix
+ * sum (numpy.cumsum order, helpers.py:72) on an arbitrary series of non-negative values;
+ * out has count + 1 entries, out[0] = 0. */
+int tls_debug_cumsum(tls_ctx *ctx, const double *f, int64_t count, double *out, int threads);
 /* block until the stream is idle */
 int tls_synchronize(tls_ctx *ctx);
 /* fetch: copy results (and counters, may be NULL) back; synchronises. */

@@ -176,24 +176,30 @@ def test_edge_cases(gpu, oracle_lib):
     got = gpu.search(*args, one, inp["table"], inp["params"])
     want = oracle_search(oracle_lib, inp, periods=one)
     assert_parity(got, want, len(inp["t"]))
-    # periods so long that no duration is in range -> inf, row 0, depth 0 (core.py:139-140)
-    params = dict(inp["params"], R_star_max=0.131, M_star_max=1.0, R_star_min=0.13)
-    long_p = numpy.array([2000.0, 5000.0])
-    got = gpu.search(*args, long_p, inp["table"], params)
-    want = oracle_lib.search(*args, long_p, inp["table"], params["transit_depth_min"],
-                             params["R_star_min"], params["R_star_max"], params["M_star_min"],
-                             params["M_star_max"], params["T0_fit_margin"])
-    numpy.testing.assert_array_equal(got[0], want[0])
-    numpy.testing.assert_array_equal(got[1], want[1])
-    # tiny light curve (ragged: n not a multiple of anything)
-    rng = numpy.random.RandomState(0)
-    t = numpy.sort(rng.uniform(0, 20, 37))
-    y = 1 + rng.normal(0, 1e-3, 37)
-    small = synthetic.search_inputs(t, y, period_min=1.0, period_max=5.0)
-    got = gpu.search(small["t"], small["y"], small["dy"], small["periods"], small["table"],
-                     small["params"])
-    want = oracle_search(oracle_lib, small)
-    assert_parity(got, want, 37)
+    # no trial duration in range for the period -> inf, row 0, depth 0 (core.py:139-140,188):
+    # a table with narrow rows only, at a period whose shortest plausible transit is wider
+    from conftest import SimpleTable
+    tab = inp["table"]
+    narrow = SimpleTable(tab.values, tab.offset[:10], tab.length[:10], tab.width[:10],
+                         tab.overshoot[:10])
+    short_p = numpy.array([0.05, 0.08, 45.0])
+    p = inp["params"]
+    got = gpu.search(*args, short_p, narrow, p)
+    want = oracle_lib.search(*args, short_p, narrow, p["transit_depth_min"], p["R_star_min"],
+                             p["R_star_max"], p["M_star_min"], p["M_star_max"], p["T0_fit_margin"])
+    assert numpy.isinf(want[0][0]) and numpy.isinf(want[0][1]) and numpy.isfinite(want[0][2])
+    assert_parity(got, want, len(inp["t"]))
+    # tiny ragged light curves: widths down to 1 sample, duplicate widths in the table
+    for n_small in (150, 211):
+        rng = numpy.random.RandomState(0)
+        t = numpy.sort(rng.uniform(0, 20, n_small))
+        y = 1 + rng.normal(0, 1e-3, n_small)
+        small = synthetic.search_inputs(t, y, period_min=1.0, period_max=5.0)
+        assert small["table"].width[0] == 1
+        got = gpu.search(small["t"], small["y"], small["dy"], small["periods"], small["table"],
+                         small["params"])
+        want = oracle_search(oracle_lib, small)
+        assert_parity(got, want, n_small)
 
 
 def test_unsorted_and_duplicate_times(gpu, oracle_lib):
@@ -258,3 +264,28 @@ def test_single_rank_rccl_allgather(gpu):
         gpu.comm_barrier()
     finally:
         gpu.comm_destroy()
+
+
+def test_exact_parallel_cumsum_is_numpy_cumsum(gpu):
+    """The workgroup scan must reproduce the SEQUENTIAL fp64 sum bit for bit
+    (numpy.cumsum, helpers.py:72), whatever the values: ties, binade crossings,
+    wide dynamic range, subnormals, large addends."""
+    rng = numpy.random.RandomState(42)
+    cases = {
+        "flux": 1 + rng.normal(0, 5e-5, 4838),
+        "flux_long": 1 + rng.normal(0, 2e-4, 78544),
+        "ties": numpy.round(rng.uniform(0.5, 1.5, 6000) * 2 ** 12) / 2 ** 12,  # exact halves abound
+        "halves": numpy.full(5000, 0.5) + (rng.randint(0, 2, 5000) * 2.0 ** -40),
+        "wide": 10.0 ** rng.uniform(-12, 3, 5000),
+        "tiny": rng.uniform(0, 1, 3000) * 1e-310,               # subnormal partial sums
+        "growing": numpy.cumsum(rng.uniform(0, 1, 2000)) ** 3,   # an addend can exceed the sum
+        "zeros": numpy.concatenate([numpy.zeros(10), rng.uniform(0, 2, 500), numpy.zeros(7)]),
+        "unnormalised": 1000.0 + rng.normal(0, 1, 5000),
+        "one": numpy.array([0.75]),
+        "empty": numpy.zeros(0),
+    }
+    for name, v in cases.items():
+        want = numpy.concatenate([[0.0], numpy.cumsum(v)])
+        for threads in (64, 512, 1024):
+            got = gpu.debug_cumsum(v, threads=threads)
+            assert numpy.array_equal(got.view(numpy.uint64), want.view(numpy.uint64)), (name, threads)

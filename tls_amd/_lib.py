@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libtls_amd.so")
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
     "tls_device_name", "tls_search", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_kernel_timing",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results",
     "tls_comm_barrier", "tls_comm_max",
 )
@@ -90,6 +90,10 @@ def load():
     lib.tls_plan_info.argtypes = [vp, cp, _c_int64_p, _c_int64_p, _c_int64_p]
     lib.tls_kernel_timing.restype = ci
     lib.tls_kernel_timing.argtypes = [vp, ci, _c_double_p, _c_int64_p]
+    lib.tls_debug_phase_cycles.restype = ci
+    lib.tls_debug_phase_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ci]
+    lib.tls_debug_cumsum.restype = ci
+    lib.tls_debug_cumsum.argtypes = [vp, _c_double_p, i64, _c_double_p, ci]
     lib.tls_grid_cells.restype = ci
     lib.tls_grid_cells.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, _c_int64_p]
     lib.tls_comm_unique_id.restype = ci
@@ -190,8 +194,24 @@ class Context(object):
         y, dy = _f8(y), _f8(dy)
         self._check(self._lib.tls_update_flux(self._h, _dp(y), _dp(dy)))
 
-    def execute(self, count_work=False):
-        self._check(self._lib.tls_execute(self._h, 1 if count_work else 0))
+    def execute(self, count_work=False, phase_clock=False):
+        self._check(self._lib.tls_execute(self._h, (1 if count_work else 0) | (2 if phase_clock else 0)))
+
+    def debug_cumsum(self, values, threads=512):
+        """[0, cumsum(values)] computed by the kernel's exact parallel sequential-order scan."""
+        v = _f8(values)
+        out = numpy.empty(len(v) + 1, dtype=numpy.float64)
+        self._check(self._lib.tls_debug_cumsum(self._h, _dp(v), len(v), _dp(out), int(threads)))
+        return out
+
+    def phase_cycles(self):
+        """Developer instrumentation: per-phase shader-cycle sums of the last
+        execute(phase_clock=True)."""
+        arr = (ctypes.c_uint64 * 12)()
+        self._check(self._lib.tls_debug_phase_cycles(self._h, arr, 12))
+        names = ("fold_count", "scan", "scatter", "rank", "gather_patch", "cumsum", "batch_prefix",
+                 "chi2", "e_convert", "predicate", "x10", "x11")
+        return dict(zip(names, [int(v) for v in arr]))
 
     def synchronize(self):
         self._check(self._lib.tls_synchronize(self._h))

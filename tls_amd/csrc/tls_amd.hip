@@ -33,7 +33,6 @@ constexpr double kFracDurationMax = 0.12;
 constexpr double kPi = 3.141592653589793;
 
 constexpr size_t kLdsPerCU = 160 * 1024;
-constexpr int kHeaderBytes = 528;  // must match kHeader in tls_kernels.hip.h
 
 std::string g_create_error;  // tls_last_error(NULL)
 
@@ -74,12 +73,14 @@ struct tls_ctx {
     int n_cu = 0;
 
     // device-resident plan
-    DevBuf<double> d_t, d_y, d_w, d_periods, d_q, d_chi2, d_depth, d_scratch, d_pack, d_gather, d_scalar;
+    DevBuf<double> d_t, d_y, d_w, d_periods, d_q, d_q2, d_chi2, d_depth, d_scratch, d_pack, d_gather, d_scalar;
     DevBuf<long long> d_row;
     DevBuf<int> d_order, d_dlo, d_dhi;
     DevBuf<tlsdev::WidthEntry> d_widths;
-    DevBuf<unsigned long long> d_counters;
-    DevBuf<unsigned int> d_queue;
+    DevBuf<unsigned long long> d_counters, d_phase;
+    DevBuf<unsigned int> d_queue, d_lists;
+    size_t list_stride = 0;
+    int hdr_bytes = 0;
 
     // host-side plan
     bool prepared = false, executed = false;
@@ -171,7 +172,10 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
         const int64_t len = tmpl->length[r];
         if (len < 1 || len > wd) return fail(ctx, TLS_E_ARG, "template row longer than its width");
         tlsdev::WidthEntry we;
-        we.width = (int)wd; we.row = (int)r; we.q_offset = (int)q_count; we.q_len = (int)len; we.pad = 0;
+        // rows are stored zero padded (kPadFront before, kPadBack after, then up to a
+        // multiple of 8 doubles) so that the unrolled dot product needs no edge handling
+        we.width = (int)wd; we.row = (int)r; we.q_offset = (int)(q_count + tlsdev::kPadFront); we.q_len = (int)len; we.pad = 0.0;
+        we.n_pos = 0; we.n_chunks = 0; we.list_base = 0; we.inv_d = 1.0 / (double)wd;
         we.xth = 1;
         if (margin > 0 && (double)wd > margin) {  // core.py:50-55
             const double inv = 1 / margin;
@@ -180,12 +184,16 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
         }
         we.overshoot = tmpl->overshoot[r];
         double s2 = 0.0;
+        if (q) q->insert(q->end(), (size_t)tlsdev::kPadFront, 0.0);
         for (int64_t j = 0; j < len; ++j) {
             const double qj = 1 - tmpl->values[tmpl->offset[r] + j];  // core.py:68
             if (q) q->push_back(qj);
             s2 += qj * qj;
         }
-        q_count += (size_t)len;
+        size_t row_total = (size_t)tlsdev::kPadFront + (size_t)len + (size_t)tlsdev::kPadBack;
+        row_total = (row_total + 7) / 8 * 8;
+        if (q) q->resize(q_count + row_total, 0.0);
+        q_count += row_total;
         we.sum_q2 = s2;
         widths.push_back(we);
     }
@@ -231,19 +239,26 @@ hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
     return hipGetLastError();
 }
 
-int enqueue(tls_ctx* ctx, bool count_work) {
+int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     TLS_HIP(ctx, hipMemsetAsync(ctx->d_queue.ptr, 0, sizeof(unsigned int), ctx->stream));
     if (count_work)
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
     tlsdev::SearchArgs a;
     a.t = ctx->d_t.ptr; a.y = ctx->d_y.ptr; a.w = ctx->uniform_w ? nullptr : ctx->d_w.ptr;
     a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.dlo = ctx->d_dlo.ptr; a.dhi = ctx->d_dhi.ptr;
-    a.widths = ctx->d_widths.ptr; a.q = ctx->d_q.ptr;
+    a.widths = ctx->d_widths.ptr; a.q = ctx->d_q.ptr; a.q2 = ctx->uniform_w ? nullptr : ctx->d_q2.ptr;
     a.out_chi2 = ctx->d_chi2.ptr; a.out_row = ctx->d_row.ptr; a.out_depth = ctx->d_depth.ptr;
     a.counters = count_work ? ctx->d_counters.ptr : nullptr;
+    a.phase_cycles = nullptr;
+    if (phase_clock) {
+        TLS_HIP(ctx, ctx->d_phase.reserve(tlsdev::kPhases));
+        TLS_HIP(ctx, hipMemsetAsync(ctx->d_phase.ptr, 0, tlsdev::kPhases * sizeof(unsigned long long), ctx->stream));
+        a.phase_cycles = ctx->d_phase.ptr;
+    }
     a.queue = ctx->d_queue.ptr;
     a.scratch = ctx->d_scratch.ptr;
-    a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1);
+    a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1 + tlsdev::kRegionPad);
+    a.chunk_lists = ctx->d_lists.ptr; a.list_stride = (long long)ctx->list_stride; a.hdr_bytes = ctx->hdr_bytes;
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
@@ -317,7 +332,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_chi2.release(); ctx->d_depth.release(); ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_row.release(); ctx->d_order.release();
     ctx->d_dlo.release(); ctx->d_dhi.release(); ctx->d_widths.release(); ctx->d_counters.release();
-    ctx->d_queue.release();
+    ctx->d_queue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release();
     for (auto& evp : ctx->ev_pool) { (void)hipEventDestroy(evp.first); (void)hipEventDestroy(evp.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -368,7 +383,11 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
 
     // launch geometry
     const size_t regions = uniform ? 2 : 3;
-    const size_t resident_bytes = kHeaderBytes + regions * 8 * (size_t)(M + 1);
+    const size_t region_doubles = (size_t)(M + 1 + tlsdev::kRegionPad);
+    // LDS header: fixed part + per-row live counters and batch prefix (+ the batch counter)
+    const size_t hdr = ((size_t)tlsdev::kFixedHeader + 4 * (2 * widths.size() + 2) + 15) / 16 * 16;
+    const size_t resident_bytes = hdr + regions * 8 * region_doubles;
+    ctx->hdr_bytes = (int)hdr;
     ctx->resident = resident_bytes <= kLdsPerCU && n <= 65535;
     if (ctx->resident) {
         ctx->nb = (int)n;
@@ -379,11 +398,26 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)wg_per_cu * ctx->n_cu);
     } else {
         ctx->nb = (int)std::min<int64_t>(n, 16384);
-        ctx->lds_bytes = kHeaderBytes + 4 * (size_t)ctx->nb;
+        ctx->lds_bytes = hdr + 4 * (size_t)ctx->nb;
         ctx->threads = 512;
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)2 * ctx->n_cu);
-        TLS_HIP(ctx, ctx->d_scratch.reserve((size_t)ctx->blocks * regions * (size_t)(M + 1)));
+        TLS_HIP(ctx, ctx->d_scratch.reserve((size_t)ctx->blocks * regions * region_doubles));
     }
+    // per-width work units of phase 3 (M is fixed for the plan, so these are period independent)
+    // and the layout of one workgroup's live-unit lists: every unit of every width has a slot
+    size_t list_cap = 0;
+    for (auto& we : widths) {
+        const int64_t n_pos = (M - we.width) / we.xth + 1;
+        const int64_t r = we.xth == 1 ? tlsdev::kR : 1;
+        we.n_pos = (int)n_pos;
+        we.n_chunks = (int)((n_pos + r - 1) / r);
+        we.list_base = (int)list_cap;
+        we.inv_d = 1.0 / (double)we.width;
+        we.pad = 0.0;
+        list_cap += (size_t)we.n_chunks;
+    }
+    ctx->list_stride = (list_cap + 63) / 64 * 64;
+    TLS_HIP(ctx, ctx->d_lists.reserve((size_t)ctx->blocks * ctx->list_stride));
 
     ctx->n = (int)n; ctx->W = (int)W; ctx->M = (int)M; ctx->n_periods = (int)n_periods;
     ctx->n_widths = (int)widths.size();
@@ -400,6 +434,12 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     if ((rc = upload(ctx, ctx->d_dhi, dhi.data(), (size_t)n_periods))) return rc;
     if ((rc = upload(ctx, ctx->d_widths, widths.data(), widths.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_q, q.data(), q.size()))) return rc;
+    std::vector<double> q2;
+    if (!uniform) {
+        q2.resize(q.size());
+        for (size_t j = 0; j < q.size(); ++j) q2[j] = q[j] * q[j];
+        if ((rc = upload(ctx, ctx->d_q2, q2.data(), q2.size()))) return rc;
+    }
     TLS_HIP(ctx, ctx->d_chi2.reserve((size_t)n_periods));
     TLS_HIP(ctx, ctx->d_row.reserve((size_t)n_periods));
     TLS_HIP(ctx, ctx->d_depth.reserve((size_t)n_periods));
@@ -435,7 +475,34 @@ int tls_execute(tls_ctx* ctx, int count_work) {
     if (!ctx->prepared) return fail(ctx, TLS_E_STATE, "tls_execute before tls_prepare");
     TLS_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->n_periods == 0) { ctx->executed = true; return TLS_OK; }
-    return enqueue(ctx, count_work != 0);
+    return enqueue(ctx, (count_work & 1) != 0, (count_work & 2) != 0);
+}
+
+int tls_debug_cumsum(tls_ctx* ctx, const double* f, int64_t count, double* out, int threads) {
+    if (!ctx || !f || !out || count < 0 || count > 100000000) return fail(ctx, TLS_E_ARG, "bad argument");
+    if (threads < 64 || threads > 1024 || threads % 64) return fail(ctx, TLS_E_ARG, "threads must be a multiple of 64 in [64, 1024]");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<double> d_f, d_out;
+    TLS_HIP(ctx, d_f.reserve((size_t)count));
+    TLS_HIP(ctx, d_out.reserve((size_t)count + 1));
+    if (count) TLS_HIP(ctx, hipMemcpyAsync(d_f.ptr, f, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3((unsigned)threads), 0, ctx->stream, d_f.ptr, d_out.ptr, (int)count);
+    TLS_HIP(ctx, hipGetLastError());
+    TLS_HIP(ctx, hipMemcpyAsync(out, d_out.ptr, ((size_t)count + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    d_f.release(); d_out.release();
+    return TLS_OK;
+}
+
+int tls_debug_phase_cycles(tls_ctx* ctx, uint64_t* cycles, int n) {
+    if (!ctx || !cycles || n < 1) return fail(ctx, TLS_E_ARG, "bad argument");
+    if (!ctx->d_phase.ptr) return fail(ctx, TLS_E_STATE, "no execute with the phase clock (count_work & 2)");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long host[tlsdev::kPhases];
+    TLS_HIP(ctx, hipMemcpy(host, ctx->d_phase.ptr, sizeof host, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < tlsdev::kPhases; ++i) cycles[i] = host[i];
+    return TLS_OK;
 }
 
 int tls_synchronize(tls_ctx* ctx) {

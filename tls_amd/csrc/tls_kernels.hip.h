@@ -5,14 +5,18 @@
 //
 //   phase 1  fold + stable sort        core.py:119-123   bucket sort on the phase, LDS atomics
 //   phase 2  patch + prefix sum        core.py:126-132, helpers.py:70-73 (numpy.cumsum order)
-//   phase 3  duration x T0 scan        core.py:162-186 -> core.py:28-76
+//   phase 3a depth predicate           core.py:58        -> compacted list of live T0 chunks
+//   phase 3b sliding chi^2             core.py:59-74     register-tiled dot products
 //   phase 4  argmin reduction          core.py:70-74, 183-188
 //
 // Data layout.  The phase-folded series lives in LDS for the whole period ("resident"
-// variant: 16*(N+W+1) bytes, N = points, W = widest trial transit) or, when it does not fit
+// variant: 16*(N+W+17) bytes, N = points, W = widest trial transit) or, when it does not fit
 // (TESS/Kepler-size N), in a per-workgroup slab of HBM scratch that stays L2/MALL-warm.
 //   regA: f[0..M)  folded flux, patched with its first W samples (M = N+W), later e = 1-f
 //   regB: C[0..M]  sequential prefix sum of f  (during the sort: bucket counters + indices)
+//   regW: w[0..M)  1/dy^2 in folded order (only when the weights are not uniform)
+// Each region has 16 spare entries so that the unrolled dot product may read a few samples
+// past a window; those samples are multiplied by the zero padding of the template rows.
 //
 // Arithmetic.  Everything is fp64 (chi^2 ~ N with the signal in the 6th digit).  For a trial
 // window starting at i with template depth profile q_j = 1 - signal_j and depth scale rs,
@@ -28,6 +32,15 @@
 // (core.py:58) is evaluated on the bit-exact reference expression 1 - (C[i+d]-C[i])/d with C
 // the sequential cumsum, so the set of evaluated cells is identical.
 //
+// Mapping to the hardware.  Only ~10 % of the trial cells pass the predicate and they come in
+// runs, so phase 3a compacts the live cells of every duration into lists of CHUNKS of kR = 5
+// consecutive T0 positions; phase 3b hands 64 chunks of one duration to a wavefront, one chunk
+// per lane.  A lane slides the template over its 5 windows at once: every folded sample it
+// reads from LDS feeds 5 FMAs (ds_read_b64 at a lane stride of 40 B is bank-conflict free for
+// consecutive chunks), and the template value is wave-uniform, fetched with scalar loads into
+// SGPRs (the template table is read through the constant address space).  That puts the loop
+// on the fp64 FMA pipe instead of the LDS pipe.
+//
 // No MFMA: the contraction is a sliding window with a per-cell scalar, not a GEMM.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -37,18 +50,47 @@ namespace tlsdev {
 
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
+constexpr int kPhases = 12;    // fold+count, scan, scatter, rank, gather+patch, cumsum, predicate, chi2
+constexpr int kR = 5;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
+constexpr int kU = 8;          // template taps per unrolled iteration
+constexpr int kPadFront = 8;   // zeros in front of every template row (>= kR-1, keeps rows 64-B aligned)
+constexpr int kPadBack = 24;   // zeros behind every template row (>= kU + kR)
+constexpr int kRegionPad = 16; // spare entries behind every folded-series region
+constexpr int kFixedHeader = 560;  // wsum[32] | wbest[16] | s_work[12] (bytes, 16-B multiple)
+
+typedef const __attribute__((address_space(4))) double* const_f64_ptr;  // -> s_load, SGPR operands
+struct WidthEntry;
+typedef const __attribute__((address_space(4))) WidthEntry* const_width_ptr;
+
+// developer instrumentation: thread 0 stamps the shader clock at phase boundaries
+struct PhaseClock {
+    unsigned long long* out;
+    long long last;
+    __device__ __forceinline__ void start(unsigned long long* o) { out = o; if (out && threadIdx.x == 0) last = clock64(); }
+    __device__ __forceinline__ void mark(int phase) {
+        if (out && threadIdx.x == 0) {
+            const long long now = clock64();
+            atomicAdd(&out[phase], (unsigned long long)(now - last));
+            last = now;
+        }
+    }
+};
 
 // One entry per DISTINCT trial width, ascending (numpy.unique, core.py:113); `row` is the
 // first template row with that width (core.py:163-165).
 struct WidthEntry {
     int width;        // trial duration d in samples
     int row;          // template row reported for this width
-    int q_offset;     // start of q_j = 1 - signal_j in the q array
+    int q_offset;     // index of q_0 of this row in the padded q array
     int q_len;        // len(signal) (== width in practice)
     int xth;          // T0 stride (core.py:50-55)
-    int pad;
+    int n_pos;        // trial T0 positions u = 0..n_pos-1, window start i = u*xth <= M-d
+    int n_chunks;     // phase-3 work units of this width: ceil(n_pos/kR) if xth == 1, else n_pos
+    int list_base;    // start of this width's live-unit list inside a workgroup's list slab
     double overshoot; // lc_cache_overview["overshoot"][row]
     double sum_q2;    // sum_j q_j^2 (uniform-weight case: A(i) = w0 * sum_q2)
+    double inv_d;     // 1/d
+    double pad;
 };
 
 struct SearchArgs {
@@ -60,19 +102,24 @@ struct SearchArgs {
     const int* dlo;         // [n_periods] smallest in-range width (samples), core.py:148
     const int* dhi;         // [n_periods] largest in-range width, core.py:149
     const WidthEntry* widths;
-    const double* q;        // all q rows back to back
+    const double* q;        // template rows q_j = 1 - signal_j, zero padded front and back
+    const double* q2;       // q_j^2, same layout (general weights only)
     double* out_chi2;       // [n_periods]
     long long* out_row;     // [n_periods]
     double* out_depth;      // [n_periods]
-    unsigned long long* counters;  // [2] evaluated cells, inner steps (nullptr: off)
+    unsigned long long* counters;      // [2] evaluated cells, inner steps (nullptr: off)
+    unsigned long long* phase_cycles;  // [kPhases] shader cycles per phase (nullptr: off)
     unsigned int* queue;    // work-queue head
-    double* scratch;        // non-resident: per-workgroup slabs
-    long long scratch_stride;  // doubles per slab
+    double* scratch;        // non-resident: per-workgroup slabs of the folded series
+    unsigned int* chunk_lists;  // per-workgroup lists of live chunks (phase 3a -> 3b)
+    long long scratch_stride;   // doubles per slab
+    long long list_stride;      // entries per workgroup
     double depth_min;
     double S0;
     double w0;
     int n, W, M;            // points, patch length, n + W
     int n_periods, n_widths, nb;  // nb: sort buckets
+    int hdr_bytes;          // LDS header: fixed part + per-row tables (16-B multiple)
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period) {
@@ -135,50 +182,267 @@ __device__ inline void block_exclusive_scan(unsigned int* cnt, int nb, unsigned 
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------
+// Exact parallel evaluation of the SEQUENTIAL fp64 prefix sum  C[k+1] = fl(C[k] + f[k]).
+//
+// The depth predicate (core.py:58) must see the bits numpy.cumsum produces (helpers.py:72),
+// and a left-to-right fp64 sum is a 5000-long dependent chain for one lane.  Inside one
+// binade [2^m, 2^(m+1)) every partial sum is an integer multiple S*u of u = 2^(m-52), and
+// adding f = a*u + rem (0 <= rem < u) rounds to  S + a + [rem > u/2] + [rem == u/2]*(S+a odd):
+// an INTEGER recurrence whose only dependence on the running sum is its parity.  Each element
+// is therefore a map  parity -> increment  (two integers), these maps compose associatively,
+// and a workgroup scan over them reproduces the sequential rounding exactly.  The scan is
+// valid until the running sum leaves the binade (S reaches 2^53); that one element is added
+// in plain fp64 and the scan restarts in the new binade (about log2(N) restarts for flux ~ 1).
+// Requires f[k] >= 0 and finite (validate.py:32-35 guarantees it for flux).
+struct ParityInc {
+    long long i0, i1;  // increment of S when S is even / odd before the step(s); saturating
+};
+constexpr long long kIncSat = 1LL << 54;
+constexpr long long kBinadeEnd = 1LL << 53;
+
+__device__ __forceinline__ ParityInc compose(const ParityInc& x, const ParityInc& y) {  // x, then y
+    ParityInc z;
+    const long long s0 = x.i0 + ((x.i0 & 1) ? y.i1 : y.i0);
+    const long long s1 = x.i1 + (((x.i1 + 1) & 1) ? y.i1 : y.i0);
+    z.i0 = s0 < kIncSat ? s0 : kIncSat;
+    z.i1 = s1 < kIncSat ? s1 : kIncSat;
+    return z;
+}
+
+// the step of one addend f in the binade with exponent m (u = 2^(m-52))
+__device__ __forceinline__ ParityInc addend_step(double f, int m) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(f);
+    const int ef = (int)((bits >> 52) & 0x7ff);
+    unsigned long long mant = bits & ((1ull << 52) - 1ull);
+    int e = -1022;
+    if (ef != 0) { mant |= 1ull << 52; e = ef - 1023; }
+    const int sh = m - e;
+    long long a = 0;
+    int up = 0, tie = 0;
+    if (sh <= 0) {
+        a = kIncSat;  // the addend alone spans the binade: forces the plain-fp64 restart
+    } else if (sh < 64) {
+        a = (long long)(mant >> sh);
+        const unsigned long long rem = mant & ((1ull << sh) - 1ull);
+        const unsigned long long half = 1ull << (sh - 1);
+        up = rem > half;
+        tie = rem == half;
+    }
+    ParityInc t;
+    t.i0 = a + up + (tie & (int)(a & 1));
+    t.i1 = a + up + (tie & (int)((a + 1) & 1));
+    return t;
+}
+
+__device__ __forceinline__ double binade_value(long long S, int m) {
+    // S * 2^(m-52) for 0 <= S < 2^53; m == -1022 also covers the subnormals (S < 2^52)
+    unsigned long long bits;
+    if (S >= (1LL << 52)) bits = ((unsigned long long)(m + 1023) << 52) | ((unsigned long long)S & ((1ull << 52) - 1ull));
+    else bits = (unsigned long long)S;
+    return __longlong_as_double((long long)bits);
+}
+
+// C[0] = 0, C[k+1] = fl(C[k] + f[k]) for k < count; all threads of the workgroup call this.
+// `wave_tot` (kMaxWaves entries), `cross` (kMaxWaves ints) and `state` (2 doubles) are LDS.
+__device__ inline void exact_sequential_cumsum(const double* f, double* C, int count, ParityInc* wave_tot,
+                                               int* cross, double* state) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (kWave - 1), nw = nt / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    if (tid == 0) {
+        C[0] = 0.0;
+        if (count > 0) C[1] = f[0];  // 0 + f is exact
+        state[0] = count > 0 ? f[0] : 0.0;
+        state[1] = 1.0;  // next element to add
+    }
+    __syncthreads();
+    constexpr int kMaxPerThread = 8;
+    for (;;) {
+        const int k_a = (int)state[1];
+        const double s_start = state[0];
+        if (k_a >= count) break;
+        // binade of the running sum
+        const unsigned long long sb = (unsigned long long)__double_as_longlong(s_start);
+        const int es = (int)((sb >> 52) & 0x7ff);
+        long long S_start = (long long)(sb & ((1ull << 52) - 1ull));
+        int m = -1022;
+        if (es != 0) { S_start |= 1LL << 52; m = es - 1023; }
+        // how far to scan: flux ~ 1 leaves the binade after ~2^m elements
+        long long want = m >= 0 && m < 30 ? (2LL << m) + 64 : (m < 0 ? 64 : (long long)nt * kMaxPerThread);
+        if (want > (long long)nt * kMaxPerThread) want = (long long)nt * kMaxPerThread;
+        const int k_b = (int)((long long)k_a + want < (long long)count ? k_a + want : count);
+        const int per = (k_b - k_a + nt - 1) / nt;
+        const int lo = k_a + tid * per < k_b ? k_a + tid * per : k_b;
+        const int hi = lo + per < k_b ? lo + per : k_b;
+
+        ParityInc loc; loc.i0 = 0; loc.i1 = 0;
+        for (int k = lo; k < hi; ++k) loc = compose(loc, addend_step(f[k], m));
+        ParityInc inc = loc;  // inclusive scan over the lanes, lower lanes first
+#pragma unroll
+        for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+            ParityInc o;
+            o.i0 = __shfl_up(inc.i0, dlt, kWave);
+            o.i1 = __shfl_up(inc.i1, dlt, kWave);
+            if (lane >= dlt) inc = compose(o, inc);
+        }
+        if (lane == kWave - 1) wave_tot[wave] = inc;
+        __syncthreads();
+        ParityInc pre; pre.i0 = 0; pre.i1 = 0;
+        for (int v = 0; v < wave; ++v) pre = compose(pre, wave_tot[v]);
+        ParityInc excl;
+        excl.i0 = __shfl_up(inc.i0, 1, kWave);
+        excl.i1 = __shfl_up(inc.i1, 1, kWave);
+        if (lane == 0) { excl.i0 = 0; excl.i1 = 0; }
+        pre = compose(pre, excl);
+        long long S = S_start + ((S_start & 1) ? pre.i1 : pre.i0);
+        int my_cross = 0x7fffffff;
+        if (S < kBinadeEnd) {  // nothing before this thread's slice left the binade
+            for (int k = lo; k < hi; ++k) {
+                const ParityInc t = addend_step(f[k], m);
+                S += (S & 1) ? t.i1 : t.i0;
+                if (S >= kBinadeEnd) { my_cross = k; break; }
+                C[k + 1] = binade_value(S, m);
+            }
+        }
+#pragma unroll
+        for (int dlt = kWave / 2; dlt > 0; dlt >>= 1) {
+            const int o = __shfl_down(my_cross, dlt, kWave);
+            my_cross = o < my_cross ? o : my_cross;
+        }
+        if (lane == 0) cross[wave] = my_cross;
+        __syncthreads();
+        if (tid == 0) {
+            int k_c = cross[0];
+            for (int v = 1; v < nw; ++v) k_c = cross[v] < k_c ? cross[v] : k_c;
+            if (k_c < k_b) {           // the sum leaves the binade at element k_c: plain fp64 step
+                const double s_new = C[k_c] + f[k_c];
+                C[k_c + 1] = s_new;
+                state[0] = s_new;
+                state[1] = (double)(k_c + 1);
+            } else {
+                state[0] = C[k_b];
+                state[1] = (double)k_b;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Depth predicate of one trial cell (core.py:58): mean = 1 - (C[i+d]-C[i])/d > depth_min.
+// The quotient is replaced by a multiplication (the two differ by < 3e-16); only a result
+// within 1e-15 of the threshold is re-decided with the exact quotient, so the decision is
+// exactly the reference's.  Returns +1 pass, 0 fail, -1 undecided (border).
+__device__ __forceinline__ int depth_class(double dC, double inv_d, double dmin) {
+    const double m_fast = fma(-dC, inv_d, 1.0);
+    return m_fast > dmin + 1e-15 ? 1 : (m_fast >= dmin - 1e-15 ? -1 : 0);
+}
+__device__ __forceinline__ bool depth_exact(double dC, double dd, double dmin) {
+    return (1.0 - dC / dd) > dmin;
+}
+
+// Per-row (= per in-range trial duration) bookkeeping of one period, in the LDS header.
+struct RowTables {
+    unsigned int* live;         // [rows]   live units found (atomic tail of the row's list)
+    unsigned int* batch_start;  // [rows+1] prefix of 64-unit batches (phase 3b work items)
+    unsigned int* next_batch;   // [1]      dynamic batch counter
+};
+
+// Candidate evaluation shared by all dot-product variants: given the dot products of one
+// T0 position, apply the predicate, form the statistic and keep the lane's best.  Positions
+// past the end of the T0 grid read the +huge sentinels behind C and fail the predicate.
+__device__ __forceinline__ void consider(Best& best, double c_lo, double c_hi, int i, double inv_d,
+                                         double dd, double dmin, double overshoot, double A, double B,
+                                         int k, unsigned long long& n_eval) {
+    const double dC = c_hi - c_lo;
+    const int cls = depth_class(dC, inv_d, dmin);
+    if (cls == 0 || (cls < 0 && !depth_exact(dC, dd, dmin))) return;
+    n_eval += 1;
+    // cheap estimate first; the exact quotient only for cells that can beat the lane's best
+    const double rs_f = 2.0 * (fma(-dC, inv_d, 1.0) * overshoot);
+    const double stat_f = rs_f * (rs_f * A - 2.0 * B);
+    if (!(stat_f <= best.stat + 1e-9 * fabs(best.stat))) return;
+    const double mean = 1.0 - dC / dd;          // helpers.py:73 + core.py:167, exact
+    const double td = mean * overshoot;          // core.py:61
+    const double rs = 2.0 * td;                  // 1/(SIGNAL_DEPTH/td), core.py:62-63
+    Best c;
+    c.stat = rs * (rs * A - 2.0 * B); c.td = td; c.k = k; c.i = i;
+    if (better(c, best)) best = c;
+}
+
+// append the live lanes' units to the row's list (order inside a list is irrelevant)
+__device__ __forceinline__ void push_live(bool live, unsigned int unit, unsigned int* live_count,
+                                          unsigned int* list, int lane) {
+    const unsigned long long mask = __ballot(live);
+    if (mask) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(live_count, (unsigned int)__popcll(mask));
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        if (live) list[base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = unit;
+    }
+}
+
 template <bool RESIDENT, bool UNIFORM_W, typename IdxT>
 __global__ void __launch_bounds__(1024)
 tls_search_kernel(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int lane = tid & (kWave - 1), wave = tid / kWave, nw = nt / kWave;
+    const int lane = tid & (kWave - 1), nw = nt / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform by construction
     const int n = a.n, W = a.W, M = a.M, nb = a.nb;
+    const int RS = M + 1 + kRegionPad;  // region stride in doubles
     const double nb_d = (double)nb;
 
     // ---- memory carve-up -----------------------------------------------------------
-    // small reduction scratch first (all variants), then the big regions
     unsigned int* wsum = reinterpret_cast<unsigned int*>(smem);            // 32 words
     Best* wbest = reinterpret_cast<Best*>(smem + 128);                      // kMaxWaves * 24 B
-    int* s_work = reinterpret_cast<int*>(smem + 128 + kMaxWaves * sizeof(Best));
-    constexpr int kHeader = 128 + kMaxWaves * 24 + 16;                      // 528, 16-B multiple
-    double *regA, *regB, *regW = nullptr, *regEW = nullptr;
+    int* s_work = reinterpret_cast<int*>(smem + 128 + kMaxWaves * sizeof(Best));  // [4]
+    RowTables rt;
+    rt.live = reinterpret_cast<unsigned int*>(smem + kFixedHeader);
+    rt.batch_start = rt.live + a.n_widths;
+    rt.next_batch = rt.batch_start + (a.n_widths + 1);
+    double *regA, *regB, *regW = nullptr;
     unsigned int* cnt;
     if constexpr (RESIDENT) {
-        regA = reinterpret_cast<double*>(smem + kHeader);
-        regB = regA + (M + 1);
-        if constexpr (!UNIFORM_W) { regW = regB + (M + 1); }
+        regA = reinterpret_cast<double*>(smem + a.hdr_bytes);
+        regB = regA + RS;
+        if constexpr (!UNIFORM_W) regW = regB + RS;
         cnt = reinterpret_cast<unsigned int*>(regB);
     } else {
         double* slab = a.scratch + (long long)blockIdx.x * a.scratch_stride;
         regA = slab;
-        regB = regA + (M + 1);
-        if constexpr (!UNIFORM_W) { regW = regB + (M + 1); }
-        cnt = reinterpret_cast<unsigned int*>(smem + kHeader);
+        regB = regA + RS;
+        if constexpr (!UNIFORM_W) regW = regB + RS;
+        cnt = reinterpret_cast<unsigned int*>(smem + a.hdr_bytes);
     }
-    (void)regEW;
+    unsigned int* chunk_list = a.chunk_lists + (long long)blockIdx.x * a.list_stride;
     // sort scratch inside regB: [cnt (resident only)] idx_tmp[n] perm[n]
     IdxT* idx_tmp = RESIDENT ? reinterpret_cast<IdxT*>(cnt + nb) : reinterpret_cast<IdxT*>(regB);
     IdxT* perm = idx_tmp + n;
     double* ph_orig = regA;  // phase by ORIGINAL index during the sort
 
+    // the spare entries behind each region are only ever multiplied by zero: make them finite
+    for (int k = tid; k < kRegionPad; k += nt) {
+        regA[M + 1 + k] = 0.0;
+        if constexpr (!UNIFORM_W) regW[M + 1 + k] = 0.0;
+    }
+
+    const const_width_ptr widths_c = (const_width_ptr)a.widths;  // read-only for the whole launch
+    const const_f64_ptr q_all = (const_f64_ptr)a.q;
+    const const_f64_ptr q2_all = (const_f64_ptr)a.q2;
+    const double dmin = a.depth_min;
+
     for (;;) {
         // ---- fetch the next period from the queue ----------------------------------
-        if (tid == 0) *s_work = (int)atomicAdd(a.queue, 1u);
+        if (tid == 0) s_work[0] = (int)atomicAdd(a.queue, 1u);
         __syncthreads();
-        const int work = *s_work;
+        const int work = s_work[0];
         __syncthreads();
         if (work >= a.n_periods) break;
         const int p = a.order[work];
         const double period = a.periods[p];
+        PhaseClock pc;
+        pc.start(a.phase_cycles);
 
         // ---- phase 1: fold + stable sort by phase ----------------------------------
         for (int b = tid; b < nb; b += nt) cnt[b] = 0;
@@ -189,13 +453,16 @@ tls_search_kernel(const SearchArgs a) {
             atomicAdd(&cnt[bucket_of(ph, nb_d, nb)], 1u);
         }
         __syncthreads();
+        pc.mark(0);
         block_exclusive_scan(cnt, nb, wsum);
+        pc.mark(1);
         for (int i = tid; i < n; i += nt) {
             int b = bucket_of(ph_orig[i], nb_d, nb);
             unsigned int slot = atomicAdd(&cnt[b], 1u);  // arbitrary order inside a bucket...
             idx_tmp[slot] = (IdxT)i;
         }
         __syncthreads();
+        pc.mark(2);
         // ...made deterministic here: rank by (phase, original index) inside the bucket.
         // cnt[b] now holds the END of bucket b.
         for (int s = tid; s < n; s += nt) {
@@ -212,6 +479,7 @@ tls_search_kernel(const SearchArgs a) {
             perm[lo + rank] = (IdxT)i;
         }
         __syncthreads();
+        pc.mark(3);
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on
         for (int k = tid; k < n; k += nt) {
             const int i = (int)perm[k];
@@ -224,101 +492,232 @@ tls_search_kernel(const SearchArgs a) {
             regA[n + k] = regA[k];
             if constexpr (!UNIFORM_W) regW[n + k] = regW[k];
         }
+        if (tid == 0) regA[M] = 0.0;
         __syncthreads();
-        if (tid == 0) {
-            // numpy.cumsum order (helpers.py:72): strictly left to right, so that the depth
-            // predicate sees the same bits as the reference.  Batches keep the loads and
-            // stores off the dependent-add chain.
-            double run = 0.0;
-            regB[0] = 0.0;
-            int k = 0;
-            constexpr int kBatch = 16;
-            for (; k + kBatch <= M; k += kBatch) {
-                double v[kBatch];
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) v[u] = regA[k + u];
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) { run += v[u]; v[u] = run; }
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) regB[k + 1 + u] = v[u];
+        pc.mark(4);
+
+        // in-range widths of this period: a contiguous range [k_lo, k_hi) of the ascending
+        // width table (core.py:148-156); widths below k_x have the dense T0 grid (stride 1)
+        const int dlo = a.dlo[p], dhi = a.dhi[p];
+        if (tid == nt - 1) {
+            int k_lo = 0;
+            while (k_lo < a.n_widths && widths_c[k_lo].width < dlo) ++k_lo;
+            int k_hi = k_lo, k_x = k_lo;
+            while (k_hi < a.n_widths && widths_c[k_hi].width <= dhi) {
+                if (widths_c[k_hi].xth == 1) k_x = k_hi + 1;
+                rt.live[k_hi - k_lo] = 0;
+                ++k_hi;
             }
-            for (; k < M; ++k) { run += regA[k]; regB[k + 1] = run; }
+            s_work[1] = k_lo; s_work[2] = k_hi; s_work[3] = k_x;
         }
         __syncthreads();
+        // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup
+        exact_sequential_cumsum(regA, regB, M, reinterpret_cast<ParityInc*>(wbest),
+                                reinterpret_cast<int*>(wsum), reinterpret_cast<double*>(s_work + 4));
+        // sentinels behind C: a window that would start past the end of the T0 grid sees an
+        // absurdly deep "mean" and fails the depth predicate without any bounds test
+        if (tid < kRegionPad) regB[M + 1 + tid] = 1.0e300;
+        __syncthreads();
+        pc.mark(5);
         // e = 1 - f in place (uniform weights) or e*w (general weights)
         for (int k = tid; k < M; k += nt) {
             double e = 1.0 - regA[k];
             if constexpr (!UNIFORM_W) e *= regW[k];
             regA[k] = e;
         }
+        const int k_lo = s_work[1], k_hi = s_work[2], k_x = s_work[3], n_rows = k_hi - k_lo;
         __syncthreads();
+        pc.mark(8);
 
-        // ---- phase 3: durations x T0 ------------------------------------------------
-        Best best;
-        best.stat = INFINITY; best.td = 0.0; best.k = 0x7fffffff; best.i = 0x7fffffff;
-        const int dlo = a.dlo[p], dhi = a.dhi[p];
-        int first_k = -1;
-        unsigned long long n_eval = 0, n_steps = 0;
-        const double dmin = a.depth_min;
-        for (int k = 0; k < a.n_widths; ++k) {
-            const WidthEntry we = a.widths[k];
-            const int d = we.width;
-            if (d < dlo || d > dhi) continue;
-            if (first_k < 0) first_k = k;
-            const int L = we.q_len, xth = we.xth;
-            const double* __restrict__ q = a.q + we.q_offset;
-            const double inv_d = 1.0 / (double)d, dd = (double)d;
-            const int n_pos = (M - d) / xth + 1;  // i = u*xth <= M-d
-            for (int u0 = wave * kWave; u0 < n_pos; u0 += nw * kWave) {
-                const int u = u0 + lane;
-                const int i = u * xth;
-                bool pass = false;
-                double dC = 0.0;
-                if (u < n_pos) {
-                    dC = regB[i + d] - regB[i];
-                    const double m_fast = 1.0 - dC * inv_d;  // within 3e-16 of the exact mean
-                    if (m_fast > dmin + 1e-15) pass = true;
-                    else if (m_fast >= dmin - 1e-15) pass = (1.0 - dC / dd) > dmin;
-                }
-                if (!__any(pass)) continue;
-                if (pass) {
-                    const double mean = 1.0 - dC / dd;       // helpers.py:73 + core.py:167
-                    const double td = mean * we.overshoot;   // core.py:61
-                    const double rs = 2.0 * td;              // 1/(SIGNAL_DEPTH/td), core.py:62-63
-                    const double* __restrict__ e = regA + i;
-                    double B0 = 0.0, B1 = 0.0, B2 = 0.0, B3 = 0.0;
-                    double A0 = 0.0, A1 = 0.0;
-                    int j = 0;
-                    if constexpr (UNIFORM_W) {
-                        for (; j + 4 <= L; j += 4) {
-                            B0 = fma(q[j], e[j], B0);
-                            B1 = fma(q[j + 1], e[j + 1], B1);
-                            B2 = fma(q[j + 2], e[j + 2], B2);
-                            B3 = fma(q[j + 3], e[j + 3], B3);
-                        }
-                        for (; j < L; ++j) B0 = fma(q[j], e[j], B0);
-                        const double B = (B0 + B1) + (B2 + B3);
-                        const double stat = rs * (rs * we.sum_q2 - 2.0 * B);
-                        Best c; c.stat = stat; c.td = td; c.k = k; c.i = i;
-                        if (better(c, best)) best = c;
-                    } else {
-                        const double* __restrict__ wv = regW + i;
-                        for (; j + 2 <= L; j += 2) {
-                            const double q0 = q[j], q1 = q[j + 1];
-                            B0 = fma(q0, e[j], B0);
-                            B1 = fma(q1, e[j + 1], B1);
-                            A0 = fma(q0 * q0, wv[j], A0);
-                            A1 = fma(q1 * q1, wv[j + 1], A1);
-                        }
-                        for (; j < L; ++j) { B0 = fma(q[j], e[j], B0); A0 = fma(q[j] * q[j], wv[j], A0); }
-                        const double stat = rs * (rs * (A0 + A1) - 2.0 * (B0 + B1));
-                        Best c; c.stat = stat; c.td = td; c.k = k; c.i = i;
-                        if (better(c, best)) best = c;
-                    }
-                    n_eval += 1; n_steps += (unsigned long long)L;
+        // ---- phase 3a: depth predicate over every trial cell -> lists of live units ----
+        // dense rows: a lane owns kR consecutive T0 positions and walks all durations with
+        // C[u0..u0+kR) held in registers; the chunk is live if its smallest window sum passes
+        // (the mean is monotone in the window sum, so min() decides exactly).
+        if (k_x > k_lo) {
+            const int units0 = widths_c[k_lo].n_chunks;  // the shortest width has the most positions
+            for (int tile = wave; tile * kWave < units0; tile += nw) {
+                const int unit = tile * kWave + lane;
+                const int u0 = unit * kR;
+                const int u0c = u0 < M - kR ? u0 : M - kR;
+                double c_lo[kR];
+#pragma unroll
+                for (int r = 0; r < kR; ++r) c_lo[r] = regB[u0c + r];
+                for (int k = k_lo; k < k_x; ++k) {
+                    const int d = widths_c[k].width;
+                    const double inv_d = widths_c[k].inv_d;
+                    const int hi0 = u0 + d < M + 1 ? u0 + d : M + 1;  // past the grid: sentinels
+                    double dC = regB[hi0] - c_lo[0];
+#pragma unroll
+                    for (int r = 1; r < kR; ++r) dC = fmin(dC, regB[hi0 + r] - c_lo[r]);
+                    const int cls = depth_class(dC, inv_d, dmin);
+                    bool live = cls > 0;
+                    if (cls < 0) live = depth_exact(dC, (double)d, dmin);  // rare: on the threshold
+                    push_live(live, (unsigned int)unit, &rt.live[k - k_lo], chunk_list + widths_c[k].list_base, lane);
                 }
             }
         }
+        // strided rows (long durations, core.py:50-58): one T0 position per lane
+        for (int k = k_x > k_lo ? k_x : k_lo; k < k_hi; ++k) {
+            const int d = widths_c[k].width, xth = widths_c[k].xth, n_pos = widths_c[k].n_pos;
+            const double inv_d = widths_c[k].inv_d;
+            for (int tile = wave; tile * kWave < n_pos; tile += nw) {
+                const int unit = tile * kWave + lane;
+                bool live = false;
+                if (unit < n_pos) {
+                    const int i = unit * xth;
+                    const double dC = regB[i + d] - regB[i];
+                    const int cls = depth_class(dC, inv_d, dmin);
+                    live = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
+                }
+                push_live(live, (unsigned int)unit, &rt.live[k - k_lo], chunk_list + widths_c[k].list_base, lane);
+            }
+        }
+        __syncthreads();
+        pc.mark(9);
+        if (wave == 0) {  // exclusive scan of the batch counts over the rows
+            unsigned int carry = 0;
+            for (int r0 = 0; r0 < n_rows; r0 += kWave) {
+                const int row = r0 + lane;
+                const unsigned int mine = row < n_rows ? (rt.live[row] + kWave - 1) / kWave : 0u;
+                unsigned int incl = mine;
+#pragma unroll
+                for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+                    const unsigned int o = __shfl_up(incl, dlt, kWave);
+                    if (lane >= dlt) incl += o;
+                }
+                if (row < n_rows) rt.batch_start[row] = carry + incl - mine;
+                carry += __shfl(incl, kWave - 1, kWave);
+            }
+            if (lane == 0) { rt.batch_start[n_rows] = carry; *rt.next_batch = 0; }
+        }
+        __syncthreads();
+        pc.mark(6);
+
+        // ---- phase 3b: sliding dot products, 64 live units of one duration per wave ----
+        Best best;
+        best.stat = INFINITY; best.td = 0.0; best.k = 0x7fffffff; best.i = 0x7fffffff;
+        unsigned long long n_eval = 0, n_steps = 0;
+        {
+            const unsigned int total_batches = rt.batch_start[n_rows];
+            int row = n_rows > 0 ? n_rows - 1 : 0;  // batch numbers only decrease within a wave
+            for (;;) {
+                unsigned int g = 0;
+                if (lane == 0) g = atomicAdd(rt.next_batch, 1u);
+                g = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
+                if (g >= total_batches) break;
+                // long durations first: batches are numbered from the widest row down
+                const unsigned int gg = total_batches - 1 - g;
+                while (gg < rt.batch_start[row]) --row;
+                const int k = k_lo + row;
+                const int d = widths_c[k].width, L = widths_c[k].q_len, xth = widths_c[k].xth;
+                const int q_offset = widths_c[k].q_offset;
+                const double overshoot = widths_c[k].overshoot, sum_q2 = widths_c[k].sum_q2;
+                const double inv_d = widths_c[k].inv_d, dd = (double)d;
+                const unsigned int slot = (gg - rt.batch_start[row]) * kWave + lane;
+                const bool have = slot < rt.live[row];
+                const int unit = have ? (int)chunk_list[widths_c[k].list_base + slot] : 0;
+                const const_f64_ptr q = q_all + q_offset;
+                const unsigned long long evals_before = n_eval;
+                if (xth == 1) {
+                    // kR windows per lane: sample e[b+t] feeds window r with template tap t-r
+                    const int b = unit * kR;
+                    const double* e = regA + b;
+                    double B0 = 0, B1 = 0, B2 = 0, B3 = 0, B4 = 0;
+                    if constexpr (UNIFORM_W) {
+                        for (int t0 = 0; t0 < L + kR - 1; t0 += kU) {
+                            double x[kU];
+#pragma unroll
+                            for (int u = 0; u < kU; ++u) x[u] = e[t0 + u];
+                            const const_f64_ptr qs = q + (t0 - (kR - 1));  // qs[m] = q_ext[t0-4+m]
+#pragma unroll
+                            for (int u = 0; u < kU; ++u) {
+                                B0 = fma(qs[u + 4], x[u], B0);
+                                B1 = fma(qs[u + 3], x[u], B1);
+                                B2 = fma(qs[u + 2], x[u], B2);
+                                B3 = fma(qs[u + 1], x[u], B3);
+                                B4 = fma(qs[u], x[u], B4);
+                            }
+                        }
+                        if (have) {
+                            const double Bv[kR] = {B0, B1, B2, B3, B4};
+                            double cl[kR], ch[kR];
+#pragma unroll
+                            for (int r = 0; r < kR; ++r) { cl[r] = regB[b + r]; ch[r] = regB[b + r + d]; }
+#pragma unroll
+                            for (int r = 0; r < kR; ++r)
+                                consider(best, cl[r], ch[r], b + r, inv_d, dd, dmin, overshoot, sum_q2, Bv[r], k, n_eval);
+                        }
+                    } else {
+                        const double* wv = regW + b;
+                        const const_f64_ptr q2 = q2_all + q_offset;
+                        double A0 = 0, A1 = 0, A2 = 0, A3 = 0, A4 = 0;
+                        for (int t0 = 0; t0 < L + kR - 1; t0 += kU) {
+                            double x[kU], z[kU];
+#pragma unroll
+                            for (int u = 0; u < kU; ++u) { x[u] = e[t0 + u]; z[u] = wv[t0 + u]; }
+                            const const_f64_ptr qs = q + (t0 - (kR - 1));
+                            const const_f64_ptr ps = q2 + (t0 - (kR - 1));
+#pragma unroll
+                            for (int u = 0; u < kU; ++u) {
+                                B0 = fma(qs[u + 4], x[u], B0); A0 = fma(ps[u + 4], z[u], A0);
+                                B1 = fma(qs[u + 3], x[u], B1); A1 = fma(ps[u + 3], z[u], A1);
+                                B2 = fma(qs[u + 2], x[u], B2); A2 = fma(ps[u + 2], z[u], A2);
+                                B3 = fma(qs[u + 1], x[u], B3); A3 = fma(ps[u + 1], z[u], A3);
+                                B4 = fma(qs[u], x[u], B4);     A4 = fma(ps[u], z[u], A4);
+                            }
+                        }
+                        if (have) {
+                            const double Bv[kR] = {B0, B1, B2, B3, B4};
+                            const double Av[kR] = {A0, A1, A2, A3, A4};
+                            double cl[kR], ch[kR];
+#pragma unroll
+                            for (int r = 0; r < kR; ++r) { cl[r] = regB[b + r]; ch[r] = regB[b + r + d]; }
+#pragma unroll
+                            for (int r = 0; r < kR; ++r)
+                                consider(best, cl[r], ch[r], b + r, inv_d, dd, dmin, overshoot, Av[r], Bv[r], k, n_eval);
+                        }
+                    }
+                } else {
+                    // strided T0 grid (core.py:50-58): one window per lane
+                    const int i = unit * xth;
+                    const double* e = regA + i;
+                    double B0 = 0, B1 = 0, A0 = 0, A1 = 0;
+                    if constexpr (UNIFORM_W) {
+                        for (int t0 = 0; t0 < L; t0 += kU) {
+                            double x[kU];
+#pragma unroll
+                            for (int u = 0; u < kU; ++u) x[u] = e[t0 + u];
+                            const const_f64_ptr qs = q + t0;
+#pragma unroll
+                            for (int u = 0; u < kU; u += 2) {
+                                B0 = fma(qs[u], x[u], B0);
+                                B1 = fma(qs[u + 1], x[u + 1], B1);
+                            }
+                        }
+                        A0 = sum_q2;
+                    } else {
+                        const double* wv = regW + i;
+                        const const_f64_ptr q2 = q2_all + q_offset;
+                        for (int t0 = 0; t0 < L; t0 += kU) {
+                            double x[kU], z[kU];
+#pragma unroll
+                            for (int u = 0; u < kU; ++u) { x[u] = e[t0 + u]; z[u] = wv[t0 + u]; }
+                            const const_f64_ptr qs = q + t0;
+                            const const_f64_ptr ps = q2 + t0;
+#pragma unroll
+                            for (int u = 0; u < kU; u += 2) {
+                                B0 = fma(qs[u], x[u], B0);         A0 = fma(ps[u], z[u], A0);
+                                B1 = fma(qs[u + 1], x[u + 1], B1); A1 = fma(ps[u + 1], z[u + 1], A1);
+                            }
+                        }
+                    }
+                    if (have) consider(best, regB[i], regB[i + d], i, inv_d, dd, dmin, overshoot, A0 + A1, B0 + B1, k, n_eval);
+                }
+                n_steps += (n_eval - evals_before) * (unsigned long long)L;
+            }
+        }
+        __syncthreads();
+        pc.mark(7);
 
         // ---- phase 4: argmin over the workgroup --------------------------------------
 #pragma unroll
@@ -334,7 +733,7 @@ tls_search_kernel(const SearchArgs a) {
             const double datapoints = (double)n;          // core.py:46 baseline
             double chi2 = INFINITY, depth = 0.0;
             long long row = 0;
-            if (first_k >= 0) {
+            if (n_rows > 0) {
                 // uniform weights: A,B were accumulated without the common factor w0
                 const double scale = UNIFORM_W ? a.w0 : 1.0;
                 const double stat = (g.stat < INFINITY) ? a.S0 + scale * g.stat : INFINITY;
@@ -343,7 +742,7 @@ tls_search_kernel(const SearchArgs a) {
                 } else {
                     // nothing beat the straight line: first in-range width registers with
                     // chi2 = N and depth 0 (core.py:46-48,183-186)
-                    chi2 = datapoints; row = a.widths[first_k].row; depth = 0.0;
+                    chi2 = datapoints; row = a.widths[k_lo].row; depth = 0.0;
                 }
             }
             a.out_chi2[p] = chi2;
@@ -363,6 +762,15 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
     }
+}
+
+// Developer/test entry: the exact sequential cumsum on an arbitrary non-negative series
+// (one workgroup, global memory).  out has count + 1 entries.
+__global__ void __launch_bounds__(1024) tls_cumsum_kernel(const double* f, double* out, int count) {
+    __shared__ ParityInc wave_tot[kMaxWaves];
+    __shared__ int cross[kMaxWaves];
+    __shared__ double state[2];
+    exact_sequential_cumsum(f, out, count, wave_tot, cross, state);
 }
 
 }  // namespace tlsdev
