@@ -210,7 +210,7 @@ class Context(object):
         arr = (ctypes.c_uint64 * 12)()
         self._check(self._lib.tls_debug_phase_cycles(self._h, arr, 12))
         names = ("fold_count", "scan", "scatter", "rank", "gather_patch", "cumsum", "batch_prefix",
-                 "chi2", "e_convert", "predicate", "x10", "x11")
+                 "chi2", "e_convert", "predicate", "cumsum_blocks", "cumsum_fallbacks")
         return dict(zip(names, [int(v) for v in arr]))
 
     def synchronize(self):

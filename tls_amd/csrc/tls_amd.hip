@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -488,6 +489,17 @@ int tls_debug_cumsum(tls_ctx* ctx, const double* f, int64_t count, double* out, 
     if (count) TLS_HIP(ctx, hipMemcpyAsync(d_f.ptr, f, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3((unsigned)threads), 0, ctx->stream, d_f.ptr, d_out.ptr, (int)count);
     TLS_HIP(ctx, hipGetLastError());
+    if (const char* reps_env = getenv("TLS_DEBUG_CUMSUM_REPS")) {  // developer timing of one workgroup
+        const int reps = atoi(reps_env);
+        TLS_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        for (int r = 0; r < reps; ++r)
+            hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3((unsigned)threads), 0, ctx->stream, d_f.ptr, d_out.ptr, (int)count);
+        TLS_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        TLS_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0;
+        TLS_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        std::fprintf(stderr, "tls_debug_cumsum: %lld elements, %d threads: %.2f us per launch\n", (long long)count, threads, 1e3 * ms / reps);
+    }
     TLS_HIP(ctx, hipMemcpyAsync(out, d_out.ptr, ((size_t)count + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     d_f.release(); d_out.release();

@@ -56,7 +56,8 @@ constexpr int kU = 8;          // template taps per unrolled iteration
 constexpr int kPadFront = 8;   // zeros in front of every template row (>= kR-1, keeps rows 64-B aligned)
 constexpr int kPadBack = 24;   // zeros behind every template row (>= kU + kR)
 constexpr int kRegionPad = 16; // spare entries behind every folded-series region
-constexpr int kFixedHeader = 560;  // wsum[32] | wbest[16] | s_work[12] (bytes, 16-B multiple)
+constexpr int kCumsumScratchBytes = 1920;  // >= sizeof(CumsumScratch), 16-B multiple
+constexpr int kFixedHeader = 560 + kCumsumScratchBytes;  // wsum[32] | wbest[16] | s_work[12] | cumsum scratch
 
 typedef const __attribute__((address_space(4))) double* const_f64_ptr;  // -> s_load, SGPR operands
 struct WidthEntry;
@@ -157,7 +158,7 @@ __device__ __forceinline__ Best shfl_down_best(const Best& v, int delta) {
 }
 
 // Exclusive prefix sum of cnt[0..nb) in place; `wsum` is LDS scratch of kMaxWaves+1 words.
-__device__ inline void block_exclusive_scan(unsigned int* cnt, int nb, unsigned int* wsum) {
+__device__ __forceinline__ void block_exclusive_scan(unsigned int* cnt, int nb, unsigned int* wsum) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid / kWave, nw = nt / kWave;
     const int chunk = (nb + nt - 1) / nt;
@@ -218,21 +219,29 @@ __device__ __forceinline__ ParityInc addend_step(double f, int m) {
     int e = -1022;
     if (ef != 0) { mant |= 1ull << 52; e = ef - 1023; }
     const int sh = m - e;
-    long long a = 0;
-    int up = 0, tie = 0;
+    long long base = 0;
+    int tie = 0;
     if (sh <= 0) {
-        a = kIncSat;  // the addend alone spans the binade: forces the plain-fp64 restart
+        base = kIncSat;  // the addend alone spans the binade: forces the plain-fp64 restart
     } else if (sh < 64) {
-        a = (long long)(mant >> sh);
-        const unsigned long long rem = mant & ((1ull << sh) - 1ull);
-        const unsigned long long half = 1ull << (sh - 1);
-        up = rem > half;
-        tie = rem == half;
+        const unsigned long long below = mant << (64 - sh);  // the bits cut off, left aligned
+        base = (long long)(mant >> sh) + (below > (1ull << 63) ? 1 : 0);
+        tie = below == (1ull << 63);
     }
+    // a tie rounds to even: the increment is a+1 exactly when S + a is odd
+    const int a_odd = (int)((mant >> (sh > 0 && sh < 64 ? sh : 0)) & 1ull) & (sh > 0 && sh < 64 ? 1 : 0);
     ParityInc t;
-    t.i0 = a + up + (tie & (int)(a & 1));
-    t.i1 = a + up + (tie & (int)((a + 1) & 1));
+    t.i0 = base + (tie & a_odd);
+    t.i1 = base + (tie & (a_odd ^ 1));
     return t;
+}
+
+// x, then y, without the saturation: for short local chains (<= kPerMax steps of <= 2^54 each)
+__device__ __forceinline__ ParityInc compose_local(const ParityInc& x, const ParityInc& y) {
+    ParityInc z;
+    z.i0 = x.i0 + ((x.i0 & 1) ? y.i1 : y.i0);
+    z.i1 = x.i1 + (((x.i1 + 1) & 1) ? y.i1 : y.i0);
+    return z;
 }
 
 __device__ __forceinline__ double binade_value(long long S, int m) {
@@ -243,35 +252,58 @@ __device__ __forceinline__ double binade_value(long long S, int m) {
     return __longlong_as_double((long long)bits);
 }
 
-// C[0] = 0, C[k+1] = fl(C[k] + f[k]) for k < count; all threads of the workgroup call this.
-// `wave_tot` (kMaxWaves entries), `cross` (kMaxWaves ints) and `state` (2 doubles) are LDS.
-__device__ inline void exact_sequential_cumsum(const double* f, double* C, int count, ParityInc* wave_tot,
-                                               int* cross, double* state) {
+// LDS scratch of the prefix-sum routines
+constexpr int kMaxSeg = 32;   // binade changes handled per block by the one-pass variant
+constexpr int kPerMax = 16;   // elements per thread and block in the one-pass variant
+struct SegAcc {               // scan element of the one-pass variant
+    ParityInc map;            // composite step since the last binade change (or since the start)
+    int cnt;                  // binade changes so far
+    int reset;                // 1 if a binade change lies inside
+};
+struct CumsumScratch {
+    ParityInc wave_tot[kMaxWaves];
+    SegAcc seg_tot[kMaxWaves];
+    ParityInc tab_T[kMaxSeg];       // composite step of the segment behind binade change j
+    long long tab_S[kMaxSeg];       // integer mantissa the segment starts from
+    double dtot[kMaxWaves];
+    double state_s;                 // running sum at state_k
+    double fail_s;
+    int tab_c[kMaxSeg + 1];         // element index of binade change j
+    int tab_m[kMaxSeg];             // binade (unbiased exponent) behind it
+    int cross[kMaxWaves];
+    int state_k, n_ok, fail_k, n_seg;
+};
+
+__device__ __forceinline__ int unbiased_exponent(double x, long long* mantissa) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const int es = (int)((b >> 52) & 0x7ff);
+    long long mant = (long long)(b & ((1ull << 52) - 1ull));
+    int m = -1022;
+    if (es != 0) { mant |= 1LL << 52; m = es - 1023; }
+    if (mantissa) *mantissa = mant;
+    return m;
+}
+
+// Robust variant: C[k+1] = fl(C[k] + f[k]) for k in [k_a, k_end), starting from C[k_a] = s_a.
+// One workgroup scan per binade of the running sum; all threads of the workgroup call this.
+__device__ __forceinline__ void sequential_cumsum_by_binade(const double* f, double* C, int k_a0, int k_end, double s_a,
+                                                   CumsumScratch* cs) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    if (tid == 0) {
-        C[0] = 0.0;
-        if (count > 0) C[1] = f[0];  // 0 + f is exact
-        state[0] = count > 0 ? f[0] : 0.0;
-        state[1] = 1.0;  // next element to add
-    }
+    if (tid == 0) { C[k_a0] = s_a; cs->state_s = s_a; cs->state_k = k_a0; }
     __syncthreads();
     constexpr int kMaxPerThread = 8;
     for (;;) {
-        const int k_a = (int)state[1];
-        const double s_start = state[0];
-        if (k_a >= count) break;
-        // binade of the running sum
-        const unsigned long long sb = (unsigned long long)__double_as_longlong(s_start);
-        const int es = (int)((sb >> 52) & 0x7ff);
-        long long S_start = (long long)(sb & ((1ull << 52) - 1ull));
-        int m = -1022;
-        if (es != 0) { S_start |= 1LL << 52; m = es - 1023; }
+        const int k_a = cs->state_k;
+        const double s_start = cs->state_s;
+        if (k_a >= k_end) break;
+        long long S_start;
+        const int m = unbiased_exponent(s_start, &S_start);
         // how far to scan: flux ~ 1 leaves the binade after ~2^m elements
         long long want = m >= 0 && m < 30 ? (2LL << m) + 64 : (m < 0 ? 64 : (long long)nt * kMaxPerThread);
         if (want > (long long)nt * kMaxPerThread) want = (long long)nt * kMaxPerThread;
-        const int k_b = (int)((long long)k_a + want < (long long)count ? k_a + want : count);
+        const int k_b = (int)((long long)k_a + want < (long long)k_end ? k_a + want : k_end);
         const int per = (k_b - k_a + nt - 1) / nt;
         const int lo = k_a + tid * per < k_b ? k_a + tid * per : k_b;
         const int hi = lo + per < k_b ? lo + per : k_b;
@@ -286,10 +318,10 @@ __device__ inline void exact_sequential_cumsum(const double* f, double* C, int c
             o.i1 = __shfl_up(inc.i1, dlt, kWave);
             if (lane >= dlt) inc = compose(o, inc);
         }
-        if (lane == kWave - 1) wave_tot[wave] = inc;
+        if (lane == kWave - 1) cs->wave_tot[wave] = inc;
         __syncthreads();
         ParityInc pre; pre.i0 = 0; pre.i1 = 0;
-        for (int v = 0; v < wave; ++v) pre = compose(pre, wave_tot[v]);
+        for (int v = 0; v < wave; ++v) pre = compose(pre, cs->wave_tot[v]);
         ParityInc excl;
         excl.i0 = __shfl_up(inc.i0, 1, kWave);
         excl.i1 = __shfl_up(inc.i1, 1, kWave);
@@ -310,21 +342,223 @@ __device__ inline void exact_sequential_cumsum(const double* f, double* C, int c
             const int o = __shfl_down(my_cross, dlt, kWave);
             my_cross = o < my_cross ? o : my_cross;
         }
-        if (lane == 0) cross[wave] = my_cross;
+        if (lane == 0) cs->cross[wave] = my_cross;
         __syncthreads();
         if (tid == 0) {
-            int k_c = cross[0];
-            for (int v = 1; v < nw; ++v) k_c = cross[v] < k_c ? cross[v] : k_c;
+            int k_c = cs->cross[0];
+            for (int v = 1; v < nw; ++v) k_c = cs->cross[v] < k_c ? cs->cross[v] : k_c;
             if (k_c < k_b) {           // the sum leaves the binade at element k_c: plain fp64 step
                 const double s_new = C[k_c] + f[k_c];
                 C[k_c + 1] = s_new;
-                state[0] = s_new;
-                state[1] = (double)(k_c + 1);
+                cs->state_s = s_new;
+                cs->state_k = k_c + 1;
             } else {
-                state[0] = C[k_b];
-                state[1] = (double)k_b;
+                cs->state_s = C[k_b];
+                cs->state_k = k_b;
             }
         }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ SegAcc seg_combine(const SegAcc& x, const SegAcc& y) {  // x, then y
+    SegAcc z;
+    z.cnt = x.cnt + y.cnt;
+    z.reset = x.reset | y.reset;
+    z.map = y.reset ? y.map : compose(x.map, y.map);
+    return z;
+}
+
+// C[0] = 0, C[k+1] = fl(C[k] + f[k]) for k < count; all threads of the workgroup call this.
+//
+// One-pass variant on top of the binade scan above.  A plain (re-associated) parallel prefix
+// sum P first predicts WHERE the running sum changes binade -- P is within ~1e-13 of the
+// sequential sum, so exponent(P[k]) is the binade of the sequential sum except within a hair
+// of a power of two.  With the binades fixed, one SEGMENTED scan of the parity maps (segments
+// restart behind every predicted binade change) covers all binades at once; the few elements
+// that change the binade are chained by one lane in plain fp64, which also VERIFIES the
+// prediction exactly (start exponent of every segment, integer mantissa staying below 2^53).
+// Whatever fails verification is redone from that point by the per-binade routine, so the
+// result is always the sequential sum, bit for bit.
+__device__ __forceinline__ void exact_sequential_cumsum(const double* f, double* C, int count, CumsumScratch* cs,
+                                               unsigned long long* dbg = nullptr) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (kWave - 1), nw = nt / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    if (tid == 0) C[0] = 0.0;
+    int k0 = 0;
+    double s0 = 0.0;
+    const int block_len = nt * kPerMax;
+    while (k0 < count) {
+        const int kb = k0 + block_len < count ? k0 + block_len : count;
+        const int per = (kb - k0 + nt - 1) / nt;  // <= kPerMax
+        const int lo = k0 + tid * per < kb ? k0 + tid * per : kb;
+        const int hi = lo + per < kb ? lo + per : kb;
+        // ---- A: re-associated prefix sum P[k] (sum before element k) into C[k0..kb] ----
+        if (tid < kMaxSeg) { cs->tab_T[tid].i0 = 0; cs->tab_T[tid].i1 = 0; }
+        double local = 0.0;
+        for (int k = lo; k < hi; ++k) local += f[k];
+        double incl = local;
+#pragma unroll
+        for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+            const double o = __shfl_up(incl, dlt, kWave);
+            if (lane >= dlt) incl += o;
+        }
+        if (lane == kWave - 1) cs->dtot[wave] = incl;
+        __syncthreads();
+        {
+            double run = s0;
+            for (int v = 0; v < wave; ++v) run += cs->dtot[v];
+            run += incl - local;
+            for (int k = lo; k < hi; ++k) { C[k] = run; run += f[k]; }
+            if (hi == kb && lo < hi) C[kb] = run;
+        }
+        __syncthreads();
+        // ---- B1: predicted binade changes and their running count ----
+        unsigned int crossmask = 0;   // bit e: element lo+e changes the binade (or opens the block)
+        int m_lo = 0;
+        {
+            int m_k = lo < hi ? unbiased_exponent(C[lo], nullptr) : 0;
+            m_lo = m_k;
+            for (int k = lo; k < hi; ++k) {
+                const int m_next = unbiased_exponent(C[k + 1], nullptr);
+                if (k == k0 || m_next != m_k) crossmask |= 1u << (k - lo);
+                m_k = m_next;
+            }
+        }
+        const int n_cross_local = __popc(crossmask);
+        int cnt_incl = n_cross_local;
+#pragma unroll
+        for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+            const int o = __shfl_up(cnt_incl, dlt, kWave);
+            if (lane >= dlt) cnt_incl += o;
+        }
+        if (lane == kWave - 1) cs->cross[wave] = cnt_incl;
+        __syncthreads();
+        int cnt_pre = cnt_incl - n_cross_local;
+        int n_seg = 0;
+        for (int v = 0; v < nw; ++v) { const int c = cs->cross[v]; n_seg += c; if (v < wave) cnt_pre += c; }
+        // ---- B2: one walk over the elements: step maps, tables of the binade changes ----
+        SegAcc acc; acc.cnt = n_cross_local; acc.reset = n_cross_local > 0;
+        ParityInc head; head.i0 = 0; head.i1 = 0;   // composite in front of the first change in my slice
+        {
+            ParityInc seg; seg.i0 = 0; seg.i1 = 0;  // composite since the last change (or since lo)
+            int j = cnt_pre - 1, m_k = m_lo;
+            bool first = true;
+            for (int k = lo; k < hi; ++k) {
+                if ((crossmask >> (k - lo)) & 1u) {
+                    if (first) { head = seg; first = false; }
+                    else if (j >= 0 && j < kMaxSeg) cs->tab_T[j] = seg;  // a segment inside my slice
+                    ++j;
+                    m_k = unbiased_exponent(C[k + 1], nullptr);
+                    if (j <= kMaxSeg) cs->tab_c[j] = k;
+                    if (j < kMaxSeg) cs->tab_m[j] = m_k;
+                    seg.i0 = 0; seg.i1 = 0;
+                } else {
+                    seg = compose_local(seg, addend_step(f[k], m_k));
+                }
+            }
+            if (first) head = seg;
+            acc.map = seg;
+        }
+        SegAcc inc = acc;
+#pragma unroll
+        for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+            SegAcc o;
+            o.map.i0 = __shfl_up(inc.map.i0, dlt, kWave);
+            o.map.i1 = __shfl_up(inc.map.i1, dlt, kWave);
+            o.cnt = __shfl_up(inc.cnt, dlt, kWave);
+            o.reset = __shfl_up(inc.reset, dlt, kWave);
+            if (lane >= dlt) inc = seg_combine(o, inc);
+        }
+        if (lane == kWave - 1) cs->seg_tot[wave] = inc;
+        __syncthreads();
+        SegAcc pre; pre.map.i0 = 0; pre.map.i1 = 0; pre.cnt = 0; pre.reset = 0;
+        for (int v = 0; v < wave; ++v) pre = seg_combine(pre, cs->seg_tot[v]);
+        {
+            SegAcc ex;
+            ex.map.i0 = __shfl_up(inc.map.i0, 1, kWave);
+            ex.map.i1 = __shfl_up(inc.map.i1, 1, kWave);
+            ex.cnt = __shfl_up(inc.cnt, 1, kWave);
+            ex.reset = __shfl_up(inc.reset, 1, kWave);
+            if (lane == 0) { ex.map.i0 = 0; ex.map.i1 = 0; ex.cnt = 0; ex.reset = 0; }
+            pre = seg_combine(pre, ex);
+        }
+        // segments that reach into my slice from the left, and the last one of the block
+        if (lo < hi) {
+            const int j_in = cnt_pre - 1;
+            if (n_cross_local > 0) {
+                if (j_in >= 0 && j_in < kMaxSeg) cs->tab_T[j_in] = compose(pre.map, head);
+                if (hi == kb) { const int j = cnt_pre + n_cross_local - 1; if (j < kMaxSeg) cs->tab_T[j] = acc.map; }
+            } else if (hi == kb && j_in >= 0 && j_in < kMaxSeg) {
+                cs->tab_T[j_in] = compose(pre.map, head);
+            }
+        }
+        __syncthreads();
+        // ---- D: wave 0 chains the binade changes in fp64 and verifies the prediction ----
+        if (wave == 0) {
+            const int n_proc = n_seg < kMaxSeg ? n_seg : kMaxSeg;
+            // lane j holds change j: its element, addend, predicted binade and segment map
+            int my_c = 0, my_m = 0;
+            double my_f = 0.0;
+            ParityInc my_T; my_T.i0 = 0; my_T.i1 = 0;
+            if (lane < n_proc) { my_c = cs->tab_c[lane]; my_m = cs->tab_m[lane]; my_T = cs->tab_T[lane]; my_f = f[my_c]; }
+            double s_end = s0;
+            int ok = 0, fail_k = kb;
+            double fail_s = 0.0;
+            bool failed = false;
+            for (int j = 0; j < n_proc; ++j) {
+                const int c = __shfl(my_c, j, kWave);
+                const double s_new = s_end + __shfl(my_f, j, kWave);  // the sequential step itself
+                long long S0;
+                const int m = unbiased_exponent(s_new, &S0);
+                if (m != __shfl(my_m, j, kWave)) { failed = true; fail_k = c; fail_s = s_end; break; }
+                const long long t0 = __shfl(my_T.i0, j, kWave), t1 = __shfl(my_T.i1, j, kWave);
+                const long long S_end = S0 + ((S0 & 1) ? t1 : t0);
+                if (lane == j) { my_f = s_new; my_T.i0 = S0; }  // keep C[c+1] and the start mantissa
+                if (S_end >= kBinadeEnd) { failed = true; fail_k = c + 1; fail_s = s_new; ok = -(j + 1); break; }
+                ok = j + 1;
+                s_end = binade_value(S_end, m);
+            }
+            if (!failed && n_seg > n_proc) { fail_k = cs->tab_c[n_proc]; fail_s = s_end; }
+            // a change whose own step verified still gets its C value, even if its segment failed
+            const int n_written = ok >= 0 ? ok : -ok;
+            if (ok < 0) ok = -ok - 1;
+            if (lane < n_written) C[my_c + 1] = my_f;
+            if (lane < ok) cs->tab_S[lane] = my_T.i0;
+            if (lane == 0) { cs->n_ok = ok; cs->fail_k = fail_k; cs->fail_s = fail_s; }
+        }
+        __syncthreads();
+        // ---- E: exact values of every element inside a verified segment ----
+        {
+            const int n_ok = cs->n_ok;
+            int j = cnt_pre - 1;
+            long long S = 0;
+            int m_k = m_lo;
+            if (j >= 0 && j < n_ok) {
+                const long long S0 = cs->tab_S[j];
+                S = S0 + ((S0 & 1) ? pre.map.i1 : pre.map.i0);
+                m_k = cs->tab_m[j];
+            }
+            for (int k = lo; k < hi; ++k) {
+                if ((crossmask >> (k - lo)) & 1u) {
+                    ++j;
+                    if (j < n_ok) { S = cs->tab_S[j]; m_k = cs->tab_m[j]; }
+                } else if (j < n_ok) {
+                    const ParityInc t = addend_step(f[k], m_k);
+                    S += (S & 1) ? t.i1 : t.i0;
+                    C[k + 1] = binade_value(S, m_k);
+                }
+            }
+        }
+        __syncthreads();
+        const int fail_k = cs->fail_k;
+        const double fail_s = cs->fail_s;
+        __syncthreads();
+        if (dbg && tid == 0) { atomicAdd(&dbg[10], 1ull); if (fail_k < kb) atomicAdd(&dbg[11], 1ull); }
+        if (fail_k < kb) sequential_cumsum_by_binade(f, C, fail_k, kb, fail_s, cs);
+        k0 = kb;
+        s0 = C[kb];
         __syncthreads();
     }
 }
@@ -397,6 +631,8 @@ tls_search_kernel(const SearchArgs a) {
     unsigned int* wsum = reinterpret_cast<unsigned int*>(smem);            // 32 words
     Best* wbest = reinterpret_cast<Best*>(smem + 128);                      // kMaxWaves * 24 B
     int* s_work = reinterpret_cast<int*>(smem + 128 + kMaxWaves * sizeof(Best));  // [4]
+    CumsumScratch* cumsum_scratch = reinterpret_cast<CumsumScratch*>(smem + 560);
+    static_assert(sizeof(CumsumScratch) <= kCumsumScratchBytes, "cumsum scratch does not fit its slot");
     RowTables rt;
     rt.live = reinterpret_cast<unsigned int*>(smem + kFixedHeader);
     rt.batch_start = rt.live + a.n_widths;
@@ -512,8 +748,7 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup
-        exact_sequential_cumsum(regA, regB, M, reinterpret_cast<ParityInc*>(wbest),
-                                reinterpret_cast<int*>(wsum), reinterpret_cast<double*>(s_work + 4));
+        exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
         // sentinels behind C: a window that would start past the end of the T0 grid sees an
         // absurdly deep "mean" and fails the depth predicate without any bounds test
         if (tid < kRegionPad) regB[M + 1 + tid] = 1.0e300;
@@ -767,10 +1002,8 @@ tls_search_kernel(const SearchArgs a) {
 // Developer/test entry: the exact sequential cumsum on an arbitrary non-negative series
 // (one workgroup, global memory).  out has count + 1 entries.
 __global__ void __launch_bounds__(1024) tls_cumsum_kernel(const double* f, double* out, int count) {
-    __shared__ ParityInc wave_tot[kMaxWaves];
-    __shared__ int cross[kMaxWaves];
-    __shared__ double state[2];
-    exact_sequential_cumsum(f, out, count, wave_tot, cross, state);
+    __shared__ CumsumScratch cs;
+    exact_sequential_cumsum(f, out, count, &cs);
 }
 
 }  // namespace tlsdev

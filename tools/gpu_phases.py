@@ -15,8 +15,9 @@ for name, sigma in (("k2_90d", None), ("k2_90d", 500e-6), ("tutorial01", None), 
     ms = ctx.execute_timed(5)
     ctx.execute(phase_clock=True)
     ph = ctx.phase_cycles()
+    blocks, fails = ph.pop("cumsum_blocks"), ph.pop("cumsum_fallbacks")
     tot = sum(ph.values())
     info = ctx.plan_info()
     print(name, sigma, "%.3f ms" % ms, "cells/s %.3e" % (info["grid_cells"] / ms * 1e3),
           {k: "%.1f%%" % (100.0 * v / tot) for k, v in ph.items()},
-          "cycles/period/wg %.0f" % (tot / len(inp["periods"])), flush=True)
+          "cycles/period/wg %.0f" % (tot / len(inp["periods"])), "cumsum blocks %d fallbacks %d" % (blocks, fails), flush=True)
