@@ -119,6 +119,16 @@ int tls_kernel_timing(tls_ctx *ctx, int reset, double *total_ms, int64_t *launch
 int tls_plan_info(const tls_ctx *ctx, tls_counters *counters, int64_t *lds_bytes,
                   int64_t *n_blocks, int64_t *resident /* 1: folded series kept in LDS */);
 
+/* ---- final T0 fit: the batched counterpart of stats.py:135-204 ------------------------ */
+/* For every trial epoch: fold (t, y) at (period, epoch), stable sort by phase, roll the folded
+ * flux by `roll` cadences, and return the chi^2 of `signal` (the template row already scaled to
+ * the fitted depth, `dur` samples) over the first `dur` samples plus the out-of-transit
+ * residuals, both weighted by 1/flux^2 of the twice-rolled flux (the reference's own weighting,
+ * stats.py:183-195).  The caller takes the FIRST minimum of out_residuals (stats.py:199-201). */
+int tls_t0_fit(tls_ctx *ctx, const double *t, const double *y, int64_t n, double period,
+               const double *signal, int64_t dur, const double *epochs, int64_t n_epochs,
+               int64_t roll, double *out_residuals);
+
 /* ---- host-only planning (no GPU needed) ------------------------------------------ */
 /* Trial cells (duration x T0 positions) each period will enumerate: the data-independent
  * cost used to place shard boundaries and to report cells/s.  Mirrors core.py:50-57,143-156. */

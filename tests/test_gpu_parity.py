@@ -289,3 +289,33 @@ def test_exact_parallel_cumsum_is_numpy_cumsum(gpu):
         for threads in (64, 512, 1024):
             got = gpu.debug_cumsum(v, threads=threads)
             assert numpy.array_equal(got.view(numpy.uint64), want.view(numpy.uint64)), (name, threads)
+
+
+def test_t0_fit_residuals_match_host_restatement(gpu):
+    """tls_t0_fit (batched final T0 fit, stats.py:135-204) against the numpy restatement that
+    the reference pins hold (tests/test_power_host.py): same residual per trial epoch, same
+    first minimum."""
+    from tls_amd.stats import t0_fit_residuals_host
+    for name, n_epochs in (("k2_90d", 1500), ("tess_27d", 64)):
+        t, f, kw = synthetic.config(name)
+        inp = synthetic.search_inputs(t, f, **kw)
+        row = 30
+        signal = 1 - (1 - inp["rows"][row]) * 0.002  # a template row scaled to a shallow depth
+        period = 10.12452
+        epochs = numpy.linspace(t.min(), t.min() + period, n_epochs)
+        roll = int(len(signal) / 2) + 1
+        want = t0_fit_residuals_host(inp["t"], inp["y"], period, signal, epochs, roll)
+        got = gpu.t0_fit_residuals(inp["t"], inp["y"], period, signal, epochs, roll)
+        numpy.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+        assert int(numpy.argmin(got)) == int(numpy.argmin(want))
+    # ties in t and an unsorted series: the stable order matters for the rolled weights
+    rng = numpy.random.RandomState(3)
+    t, f, kw = synthetic.config("k2_90d")
+    p = rng.permutation(len(t))
+    t, f = t[p], f[p]
+    t[50:60] = t[50]
+    signal = numpy.linspace(0.999, 0.9995, 77)
+    epochs = numpy.linspace(t.min(), t.min() + 3.3, 200)
+    want = t0_fit_residuals_host(t, f, 3.3, signal, epochs, 39)
+    got = gpu.t0_fit_residuals(t, f, 3.3, signal, epochs, 39)
+    numpy.testing.assert_allclose(got, want, rtol=1e-12, atol=0)

@@ -203,3 +203,15 @@ def test_transit_mask_and_public_surface():
     for name in ("transitleastsquares", "cleaned_array", "resample", "transit_mask",
                  "duration_grid", "period_grid", "FAP", "fold"):
         assert hasattr(tls_amd, name)
+
+
+def test_pink_noise_equals_reference_loop():
+    """Vectorised pink_noise against the reference's loop (stats.py:72-77), bit for bit."""
+    from tls_amd.stats import pink_noise
+    rng = numpy.random.RandomState(0)
+    for n, w in ((4000, 7), (3000, 13), (500, 1), (200, 200), (1000, 64)):
+        d = 1 + rng.normal(0, 1e-4, n)
+        total = 0
+        for i in range(n - w + 1):
+            total += numpy.std(d[i: i + w]) / w ** 0.5
+        assert pink_noise(d, w) == total / (n - w + 1)

@@ -18,7 +18,12 @@ def make_model(monkeypatch, oracle_lib):
                                                 T0_fit_margin)
         return chi2, row, depth
 
+    def host_t0_fit_residuals(t, y, period, signal, T0_array, roll, **_unused):
+        from tls_amd.stats import t0_fit_residuals_host   # numpy restatement of stats.py:178-195
+        return t0_fit_residuals_host(t, y, period, signal, T0_array, roll)
+
     monkeypatch.setattr(tls_amd.search, "search_periods", oracle_search_periods)
+    monkeypatch.setattr(tls_amd.search, "t0_fit_residuals", host_t0_fit_residuals)
     return lambda t, y, dy: tls_amd.transitleastsquares(t, y, dy, verbose=False)
 
 

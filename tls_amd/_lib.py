@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libtls_amd.so")
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
     "tls_device_name", "tls_search", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_t0_fit", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results",
     "tls_comm_barrier", "tls_comm_max",
 )
@@ -92,6 +92,9 @@ def load():
     lib.tls_kernel_timing.argtypes = [vp, ci, _c_double_p, _c_int64_p]
     lib.tls_debug_phase_cycles.restype = ci
     lib.tls_debug_phase_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ci]
+    lib.tls_t0_fit.restype = ci
+    lib.tls_t0_fit.argtypes = [vp, _c_double_p, _c_double_p, i64, dbl, _c_double_p, i64, _c_double_p,
+                               i64, i64, _c_double_p]
     lib.tls_debug_cumsum.restype = ci
     lib.tls_debug_cumsum.argtypes = [vp, _c_double_p, i64, _c_double_p, ci]
     lib.tls_grid_cells.restype = ci
@@ -196,6 +199,14 @@ class Context(object):
 
     def execute(self, count_work=False, phase_clock=False):
         self._check(self._lib.tls_execute(self._h, (1 if count_work else 0) | (2 if phase_clock else 0)))
+
+    def t0_fit_residuals(self, t, y, period, signal, epochs, roll):
+        """Residual of the depth-scaled template at every trial epoch (stats.py:178-195)."""
+        t, y, signal, epochs = _f8(t), _f8(y), _f8(signal), _f8(epochs)
+        out = numpy.empty(len(epochs), dtype=numpy.float64)
+        self._check(self._lib.tls_t0_fit(self._h, _dp(t), _dp(y), len(t), float(period), _dp(signal),
+                                         len(signal), _dp(epochs), len(epochs), int(roll), _dp(out)))
+        return out
 
     def debug_cumsum(self, values, threads=512):
         """[0, cumsum(values)] computed by the kernel's exact parallel sequential-order scan."""

@@ -109,9 +109,11 @@ class transitleastsquares(object):
         index_highest_power = numpy.argmax(power)
         period = test_statistic_periods[index_highest_power]
         depth = test_statistic_depths[index_highest_power]
+        ctx, dev = kwargs.get("context"), kwargs.get("device")
         T0 = final_T0_fit(signal=lc_arr[best_row], depth=depth, t=self.t, y=self.y, dy=self.dy,
                           period=period, T0_fit_margin=self.T0_fit_margin,
-                          show_progress_bar=self.show_progress_bar, verbose=self.verbose)
+                          show_progress_bar=self.show_progress_bar, verbose=self.verbose,
+                          residuals_fn=lambda *a: _search.t0_fit_residuals(*a, context=ctx, device=dev))
         transit_times = all_transit_times(T0, self.t, period)
         transit_duration_in_days = calculate_transit_duration_in_days(
             self.t, period, transit_times, duration)

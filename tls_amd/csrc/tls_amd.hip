@@ -80,6 +80,7 @@ struct tls_ctx {
     DevBuf<tlsdev::WidthEntry> d_widths;
     DevBuf<unsigned long long> d_counters, d_phase;
     DevBuf<unsigned int> d_queue, d_lists;
+    DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
     size_t list_stride = 0;
     int hdr_bytes = 0;
 
@@ -263,6 +264,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
+    { const char* dbg = getenv("TLS_DEBUG_SKIP"); a.dbg_skip = dbg ? atoi(dbg) : 0; }
     hipError_t e;
     if (ctx->resident)
         e = ctx->uniform_w ? launch_variant<true, true, unsigned short>(ctx, a)
@@ -334,6 +336,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_row.release(); ctx->d_order.release();
     ctx->d_dlo.release(); ctx->d_dhi.release(); ctx->d_widths.release(); ctx->d_counters.release();
     ctx->d_queue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release();
+    ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     for (auto& evp : ctx->ev_pool) { (void)hipEventDestroy(evp.first); (void)hipEventDestroy(evp.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -477,6 +480,59 @@ int tls_execute(tls_ctx* ctx, int count_work) {
     TLS_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->n_periods == 0) { ctx->executed = true; return TLS_OK; }
     return enqueue(ctx, (count_work & 1) != 0, (count_work & 2) != 0);
+}
+
+int tls_t0_fit(tls_ctx* ctx, const double* t, const double* y, int64_t n, double period, const double* signal,
+               int64_t dur, const double* epochs, int64_t n_epochs, int64_t roll, double* out_residuals) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!t || !y || !signal || !epochs || !out_residuals) return fail(ctx, TLS_E_ARG, "null argument");
+    if (n < 3 || n > 50000000 || dur < 1 || dur > n || n_epochs < 0 || roll < 0 || !(period > 0))
+        return fail(ctx, TLS_E_ARG, "tls_t0_fit: argument out of range");
+    if (n_epochs == 0) return TLS_OK;
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    TLS_HIP(ctx, ctx->d_queue.reserve(1));
+    int rc;
+    if ((rc = upload(ctx, ctx->d_ft, t, (size_t)n))) return rc;
+    if ((rc = upload(ctx, ctx->d_fy, y, (size_t)n))) return rc;
+    if ((rc = upload(ctx, ctx->d_fsig, signal, (size_t)dur))) return rc;
+    if ((rc = upload(ctx, ctx->d_fep, epochs, (size_t)n_epochs))) return rc;
+    TLS_HIP(ctx, ctx->d_fres.reserve((size_t)n_epochs));
+    TLS_HIP(ctx, hipMemsetAsync(ctx->d_queue.ptr, 0, sizeof(unsigned int), ctx->stream));
+    tlsdev::T0FitArgs a;
+    a.t = ctx->d_ft.ptr; a.y = ctx->d_fy.ptr; a.signal = ctx->d_fsig.ptr; a.epochs = ctx->d_fep.ptr;
+    a.residuals = ctx->d_fres.ptr; a.queue = ctx->d_queue.ptr; a.scratch = nullptr; a.scratch_stride = 0;
+    a.period = period; a.n = (int)n; a.dur = (int)dur; a.roll = (int)(roll % n); a.n_epochs = (int)n_epochs;
+    const size_t hdr = 272;
+    const size_t resident_bytes = hdr + 16 * (size_t)n;
+    const bool resident = resident_bytes <= kLdsPerCU && n <= 65535;
+    size_t lds; int threads, blocks;
+    if (resident) {
+        a.nb = (int)n; lds = resident_bytes;
+        const size_t per_cu = kLdsPerCU / resident_bytes;
+        threads = per_cu >= 2 ? 512 : 1024;
+        const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)threads);
+        blocks = (int)std::min<int64_t>(n_epochs, (int64_t)wg_per_cu * ctx->n_cu);
+    } else {
+        a.nb = (int)std::min<int64_t>(n, 16384); lds = hdr + 4 * (size_t)a.nb;
+        threads = 512; blocks = (int)std::min<int64_t>(n_epochs, (int64_t)2 * ctx->n_cu);
+        a.scratch_stride = 3 * n;
+        TLS_HIP(ctx, ctx->d_fscratch.reserve((size_t)blocks * (size_t)a.scratch_stride));
+        a.scratch = ctx->d_fscratch.ptr;
+    }
+    hipError_t e;
+    if (resident) {
+        auto kernel = tlsdev::tls_t0fit_kernel<true, unsigned short>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
+    } else {
+        auto kernel = tlsdev::tls_t0fit_kernel<false, unsigned int>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
+    }
+    if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("t0 fit launch: ") + hipGetErrorString(e));
+    TLS_HIP(ctx, hipMemcpyAsync(out_residuals, ctx->d_fres.ptr, (size_t)n_epochs * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TLS_OK;
 }
 
 int tls_debug_cumsum(tls_ctx* ctx, const double* f, int64_t count, double* out, int threads) {

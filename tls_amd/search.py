@@ -37,3 +37,10 @@ def search_periods(t, y, dy, periods, table, transit_depth_min, R_star_min, R_st
     if return_counters:
         return chi2, row, depth, counters
     return chi2, row, depth
+
+
+def t0_fit_residuals(t, y, period, signal, T0_array, roll, context=None, device=None):
+    """Device evaluation of the final-T0-fit residuals (tls_t0_fit); same contract as
+    tls_amd.stats.t0_fit_residuals_host."""
+    ctx = context if context is not None else default_context(device)
+    return ctx.t0_fit_residuals(t, y, period, signal, T0_array, roll)

@@ -69,11 +69,15 @@ def rp_rs_from_depth(depth, law, params):
 
 def pink_noise(data, width):
     """Mean over all windows of `width` points of std(window)/sqrt(width)
-    (reference stats.py:72-77)."""
+    (reference stats.py:72-77).  Window statistics in one vectorised call; the
+    running total is accumulated left to right like the reference's loop."""
+    data = numpy.asarray(data, dtype=float)
     n_windows = len(data) - width + 1
+    windows = numpy.lib.stride_tricks.sliding_window_view(data, width)
+    terms = numpy.std(windows, axis=1) / width ** 0.5
     total = 0
-    for i in range(n_windows):
-        total += numpy.std(data[i: i + width]) / width ** 0.5
+    for v in terms.tolist():
+        total += v
     return total / n_windows
 
 
@@ -116,14 +120,34 @@ def spectra(chi2, oversampling_factor):
     return SR, power_raw, power, SDE_raw, SDE
 
 
+def t0_fit_residuals_host(t, y, period, signal, T0_array, roll, batch_bytes=64 << 20):
+    """Host (numpy) evaluation of the T0-fit residuals, trial epochs in batches: the restatement
+    of the loop body of stats.py:178-195 that pins the device kernel (tls_t0_fit)."""
+    n, dur = numpy.size(y), len(signal)
+    out = numpy.empty(len(T0_array))
+    rows = max(1, int(batch_bytes // (8 * n * 4)))
+    for lo in range(0, len(T0_array), rows):
+        Tx = T0_array[lo: lo + rows]
+        phases = fold(t[None, :], period, Tx[:, None])
+        order = numpy.argsort(phases, axis=1, kind="stable")
+        flux = numpy.roll(y[order], roll, axis=1)  # template starts at index 0
+        weight = numpy.roll(flux, roll, axis=1)
+        res_in = numpy.sum((flux[:, :dur] - signal) ** 2 / weight[:, :dur] ** 2, axis=1)
+        res_out = numpy.sum((flux[:, dur:] - 1.0) ** 2 / weight[:, dur:] ** 2, axis=1)
+        out[lo: lo + rows] = res_in + res_out
+    return out
+
+
 def final_T0_fit(signal, depth, t, y, dy, period, T0_fit_margin, show_progress_bar, verbose,
-                 batch_bytes=64 << 20):
+                 residuals_fn=None):
     """Mid-transit time of the best (period, duration, depth): chi^2 of the
     depth-scaled template over a grid of trial T0s, first minimum wins.
 
     Reference stats.py:135-204.  Kept quirk: the weights are 1/flux^2 of the
     flux rolled twice, not 1/dy^2 (the reference overwrites dy with the rolled
     flux, stats.py:191), so `dy` does not influence the result.
+    residuals_fn(t, y, period, signal, T0_array, roll) evaluates the trial epochs; the
+    drop-in passes the device kernel, the default is the numpy restatement.
     """
     dur = len(signal)
     scale = C.SIGNAL_DEPTH / (1 - depth)
@@ -138,23 +162,13 @@ def final_T0_fit(signal, depth, t, y, dy, period, T0_fit_margin, show_progress_b
     T0_array = numpy.linspace(start=numpy.min(t), stop=numpy.min(t) + period, num=points)
     if verbose:
         print("Searching for best T0 for period", format(period, ".5f"), "days")
-
     roll = int(dur / 2) + 1
-    best, T0 = float("inf"), 0
-    rows = max(1, int(batch_bytes // (8 * n * 4)))
-    for lo in range(0, points, rows):
-        Tx = T0_array[lo: lo + rows]
-        phases = fold(t[None, :], period, Tx[:, None])
-        order = numpy.argsort(phases, axis=1, kind="stable")
-        flux = numpy.roll(y[order], roll, axis=1)  # template starts at index 0
-        weight = numpy.roll(flux, roll, axis=1)
-        res_in = numpy.sum((flux[:, :dur] - signal) ** 2 / weight[:, :dur] ** 2, axis=1)
-        res_out = numpy.sum((flux[:, dur:] - 1.0) ** 2 / weight[:, dur:] ** 2, axis=1)
-        total = res_in + res_out
-        k = int(numpy.argmin(total))
-        if total[k] < best:
-            best, T0 = total[k], Tx[k]
-    return T0
+    if residuals_fn is None:
+        residuals_fn = t0_fit_residuals_host
+    total = residuals_fn(t, y, period, signal, T0_array, roll)
+    if len(total) == 0 or not (numpy.min(total) < float("inf")):
+        return 0
+    return T0_array[int(numpy.argmin(total))]  # first strict minimum (stats.py:199-201)
 
 
 def all_transit_times(T0, t, period):
