@@ -412,7 +412,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     size_t list_cap = 0;
     for (auto& we : widths) {
         const int64_t n_pos = (M - we.width) / we.xth + 1;
-        const int64_t r = we.xth == 1 ? tlsdev::kR : 1;
+        const int64_t r = we.xth <= tlsdev::kMaxTiledStride ? tlsdev::kR : 1;
         we.n_pos = (int)n_pos;
         we.n_chunks = (int)((n_pos + r - 1) / r);
         we.list_base = (int)list_cap;

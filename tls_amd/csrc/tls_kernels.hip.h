@@ -53,9 +53,10 @@ constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
 constexpr int kPhases = 12;    // fold+count, scan, scatter, rank, gather+patch, cumsum, predicate, chi2
 constexpr int kR = 5;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
 constexpr int kU = 8;          // template taps per unrolled iteration
-constexpr int kPadFront = 8;   // zeros in front of every template row (>= kR-1, keeps rows 64-B aligned)
-constexpr int kPadBack = 24;   // zeros behind every template row (>= kU + kR)
-constexpr int kRegionPad = 16; // spare entries behind every folded-series region
+constexpr int kMaxTiledStride = 5;  // T0 strides up to this use the kR-window dot product
+constexpr int kPadFront = 24;  // zeros in front of every template row (>= (kR-1)*kMaxTiledStride, 64-B multiple)
+constexpr int kPadBack = 40;   // zeros behind every template row (>= 2*kU + (kR-1)*kMaxTiledStride)
+constexpr int kRegionPad = 40; // spare entries behind every folded-series region (>= 2*kU + kR*kMaxTiledStride)
 constexpr int kCumsumScratchBytes = 1920;  // >= sizeof(CumsumScratch), 16-B multiple
 constexpr int kFixedHeader = 560 + kCumsumScratchBytes;  // wsum[32] | wbest[16] | s_work[12] | cumsum scratch
 
@@ -645,6 +646,43 @@ __device__ __forceinline__ void push_live(bool live, unsigned int unit, unsigned
     }
 }
 
+// kR sliding dot products of one lane: windows r = 0..kR-1 start XTH samples apart (XTH = 1 is
+// the dense T0 grid, 2..kMaxTiledStride the strided grids of long durations, core.py:50-58).
+// Sample e[t] feeds window r with template tap t - r*XTH; the taps are wave-uniform (SGPRs).
+template <bool IN_LDS, int XTH>
+__device__ __forceinline__ void dot_windows(const double* e, const_f64_ptr q, int L, double (&B)[kR]) {
+    constexpr int S = (kR - 1) * XTH;
+    for (int t0 = 0; t0 < L + S; t0 += kU) {
+        double x[kU];
+        load_taps<IN_LDS>(e + t0, x);
+        const const_f64_ptr qs = q + (t0 - S);  // qs[m] = q_ext[t0 - S + m]
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+            for (int r = 0; r < kR; ++r) B[r] = fma(qs[u + S - r * XTH], x[u], B[r]);
+    }
+}
+// the same with per-sample weights: B over e*w with taps q, A over w with taps q^2
+template <bool IN_LDS, int XTH>
+__device__ __forceinline__ void dot_windows_weighted(const double* ew, const double* w, const_f64_ptr q,
+                                                     const_f64_ptr q2, int L, double (&B)[kR], double (&A)[kR]) {
+    constexpr int S = (kR - 1) * XTH;
+    for (int t0 = 0; t0 < L + S; t0 += kU) {
+        double x[kU], z[kU];
+        load_taps<IN_LDS>(ew + t0, x);
+        load_taps<IN_LDS>(w + t0, z);
+        const const_f64_ptr qs = q + (t0 - S);
+        const const_f64_ptr ps = q2 + (t0 - S);
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+                B[r] = fma(qs[u + S - r * XTH], x[u], B[r]);
+                A[r] = fma(ps[u + S - r * XTH], z[u], A[r]);
+            }
+    }
+}
+
 // Fold `t` at (period, epoch) and produce the STABLE ascending order of the phases
 // (numpy.argsort(kind="mergesort"), core.py:119-120 / stats.py:178-179): perm[k] = original index
 // of the k-th smallest phase.  Bucket sort: histogram of floor(phase*nb) with LDS atomics, scan,
@@ -857,20 +895,41 @@ tls_search_kernel(const SearchArgs a) {
                 }
             }
         }
-        // strided rows (long durations, core.py:50-58): one T0 position per lane
+        // strided rows (long durations, core.py:50-58): kR strided positions per lane while the
+        // stride allows the tiled dot product, else one position per lane
         for (int k = k_x > k_lo ? k_x : k_lo; k < ((a.dbg_skip & 2) ? 0 : k_hi); ++k) {
             const int d = widths_c[k].width, xth = widths_c[k].xth, n_pos = widths_c[k].n_pos;
+            const int n_units = widths_c[k].n_chunks;
             const double inv_d = widths_c[k].inv_d;
-            for (int tile = wave; tile * kWave < n_pos; tile += nw) {
-                const int unit = tile * kWave + lane;
-                bool live = false;
-                if (unit < n_pos) {
-                    const int i = unit * xth;
-                    const double dC = regB[i + d] - regB[i];
+            unsigned int* list = chunk_list + widths_c[k].list_base;
+            if (xth <= kMaxTiledStride) {
+                for (int tile = wave; tile * kWave < n_units; tile += nw) {
+                    const int unit = tile * kWave + lane;
+                    const int uc = unit < n_units ? unit : n_units - 1;
+                    const double* c0 = regB + uc * kR * xth;
+                    double c_lo[kR], c_hi[kR];
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) { c_lo[r] = c0[r * xth]; c_hi[r] = c0[r * xth + d]; }
+                    double dC = c_hi[0] - c_lo[0];
+#pragma unroll
+                    for (int r = 1; r < kR; ++r) dC = fmin(dC, c_hi[r] - c_lo[r]);
                     const int cls = depth_class(dC, inv_d, dmin);
-                    live = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
+                    bool live = cls > 0;
+                    if (cls < 0) live = depth_exact(dC, (double)d, dmin);
+                    push_live(live && unit < n_units, (unsigned int)unit, &rt.live[k - k_lo], list, lane);
                 }
-                push_live(live, (unsigned int)unit, &rt.live[k - k_lo], chunk_list + widths_c[k].list_base, lane);
+            } else {
+                for (int tile = wave; tile * kWave < n_pos; tile += nw) {
+                    const int unit = tile * kWave + lane;
+                    bool live = false;
+                    if (unit < n_pos) {
+                        const int i = unit * xth;
+                        const double dC = regB[i + d] - regB[i];
+                        const int cls = depth_class(dC, inv_d, dmin);
+                        live = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
+                    }
+                    push_live(live, (unsigned int)unit, &rt.live[k - k_lo], list, lane);
+                }
             }
         }
         __syncthreads();
@@ -899,6 +958,8 @@ tls_search_kernel(const SearchArgs a) {
         best.stat = INFINITY; best.td = 0.0; best.k = 0x7fffffff; best.i = 0x7fffffff;
         unsigned long long n_eval = 0, n_steps = 0;
         {
+            // batches are numbered from the widest row down (long templates first) and handed out
+            // dynamically through an LDS ticket counter
             const unsigned int total_batches = rt.batch_start[n_rows];
             int row = n_rows > 0 ? n_rows - 1 : 0;  // batch numbers only decrease within a wave
             for (;;) {
@@ -906,82 +967,57 @@ tls_search_kernel(const SearchArgs a) {
                 if (lane == 0) g = atomicAdd(rt.next_batch, 1u);
                 g = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
                 if (g >= total_batches) break;
-                // long durations first: batches are numbered from the widest row down
                 const unsigned int gg = total_batches - 1 - g;
                 while (gg < rt.batch_start[row]) --row;
+                const unsigned int slot = (gg - rt.batch_start[row]) * kWave + lane;
+                const bool have = slot < rt.live[row];
+                const int unit = have ? (int)chunk_list[widths_c[k_lo + row].list_base + slot] : 0;
                 const int k = k_lo + row;
                 const int d = widths_c[k].width, L = widths_c[k].q_len, xth = widths_c[k].xth;
                 const int q_offset = widths_c[k].q_offset;
                 const double overshoot = widths_c[k].overshoot, sum_q2 = widths_c[k].sum_q2;
                 const double inv_d = widths_c[k].inv_d, dd = (double)d;
-                const unsigned int slot = (gg - rt.batch_start[row]) * kWave + lane;
-                const bool have = slot < rt.live[row];
-                const int unit = have ? (int)chunk_list[widths_c[k].list_base + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
                 const unsigned long long evals_before = n_eval;
-                if (xth == 1) {
-                    // kR windows per lane: sample e[b+t] feeds window r with template tap t-r
-                    const int b = unit * kR;
+                if (xth <= kMaxTiledStride) {
+                    // kR windows per lane, xth samples apart
+                    const int u0 = unit * kR;
+                    const int b = u0 * xth;
                     const double* e = regA + b;
-                    double B0 = 0, B1 = 0, B2 = 0, B3 = 0, B4 = 0;
+                    double Bv[kR] = {0, 0, 0, 0, 0}, Av[kR] = {0, 0, 0, 0, 0};
+                    const int Lr = (a.dbg_skip & 16) ? 0 : L;
                     if constexpr (UNIFORM_W) {
-                        const int t_end = (a.dbg_skip & 16) ? 0 : L + kR - 1;
-                        for (int t0 = 0; t0 < t_end; t0 += kU) {
-                            double x[kU];
-                            load_taps<RESIDENT>(e + t0, x);
-                            const const_f64_ptr qs = q + (t0 - (kR - 1));  // qs[m] = q_ext[t0-4+m]
-#pragma unroll
-                            for (int u = 0; u < kU; ++u) {
-                                B0 = fma(qs[u + 4], x[u], B0);
-                                B1 = fma(qs[u + 3], x[u], B1);
-                                B2 = fma(qs[u + 2], x[u], B2);
-                                B3 = fma(qs[u + 1], x[u], B3);
-                                B4 = fma(qs[u], x[u], B4);
-                            }
+                        switch (xth) {
+                            case 1: dot_windows<RESIDENT, 1>(e, q, Lr, Bv); break;
+                            case 2: dot_windows<RESIDENT, 2>(e, q, Lr, Bv); break;
+                            case 3: dot_windows<RESIDENT, 3>(e, q, Lr, Bv); break;
+                            case 4: dot_windows<RESIDENT, 4>(e, q, Lr, Bv); break;
+                            default: dot_windows<RESIDENT, 5>(e, q, Lr, Bv); break;
                         }
-                        if (a.dbg_skip & 8) { if (B0 + B1 + B2 + B3 + B4 == 1.2345) best.i = 1; }
-                        else
-                        if (have) {
-                            const double Bv[kR] = {B0, B1, B2, B3, B4};
-                            double cl[kR], ch[kR];
 #pragma unroll
-                            for (int r = 0; r < kR; ++r) { cl[r] = regB[b + r]; ch[r] = regB[b + r + d]; }
-#pragma unroll
-                            for (int r = 0; r < kR; ++r)
-                                consider(best, cl[r], ch[r], b + r, inv_d, dd, dmin, overshoot, sum_q2, Bv[r], k, n_eval);
-                        }
+                        for (int r = 0; r < kR; ++r) Av[r] = sum_q2;
                     } else {
                         const double* wv = regW + b;
                         const const_f64_ptr q2 = q2_all + q_offset;
-                        double A0 = 0, A1 = 0, A2 = 0, A3 = 0, A4 = 0;
-                        for (int t0 = 0; t0 < L + kR - 1; t0 += kU) {
-                            double x[kU], z[kU];
-                            load_taps<RESIDENT>(e + t0, x);
-                            load_taps<RESIDENT>(wv + t0, z);
-                            const const_f64_ptr qs = q + (t0 - (kR - 1));
-                            const const_f64_ptr ps = q2 + (t0 - (kR - 1));
-#pragma unroll
-                            for (int u = 0; u < kU; ++u) {
-                                B0 = fma(qs[u + 4], x[u], B0); A0 = fma(ps[u + 4], z[u], A0);
-                                B1 = fma(qs[u + 3], x[u], B1); A1 = fma(ps[u + 3], z[u], A1);
-                                B2 = fma(qs[u + 2], x[u], B2); A2 = fma(ps[u + 2], z[u], A2);
-                                B3 = fma(qs[u + 1], x[u], B3); A3 = fma(ps[u + 1], z[u], A3);
-                                B4 = fma(qs[u], x[u], B4);     A4 = fma(ps[u], z[u], A4);
-                            }
-                        }
-                        if (have) {
-                            const double Bv[kR] = {B0, B1, B2, B3, B4};
-                            const double Av[kR] = {A0, A1, A2, A3, A4};
-                            double cl[kR], ch[kR];
-#pragma unroll
-                            for (int r = 0; r < kR; ++r) { cl[r] = regB[b + r]; ch[r] = regB[b + r + d]; }
-#pragma unroll
-                            for (int r = 0; r < kR; ++r)
-                                consider(best, cl[r], ch[r], b + r, inv_d, dd, dmin, overshoot, Av[r], Bv[r], k, n_eval);
+                        switch (xth) {
+                            case 1: dot_windows_weighted<RESIDENT, 1>(e, wv, q, q2, Lr, Bv, Av); break;
+                            case 2: dot_windows_weighted<RESIDENT, 2>(e, wv, q, q2, Lr, Bv, Av); break;
+                            case 3: dot_windows_weighted<RESIDENT, 3>(e, wv, q, q2, Lr, Bv, Av); break;
+                            case 4: dot_windows_weighted<RESIDENT, 4>(e, wv, q, q2, Lr, Bv, Av); break;
+                            default: dot_windows_weighted<RESIDENT, 5>(e, wv, q, q2, Lr, Bv, Av); break;
                         }
                     }
+                    if (a.dbg_skip & 8) { if (Bv[0] + Bv[1] + Bv[2] + Bv[3] + Bv[4] == 1.2345) best.i = 1; }
+                    else if (have) {
+                        double cl[kR], ch[kR];
+#pragma unroll
+                        for (int r = 0; r < kR; ++r) { cl[r] = regB[b + r * xth]; ch[r] = regB[b + r * xth + d]; }
+#pragma unroll
+                        for (int r = 0; r < kR; ++r)
+                            consider(best, cl[r], ch[r], b + r * xth, inv_d, dd, dmin, overshoot, Av[r], Bv[r], k, n_eval);
+                    }
                 } else {
-                    // strided T0 grid (core.py:50-58): one window per lane
+                    // wide T0 strides: one window per lane
                     const int i = unit * xth;
                     const double* e = regA + i;
                     double B0 = 0, B1 = 0, A0 = 0, A1 = 0;
