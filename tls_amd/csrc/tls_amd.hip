@@ -264,7 +264,6 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
-    { const char* dbg = getenv("TLS_DEBUG_SKIP"); a.dbg_skip = dbg ? atoi(dbg) : 0; }
     hipError_t e;
     if (ctx->resident)
         e = ctx->uniform_w ? launch_variant<true, true, unsigned short>(ctx, a)

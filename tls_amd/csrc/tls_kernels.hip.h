@@ -46,6 +46,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef TLS_WAVES_PER_EU
+#define TLS_WAVES_PER_EU 4
+#endif
+
 namespace tlsdev {
 
 constexpr int kWave = 64;
@@ -149,7 +153,6 @@ struct SearchArgs {
     int n, W, M;            // points, patch length, n + W
     int n_periods, n_widths, nb;  // nb: sort buckets
     int hdr_bytes;          // LDS header: fixed part + per-row tables (16-B multiple)
-    int dbg_skip;           // developer ablation switches (0 in production)
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period, double epoch) {
@@ -733,7 +736,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
 }
 
 template <bool RESIDENT, bool UNIFORM_W, typename IdxT>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -849,7 +852,7 @@ tls_search_kernel(const SearchArgs a) {
         // dense rows: a lane owns kR consecutive T0 positions and walks all durations with
         // C[u0..u0+kR) held in registers; the chunk is live if its smallest window sum passes
         // (the mean is monotone in the window sum, so min() decides exactly).
-        if (k_x > k_lo && !(a.dbg_skip & 4)) {
+        if (k_x > k_lo) {
             const int units0 = widths_c[k_lo].n_chunks;  // the shortest width has the most positions
             for (int tile = wave; tile * kWave < units0; tile += nw) {
                 const int unit = tile * kWave + lane;
@@ -886,8 +889,6 @@ tls_search_kernel(const SearchArgs a) {
                             const int cls = depth_class(dC[j], inv[j], dmin);
                             bool live = cls > 0;
                             if (cls < 0) live = depth_exact(dC[j], (double)dv[j], dmin);  // rare: on the threshold
-                            if (a.dbg_skip & 1) { if (live && unit == 0x7fffffff) rt.live[0] = 1; }
-                            else
                             push_live(live, (unsigned int)unit, &rt.live[k + j - k_lo],
                                       chunk_list + widths_c[k + j].list_base, lane);
                         }
@@ -897,7 +898,7 @@ tls_search_kernel(const SearchArgs a) {
         }
         // strided rows (long durations, core.py:50-58): kR strided positions per lane while the
         // stride allows the tiled dot product, else one position per lane
-        for (int k = k_x > k_lo ? k_x : k_lo; k < ((a.dbg_skip & 2) ? 0 : k_hi); ++k) {
+        for (int k = k_x > k_lo ? k_x : k_lo; k < k_hi; ++k) {
             const int d = widths_c[k].width, xth = widths_c[k].xth, n_pos = widths_c[k].n_pos;
             const int n_units = widths_c[k].n_chunks;
             const double inv_d = widths_c[k].inv_d;
@@ -985,7 +986,7 @@ tls_search_kernel(const SearchArgs a) {
                     const int b = u0 * xth;
                     const double* e = regA + b;
                     double Bv[kR] = {0, 0, 0, 0, 0}, Av[kR] = {0, 0, 0, 0, 0};
-                    const int Lr = (a.dbg_skip & 16) ? 0 : L;
+                    const int Lr = L;
                     if constexpr (UNIFORM_W) {
                         switch (xth) {
                             case 1: dot_windows<RESIDENT, 1>(e, q, Lr, Bv); break;
@@ -1007,8 +1008,7 @@ tls_search_kernel(const SearchArgs a) {
                             default: dot_windows_weighted<RESIDENT, 5>(e, wv, q, q2, Lr, Bv, Av); break;
                         }
                     }
-                    if (a.dbg_skip & 8) { if (Bv[0] + Bv[1] + Bv[2] + Bv[3] + Bv[4] == 1.2345) best.i = 1; }
-                    else if (have) {
+                    if (have) {
                         double cl[kR], ch[kR];
 #pragma unroll
                         for (int r = 0; r < kR; ++r) { cl[r] = regB[b + r * xth]; ch[r] = regB[b + r * xth + d]; }
