@@ -82,7 +82,8 @@ struct tls_ctx {
     DevBuf<unsigned int> d_queue, d_lists;
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
     size_t list_stride = 0;
-    int hdr_bytes = 0;
+    int hdr_bytes = 0, tile_len = 0, tile_halo = 0;
+    bool stage_c = false;
 
     // host-side plan
     bool prepared = false, executed = false;
@@ -222,9 +223,9 @@ int64_t period_window(const std::vector<tlsdev::WidthEntry>& widths, const tls_p
     return c;
 }
 
-template <bool RES, bool UNI, typename IdxT>
+template <bool RES, bool UNI, bool STAGE_C, typename IdxT>
 hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
-    auto kernel = tlsdev::tls_search_kernel<RES, UNI, IdxT>;
+    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
@@ -260,17 +261,20 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     a.queue = ctx->d_queue.ptr;
     a.scratch = ctx->d_scratch.ptr;
     a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1 + tlsdev::kRegionPad);
-    a.chunk_lists = ctx->d_lists.ptr; a.list_stride = (long long)ctx->list_stride; a.hdr_bytes = ctx->hdr_bytes;
+    a.chunk_lists = ctx->d_lists.ptr; a.list_stride = (long long)ctx->list_stride; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
     hipError_t e;
     if (ctx->resident)
-        e = ctx->uniform_w ? launch_variant<true, true, unsigned short>(ctx, a)
-                           : launch_variant<true, false, unsigned short>(ctx, a);
+        e = ctx->uniform_w ? launch_variant<true, true, false, unsigned short>(ctx, a)
+                           : launch_variant<true, false, false, unsigned short>(ctx, a);
+    else if (ctx->stage_c)
+        e = ctx->uniform_w ? launch_variant<false, true, true, unsigned int>(ctx, a)
+                           : launch_variant<false, false, true, unsigned int>(ctx, a);
     else
-        e = ctx->uniform_w ? launch_variant<false, true, unsigned int>(ctx, a)
-                           : launch_variant<false, false, unsigned int>(ctx, a);
+        e = ctx->uniform_w ? launch_variant<false, true, false, unsigned int>(ctx, a)
+                           : launch_variant<false, false, false, unsigned int>(ctx, a);
     if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     ctx->executed = true;
     ctx->counted = count_work;
@@ -394,16 +398,34 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->resident = resident_bytes <= kLdsPerCU && n <= 65535;
     if (ctx->resident) {
         ctx->nb = (int)n;
+        ctx->tile_len = 0; ctx->tile_halo = 0;
         ctx->lds_bytes = resident_bytes;
         const size_t per_cu = kLdsPerCU / resident_bytes;
         ctx->threads = per_cu >= 2 ? 512 : 1024;
         const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)ctx->threads);
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)wg_per_cu * ctx->n_cu);
     } else {
+        // the folded series lives in a per-workgroup HBM slab; phase 3 stages it through LDS in
+        // tiles of `tile_len` window-start positions plus a halo of the widest window
         ctx->nb = (int)std::min<int64_t>(n, 16384);
-        ctx->lds_bytes = hdr + 4 * (size_t)ctx->nb;
-        ctx->threads = 512;
-        ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)2 * ctx->n_cu);
+        const size_t halo = (size_t)W + 4 * tlsdev::kMaxTiledStride + 2 * tlsdev::kU + 4;
+        const size_t unit = (size_t)tlsdev::kR * tlsdev::kWave;  // tile bounds: multiples of 320
+        // staged per tile: e (or e*w), w for per-point weights, and the prefix sum C if it fits
+        size_t buffers = (uniform ? 1 : 2) + 1;
+        size_t cap_doubles = (kLdsPerCU - hdr) / 8 / buffers;
+        ctx->stage_c = cap_doubles >= halo + unit;
+        if (!ctx->stage_c) { buffers -= 1; cap_doubles = (kLdsPerCU - hdr) / 8 / buffers; }
+        if (cap_doubles < halo + unit) return fail(ctx, TLS_E_ARG, "widest transit window does not fit the LDS tile");
+        const size_t cap_tile = (cap_doubles - halo) / unit * unit;
+        const size_t n_tiles = ((size_t)M + cap_tile - 1) / cap_tile;
+        size_t tile = (((size_t)M + n_tiles - 1) / n_tiles + unit - 1) / unit * unit;
+        if (tile > cap_tile) tile = cap_tile;
+        ctx->tile_len = (int)tile; ctx->tile_halo = (int)halo;
+        const size_t cumsum_bytes = 8 * (2 * (size_t)tlsdev::kCumsumChunk + 2);
+        ctx->lds_bytes = hdr + std::max<size_t>(std::max<size_t>(4 * (size_t)ctx->nb, cumsum_bytes),
+                                                buffers * 8 * (tile + halo));
+        ctx->threads = 1024;
+        ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)ctx->n_cu);
         TLS_HIP(ctx, ctx->d_scratch.reserve((size_t)ctx->blocks * regions * region_doubles));
     }
     // per-width work units of phase 3 (M is fixed for the plan, so these are period independent)

@@ -54,7 +54,7 @@ namespace tlsdev {
 
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
-constexpr int kPhases = 12;    // fold+count, scan, scatter, rank, gather+patch, cumsum, predicate, chi2
+constexpr int kPhases = 14;    // fold+count, scan, scatter, rank, gather+patch, cumsum, predicate, chi2
 constexpr int kR = 5;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
 constexpr int kU = 8;          // template taps per unrolled iteration
 constexpr int kMaxTiledStride = 5;  // T0 strides up to this use the kR-window dot product
@@ -153,6 +153,8 @@ struct SearchArgs {
     int n, W, M;            // points, patch length, n + W
     int n_periods, n_widths, nb;  // nb: sort buckets
     int hdr_bytes;          // LDS header: fixed part + per-row tables (16-B multiple)
+    int tile_len;           // non-resident: window-start positions per LDS tile (multiple of 320)
+    int tile_halo;          // non-resident: samples staged behind a tile (widest window + slack)
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period, double epoch) {
@@ -286,6 +288,7 @@ __device__ __forceinline__ double binade_value(long long S, int m) {
 }
 
 // LDS scratch of the prefix-sum routines
+constexpr int kCumsumChunk = 8192;  // non-resident variant: elements scanned per LDS round trip
 constexpr int kMaxSeg = 32;   // binade changes handled per block by the one-pass variant
 constexpr int kPerMax = 16;   // elements per thread and block in the one-pass variant
 struct SegAcc {               // scan element of the one-pass variant
@@ -402,7 +405,7 @@ __device__ __forceinline__ SegAcc seg_combine(const SegAcc& x, const SegAcc& y) 
     return z;
 }
 
-// C[0] = 0, C[k+1] = fl(C[k] + f[k]) for k < count; all threads of the workgroup call this.
+// C[0] = s_start, C[k+1] = fl(C[k] + f[k]) for k < count; all threads of the workgroup call this.
 //
 // One-pass variant on top of the binade scan above.  A plain (re-associated) parallel prefix
 // sum P first predicts WHERE the running sum changes binade -- P is within ~1e-13 of the
@@ -414,13 +417,13 @@ __device__ __forceinline__ SegAcc seg_combine(const SegAcc& x, const SegAcc& y) 
 // Whatever fails verification is redone from that point by the per-binade routine, so the
 // result is always the sequential sum, bit for bit.
 __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double* C, int count, CumsumScratch* cs,
-                                               unsigned long long* dbg = nullptr) {
+                                               unsigned long long* dbg = nullptr, double s_start = 0.0) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    if (tid == 0) C[0] = 0.0;
+    if (tid == 0) C[0] = s_start;
     int k0 = 0;
-    double s0 = 0.0;
+    double s0 = s_start;
     const int block_len = nt * kPerMax;
     while (k0 < count) {
         const int kb = k0 + block_len < count ? k0 + block_len : count;
@@ -735,7 +738,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
     pc.mark(3);
 }
 
-template <bool RESIDENT, bool UNIFORM_W, typename IdxT>
+template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT>
 __global__ void __launch_bounds__(1024, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -790,7 +793,7 @@ tls_search_kernel(const SearchArgs a) {
         // ---- fetch the next period from the queue ----------------------------------
         if (tid == 0) s_work[0] = (int)atomicAdd(a.queue, 1u);
         __syncthreads();
-        const int work = s_work[0];
+        const int work = __builtin_amdgcn_readfirstlane(s_work[0]);
         __syncthreads();
         if (work >= a.n_periods) break;
         const int p = a.order[work];
@@ -832,7 +835,24 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup
-        exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
+        if constexpr (RESIDENT) {
+            exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
+        } else {
+            // the series is in the HBM slab: run the scan on LDS copies, kCumsumChunk elements a time
+            double* f_l = reinterpret_cast<double*>(smem + a.hdr_bytes);
+            double* c_l = f_l + kCumsumChunk;
+            double carry = 0.0;
+            for (int c0 = 0; c0 < M; c0 += kCumsumChunk) {
+                const int len = M - c0 < kCumsumChunk ? M - c0 : kCumsumChunk;
+                for (int k = tid; k < len; k += nt) f_l[k] = regA[c0 + k];
+                __syncthreads();
+                exact_sequential_cumsum(f_l, c_l, len, cumsum_scratch, a.phase_cycles, carry);
+                __syncthreads();
+                for (int k = tid; k <= len; k += nt) regB[c0 + k] = c_l[k];
+                carry = c_l[len];
+                __syncthreads();
+            }
+        }
         // sentinels behind C: a window that would start past the end of the T0 grid sees an
         // absurdly deep "mean" and fails the depth predicate without any bounds test
         if (tid < kRegionPad) regB[M + 1 + tid] = 1.0e300;
@@ -844,9 +864,47 @@ tls_search_kernel(const SearchArgs a) {
             if constexpr (!UNIFORM_W) e *= regW[k];
             regA[k] = e;
         }
-        const int k_lo = s_work[1], k_hi = s_work[2], k_x = s_work[3], n_rows = k_hi - k_lo;
+        // wave-uniform by construction; say so, or the template taps stop being scalar loads
+        const int k_lo = __builtin_amdgcn_readfirstlane(s_work[1]);
+        const int k_hi = __builtin_amdgcn_readfirstlane(s_work[2]);
+        const int k_x = __builtin_amdgcn_readfirstlane(s_work[3]);
+        const int n_rows = k_hi - k_lo;
         __syncthreads();
         pc.mark(8);
+
+        Best best;
+        best.stat = INFINITY; best.td = 0.0; best.k = 0x7fffffff; best.i = 0x7fffffff;
+        unsigned long long n_eval = 0, n_steps = 0;
+        // ---- phase 3 runs over TILES of window-start positions [p_lo, p_hi).  Resident variant:
+        // one tile, the folded series already sits in LDS.  Otherwise the series is in the HBM slab
+        // and each tile (+ halo = widest window) is staged into LDS first; windows are owned by the
+        // tile that contains their first sample.
+        const int tile_len = RESIDENT ? (1 << 30) : a.tile_len;
+        for (int p_lo = 0; p_lo < M; p_lo += tile_len) {
+        const int p_hi = p_lo + tile_len;
+        const double* e_base = regA;   // e_base[b] = sample b of e (or e*w)
+        const double* w_base = regW;
+        const double* c_base = regB;   // c_base[i] = C[i] (STAGE_C: the tile's LDS copy)
+        if constexpr (!RESIDENT) {
+            double* tile_e = reinterpret_cast<double*>(smem + a.hdr_bytes);
+            const int staged = a.tile_len + a.tile_halo;
+            double* tile_w = tile_e + staged;
+            double* tile_c = UNIFORM_W ? tile_w : tile_w + staged;
+            __syncthreads();  // the previous tile (or the sort histogram) is no longer read
+            for (int k = tid; k < staged; k += nt) {
+                const int src = p_lo + k;
+                const bool in = src < M + 1 + kRegionPad;
+                tile_e[k] = in ? regA[src] : 0.0;
+                if constexpr (!UNIFORM_W) tile_w[k] = in ? regW[src] : 0.0;
+                if constexpr (STAGE_C) tile_c[k] = in ? regB[src] : 1.0e300;
+            }
+            for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;
+            e_base = tile_e - p_lo;
+            w_base = tile_w - p_lo;
+            if constexpr (STAGE_C) c_base = tile_c - p_lo;
+            __syncthreads();
+            pc.mark(12);
+        }
 
         // ---- phase 3a: depth predicate over every trial cell -> lists of live units ----
         // dense rows: a lane owns kR consecutive T0 positions and walks all durations with
@@ -854,13 +912,15 @@ tls_search_kernel(const SearchArgs a) {
         // (the mean is monotone in the window sum, so min() decides exactly).
         if (k_x > k_lo) {
             const int units0 = widths_c[k_lo].n_chunks;  // the shortest width has the most positions
-            for (int tile = wave; tile * kWave < units0; tile += nw) {
-                const int unit = tile * kWave + lane;
+            const int unit_lo = p_lo / kR;               // tile bounds are multiples of kR * 64
+            const int unit_hi = p_hi / kR < units0 ? p_hi / kR : units0;
+            for (int tile = wave; unit_lo + tile * kWave < unit_hi; tile += nw) {
+                const int unit = unit_lo + tile * kWave + lane;
                 const int u0 = unit * kR;
                 const int u0c = u0 < M - kR ? u0 : M - kR;
                 double c_lo[kR];
 #pragma unroll
-                for (int r = 0; r < kR; ++r) c_lo[r] = regB[u0c + r];
+                for (int r = 0; r < kR; ++r) c_lo[r] = c_base[u0c + r];
                 // kRowBatch durations per step: all LDS reads of the step are in flight together
                 constexpr int kRowBatch = 4;
                 for (int k = k_lo; k < k_x; k += kRowBatch) {
@@ -874,7 +934,7 @@ tls_search_kernel(const SearchArgs a) {
                         inv[j] = widths_c[kk].inv_d;
                         const int hi0 = u0 + dv[j] < M + 1 ? u0 + dv[j] : M + 1;  // past the grid: sentinels
 #pragma unroll
-                        for (int r = 0; r < kR; ++r) c_hi[j][r] = regB[hi0 + r];
+                        for (int r = 0; r < kR; ++r) c_hi[j][r] = c_base[hi0 + r];
                     }
 #pragma unroll
                     for (int j = 0; j < kRowBatch; ++j) {
@@ -889,13 +949,14 @@ tls_search_kernel(const SearchArgs a) {
                             const int cls = depth_class(dC[j], inv[j], dmin);
                             bool live = cls > 0;
                             if (cls < 0) live = depth_exact(dC[j], (double)dv[j], dmin);  // rare: on the threshold
-                            push_live(live, (unsigned int)unit, &rt.live[k + j - k_lo],
+                            push_live(live && unit < unit_hi, (unsigned int)unit, &rt.live[k + j - k_lo],
                                       chunk_list + widths_c[k + j].list_base, lane);
                         }
                     }
                 }
             }
         }
+        pc.mark(13);
         // strided rows (long durations, core.py:50-58): kR strided positions per lane while the
         // stride allows the tiled dot product, else one position per lane
         for (int k = k_x > k_lo ? k_x : k_lo; k < k_hi; ++k) {
@@ -904,10 +965,13 @@ tls_search_kernel(const SearchArgs a) {
             const double inv_d = widths_c[k].inv_d;
             unsigned int* list = chunk_list + widths_c[k].list_base;
             if (xth <= kMaxTiledStride) {
-                for (int tile = wave; tile * kWave < n_units; tile += nw) {
-                    const int unit = tile * kWave + lane;
+                const int span = kR * xth;  // samples between the first windows of two units
+                const int unit_lo = (p_lo + span - 1) / span;
+                const int unit_hi = (p_hi + span - 1) / span < n_units ? (p_hi + span - 1) / span : n_units;
+                for (int tile = wave; unit_lo + tile * kWave < unit_hi; tile += nw) {
+                    const int unit = unit_lo + tile * kWave + lane;
                     const int uc = unit < n_units ? unit : n_units - 1;
-                    const double* c0 = regB + uc * kR * xth;
+                    const double* c0 = c_base + uc * kR * xth;
                     double c_lo[kR], c_hi[kR];
 #pragma unroll
                     for (int r = 0; r < kR; ++r) { c_lo[r] = c0[r * xth]; c_hi[r] = c0[r * xth + d]; }
@@ -917,15 +981,17 @@ tls_search_kernel(const SearchArgs a) {
                     const int cls = depth_class(dC, inv_d, dmin);
                     bool live = cls > 0;
                     if (cls < 0) live = depth_exact(dC, (double)d, dmin);
-                    push_live(live && unit < n_units, (unsigned int)unit, &rt.live[k - k_lo], list, lane);
+                    push_live(live && unit < unit_hi, (unsigned int)unit, &rt.live[k - k_lo], list, lane);
                 }
             } else {
-                for (int tile = wave; tile * kWave < n_pos; tile += nw) {
-                    const int unit = tile * kWave + lane;
+                const int unit_lo = (p_lo + xth - 1) / xth;
+                const int unit_hi = (p_hi + xth - 1) / xth < n_pos ? (p_hi + xth - 1) / xth : n_pos;
+                for (int tile = wave; unit_lo + tile * kWave < unit_hi; tile += nw) {
+                    const int unit = unit_lo + tile * kWave + lane;
                     bool live = false;
-                    if (unit < n_pos) {
+                    if (unit < unit_hi) {
                         const int i = unit * xth;
-                        const double dC = regB[i + d] - regB[i];
+                        const double dC = c_base[i + d] - c_base[i];
                         const int cls = depth_class(dC, inv_d, dmin);
                         live = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
                     }
@@ -955,13 +1021,10 @@ tls_search_kernel(const SearchArgs a) {
         pc.mark(6);
 
         // ---- phase 3b: sliding dot products, 64 live units of one duration per wave ----
-        Best best;
-        best.stat = INFINITY; best.td = 0.0; best.k = 0x7fffffff; best.i = 0x7fffffff;
-        unsigned long long n_eval = 0, n_steps = 0;
         {
             // batches are numbered from the widest row down (long templates first) and handed out
             // dynamically through an LDS ticket counter
-            const unsigned int total_batches = rt.batch_start[n_rows];
+            const unsigned int total_batches = (unsigned int)__builtin_amdgcn_readfirstlane((int)rt.batch_start[n_rows]);
             int row = n_rows > 0 ? n_rows - 1 : 0;  // batch numbers only decrease within a wave
             for (;;) {
                 unsigned int g = 0;
@@ -969,49 +1032,52 @@ tls_search_kernel(const SearchArgs a) {
                 g = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
                 if (g >= total_batches) break;
                 const unsigned int gg = total_batches - 1 - g;
-                while (gg < rt.batch_start[row]) --row;
-                const unsigned int slot = (gg - rt.batch_start[row]) * kWave + lane;
-                const bool have = slot < rt.live[row];
-                const int unit = have ? (int)chunk_list[widths_c[k_lo + row].list_base + slot] : 0;
-                const int k = k_lo + row;
+                while (gg < (unsigned int)__builtin_amdgcn_readfirstlane((int)rt.batch_start[row])) --row;
+                // every per-row constant is fetched with wave-uniform (scalar) loads BEFORE any
+                // lane-dependent branch: an address that reaches a load through a divergent join
+                // is treated as divergent and the template taps would stop being scalar loads
+                const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
                 const int d = widths_c[k].width, L = widths_c[k].q_len, xth = widths_c[k].xth;
-                const int q_offset = widths_c[k].q_offset;
+                const int q_offset = widths_c[k].q_offset, list_base = widths_c[k].list_base;
                 const double overshoot = widths_c[k].overshoot, sum_q2 = widths_c[k].sum_q2;
                 const double inv_d = widths_c[k].inv_d, dd = (double)d;
+                const unsigned int slot = (gg - rt.batch_start[row]) * kWave + lane;
+                const bool have = slot < rt.live[row];
+                const int unit = have ? (int)chunk_list[list_base + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
                 const unsigned long long evals_before = n_eval;
                 if (xth <= kMaxTiledStride) {
                     // kR windows per lane, xth samples apart
                     const int u0 = unit * kR;
                     const int b = u0 * xth;
-                    const double* e = regA + b;
+                    const double* e = e_base + b;
                     double Bv[kR] = {0, 0, 0, 0, 0}, Av[kR] = {0, 0, 0, 0, 0};
                     const int Lr = L;
                     if constexpr (UNIFORM_W) {
                         switch (xth) {
-                            case 1: dot_windows<RESIDENT, 1>(e, q, Lr, Bv); break;
-                            case 2: dot_windows<RESIDENT, 2>(e, q, Lr, Bv); break;
-                            case 3: dot_windows<RESIDENT, 3>(e, q, Lr, Bv); break;
-                            case 4: dot_windows<RESIDENT, 4>(e, q, Lr, Bv); break;
-                            default: dot_windows<RESIDENT, 5>(e, q, Lr, Bv); break;
+                            case 1: dot_windows<true, 1>(e, q, Lr, Bv); break;
+                            case 2: dot_windows<true, 2>(e, q, Lr, Bv); break;
+                            case 3: dot_windows<true, 3>(e, q, Lr, Bv); break;
+                            case 4: dot_windows<true, 4>(e, q, Lr, Bv); break;
+                            default: dot_windows<true, 5>(e, q, Lr, Bv); break;
                         }
 #pragma unroll
                         for (int r = 0; r < kR; ++r) Av[r] = sum_q2;
                     } else {
-                        const double* wv = regW + b;
+                        const double* wv = w_base + b;
                         const const_f64_ptr q2 = q2_all + q_offset;
                         switch (xth) {
-                            case 1: dot_windows_weighted<RESIDENT, 1>(e, wv, q, q2, Lr, Bv, Av); break;
-                            case 2: dot_windows_weighted<RESIDENT, 2>(e, wv, q, q2, Lr, Bv, Av); break;
-                            case 3: dot_windows_weighted<RESIDENT, 3>(e, wv, q, q2, Lr, Bv, Av); break;
-                            case 4: dot_windows_weighted<RESIDENT, 4>(e, wv, q, q2, Lr, Bv, Av); break;
-                            default: dot_windows_weighted<RESIDENT, 5>(e, wv, q, q2, Lr, Bv, Av); break;
+                            case 1: dot_windows_weighted<true, 1>(e, wv, q, q2, Lr, Bv, Av); break;
+                            case 2: dot_windows_weighted<true, 2>(e, wv, q, q2, Lr, Bv, Av); break;
+                            case 3: dot_windows_weighted<true, 3>(e, wv, q, q2, Lr, Bv, Av); break;
+                            case 4: dot_windows_weighted<true, 4>(e, wv, q, q2, Lr, Bv, Av); break;
+                            default: dot_windows_weighted<true, 5>(e, wv, q, q2, Lr, Bv, Av); break;
                         }
                     }
                     if (have) {
                         double cl[kR], ch[kR];
 #pragma unroll
-                        for (int r = 0; r < kR; ++r) { cl[r] = regB[b + r * xth]; ch[r] = regB[b + r * xth + d]; }
+                        for (int r = 0; r < kR; ++r) { cl[r] = c_base[b + r * xth]; ch[r] = c_base[b + r * xth + d]; }
 #pragma unroll
                         for (int r = 0; r < kR; ++r)
                             consider(best, cl[r], ch[r], b + r * xth, inv_d, dd, dmin, overshoot, Av[r], Bv[r], k, n_eval);
@@ -1019,12 +1085,12 @@ tls_search_kernel(const SearchArgs a) {
                 } else {
                     // wide T0 strides: one window per lane
                     const int i = unit * xth;
-                    const double* e = regA + i;
+                    const double* e = e_base + i;
                     double B0 = 0, B1 = 0, A0 = 0, A1 = 0;
                     if constexpr (UNIFORM_W) {
                         for (int t0 = 0; t0 < L; t0 += kU) {
                             double x[kU];
-                            load_taps<RESIDENT>(e + t0, x);
+                            load_taps<true>(e + t0, x);
                             const const_f64_ptr qs = q + t0;
 #pragma unroll
                             for (int u = 0; u < kU; u += 2) {
@@ -1034,12 +1100,12 @@ tls_search_kernel(const SearchArgs a) {
                         }
                         A0 = sum_q2;
                     } else {
-                        const double* wv = regW + i;
+                        const double* wv = w_base + i;
                         const const_f64_ptr q2 = q2_all + q_offset;
                         for (int t0 = 0; t0 < L; t0 += kU) {
                             double x[kU], z[kU];
-                            load_taps<RESIDENT>(e + t0, x);
-                            load_taps<RESIDENT>(wv + t0, z);
+                            load_taps<true>(e + t0, x);
+                            load_taps<true>(wv + t0, z);
                             const const_f64_ptr qs = q + t0;
                             const const_f64_ptr ps = q2 + t0;
 #pragma unroll
@@ -1049,11 +1115,12 @@ tls_search_kernel(const SearchArgs a) {
                             }
                         }
                     }
-                    if (have) consider(best, regB[i], regB[i + d], i, inv_d, dd, dmin, overshoot, A0 + A1, B0 + B1, k, n_eval);
+                    if (have) consider(best, c_base[i], c_base[i + d], i, inv_d, dd, dmin, overshoot, A0 + A1, B0 + B1, k, n_eval);
                 }
                 n_steps += (n_eval - evals_before) * (unsigned long long)L;
             }
         }
+        }  // position tiles
         __syncthreads();
         pc.mark(7);
 
