@@ -319,3 +319,15 @@ def test_t0_fit_residuals_match_host_restatement(gpu):
     want = t0_fit_residuals_host(t, f, 3.3, signal, epochs, 39)
     got = gpu.t0_fit_residuals(t, f, 3.3, signal, epochs, 39)
     numpy.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+
+
+def test_too_short_series_is_rejected(gpu):
+    from conftest import SimpleTable
+    t = numpy.linspace(0.0, 1.0, 9)
+    y = numpy.ones(9)
+    table = SimpleTable(numpy.array([0.5, 0.6]), numpy.array([0, 1]), numpy.array([1, 1]),
+                        numpy.array([1, 2]), numpy.array([1.0, 1.0]))
+    params = dict(transit_depth_min=1e-5, R_star_min=0.13, R_star_max=3.5, M_star_min=0.1,
+                  M_star_max=1.0, T0_fit_margin=0.01)
+    with pytest.raises(RuntimeError, match="too short"):
+        gpu.search(t, y, numpy.full(9, 0.01), numpy.array([0.3]), table, params)

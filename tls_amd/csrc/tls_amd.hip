@@ -365,6 +365,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     if (W % 2 != 0) W += 1;
     const int64_t M = n + W;
     if (M + 1 > 0x7fffffff / 4) return fail(ctx, TLS_E_ARG, "series too long");
+    if (M < 4 * tlsdev::kR) return fail(ctx, TLS_E_ARG, "series too short (need n + widest width >= 20 samples)");
 
     // per-period duration window (core.py:143-156) and cost
     double t_min = t[0], t_max = t[0];
@@ -392,7 +393,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     const size_t regions = uniform ? 2 : 3;
     const size_t region_doubles = (size_t)(M + 1 + tlsdev::kRegionPad);
     // LDS header: fixed part + per-row live counters and batch prefix (+ the batch counter)
-    const size_t hdr = ((size_t)tlsdev::kFixedHeader + 4 * (2 * widths.size() + 2) + 15) / 16 * 16;
+    const size_t hdr = ((size_t)tlsdev::kFixedHeader + 4 * (3 * widths.size() + 2) + 15) / 16 * 16;
     const size_t resident_bytes = hdr + regions * 8 * region_doubles;
     ctx->hdr_bytes = (int)hdr;
     ctx->resident = resident_bytes <= kLdsPerCU && n <= 65535;

@@ -54,9 +54,10 @@ namespace tlsdev {
 
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
-constexpr int kPhases = 14;    // fold+count, scan, scatter, rank, gather+patch, cumsum, predicate, chi2
+constexpr int kPhases = 22;    // fold+count, scan, scatter, rank, gather+patch, cumsum, predicate, chi2
 constexpr int kR = 5;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
 constexpr int kU = 8;          // template taps per unrolled iteration
+constexpr int kSparseRow = 40;      // rows with at most this many live chunks are re-listed position by position
 constexpr int kMaxTiledStride = 5;  // T0 strides up to this use the kR-window dot product
 constexpr int kPadFront = 24;  // zeros in front of every template row (>= (kR-1)*kMaxTiledStride, 64-B multiple)
 constexpr int kPadBack = 40;   // zeros behind every template row (>= 2*kU + (kR-1)*kMaxTiledStride)
@@ -320,6 +321,17 @@ __device__ __forceinline__ int unbiased_exponent(double x, long long* mantissa) 
     return m;
 }
 
+// value of lane `src` (wave-uniform index) without a trip through the LDS crossbar
+__device__ __forceinline__ int lane_value(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ long long lane_value(long long v, int src) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffLL), src);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ double lane_value(double v, int src) {
+    return __longlong_as_double(lane_value(__double_as_longlong(v), src));
+}
+
 // Robust variant: C[k+1] = fl(C[k] + f[k]) for k in [k_a, k_end), starting from C[k_a] = s_a.
 // One workgroup scan per binade of the running sum; all threads of the workgroup call this.
 __device__ __forceinline__ void sequential_cumsum_by_binade(const double* f, double* C, int k_a0, int k_end, double s_a,
@@ -418,6 +430,7 @@ __device__ __forceinline__ SegAcc seg_combine(const SegAcc& x, const SegAcc& y) 
 // result is always the sequential sum, bit for bit.
 __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double* C, int count, CumsumScratch* cs,
                                                unsigned long long* dbg = nullptr, double s_start = 0.0) {
+    PhaseClock cpc; cpc.start(dbg);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -450,6 +463,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             if (hi == kb && lo < hi) C[kb] = run;
         }
         __syncthreads();
+        cpc.mark(14);
         // ---- B1: predicted binade changes and their running count ----
         unsigned int crossmask = 0;   // bit e: element lo+e changes the binade (or opens the block)
         int m_lo = 0;
@@ -474,6 +488,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
         int cnt_pre = cnt_incl - n_cross_local;
         int n_seg = 0;
         for (int v = 0; v < nw; ++v) { const int c = cs->cross[v]; n_seg += c; if (v < wave) cnt_pre += c; }
+        cpc.mark(15);
         // ---- B2: one walk over the elements: step maps, tables of the binade changes ----
         SegAcc acc; acc.cnt = n_cross_local; acc.reset = n_cross_local > 0;
         ParityInc head; head.i0 = 0; head.i1 = 0;   // composite in front of the first change in my slice
@@ -497,6 +512,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             if (first) head = seg;
             acc.map = seg;
         }
+        cpc.mark(16);
         SegAcc inc = acc;
 #pragma unroll
         for (int dlt = 1; dlt < kWave; dlt <<= 1) {
@@ -531,6 +547,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             }
         }
         __syncthreads();
+        cpc.mark(17);
         // ---- D: wave 0 chains the binade changes in fp64 and verifies the prediction ----
         if (wave == 0) {
             const int n_proc = n_seg < kMaxSeg ? n_seg : kMaxSeg;
@@ -544,12 +561,12 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             double fail_s = 0.0;
             bool failed = false;
             for (int j = 0; j < n_proc; ++j) {
-                const int c = __shfl(my_c, j, kWave);
-                const double s_new = s_end + __shfl(my_f, j, kWave);  // the sequential step itself
+                const int c = lane_value(my_c, j);
+                const double s_new = s_end + lane_value(my_f, j);  // the sequential step itself
                 long long S0;
                 const int m = unbiased_exponent(s_new, &S0);
-                if (m != __shfl(my_m, j, kWave)) { failed = true; fail_k = c; fail_s = s_end; break; }
-                const long long t0 = __shfl(my_T.i0, j, kWave), t1 = __shfl(my_T.i1, j, kWave);
+                if (m != lane_value(my_m, j)) { failed = true; fail_k = c; fail_s = s_end; break; }
+                const long long t0 = lane_value(my_T.i0, j), t1 = lane_value(my_T.i1, j);
                 const long long S_end = S0 + ((S0 & 1) ? t1 : t0);
                 if (lane == j) { my_f = s_new; my_T.i0 = S0; }  // keep C[c+1] and the start mantissa
                 if (S_end >= kBinadeEnd) { failed = true; fail_k = c + 1; fail_s = s_new; ok = -(j + 1); break; }
@@ -565,6 +582,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             if (lane == 0) { cs->n_ok = ok; cs->fail_k = fail_k; cs->fail_s = fail_s; }
         }
         __syncthreads();
+        cpc.mark(18);
         // ---- E: exact values of every element inside a verified segment ----
         {
             const int n_ok = cs->n_ok;
@@ -588,6 +606,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             }
         }
         __syncthreads();
+        cpc.mark(19);
         const int fail_k = cs->fail_k;
         const double fail_s = cs->fail_s;
         __syncthreads();
@@ -614,6 +633,7 @@ __device__ __forceinline__ bool depth_exact(double dC, double dd, double dmin) {
 // Per-row (= per in-range trial duration) bookkeeping of one period, in the LDS header.
 struct RowTables {
     unsigned int* live;         // [rows]   live units found (atomic tail of the row's list)
+    unsigned int* singles;      // [rows]   > 0: the row was re-listed as that many single positions
     unsigned int* batch_start;  // [rows+1] prefix of 64-unit batches (phase 3b work items)
     unsigned int* next_batch;   // [1]      dynamic batch counter
 };
@@ -756,7 +776,8 @@ tls_search_kernel(const SearchArgs a) {
     static_assert(sizeof(CumsumScratch) <= kCumsumScratchBytes, "cumsum scratch does not fit its slot");
     RowTables rt;
     rt.live = reinterpret_cast<unsigned int*>(smem + kFixedHeader);
-    rt.batch_start = rt.live + a.n_widths;
+    rt.singles = rt.live + a.n_widths;
+    rt.batch_start = rt.singles + a.n_widths;
     rt.next_batch = rt.batch_start + (a.n_widths + 1);
     double *regA, *regB, *regW = nullptr;
     unsigned int* cnt;
@@ -1001,11 +1022,47 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
         pc.mark(9);
+        // Sparse rows: a handful of live chunks would still occupy a whole 64-lane batch with kR
+        // FMAs per tap.  Re-list such rows position by position (only the positions that pass the
+        // predicate) behind their chunk list; phase 3b then runs them one window per lane, which
+        // costs a fraction of the tiled form when most lanes would idle.
+        for (int row = wave; row < n_rows; row += nw) {
+            const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
+            const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
+            const int xth = widths_c[k].xth, n_units = widths_c[k].n_chunks;
+            unsigned int count = 0;
+            if (xth <= kMaxTiledStride && n_live > 0 && n_live <= kSparseRow && n_units >= (kR + 1) * kSparseRow) {
+                const int d = widths_c[k].width;
+                const double inv_d = widths_c[k].inv_d;
+                unsigned int* list = chunk_list + widths_c[k].list_base;
+                for (int base = 0; base < n_live * kR; base += kWave) {
+                    const int idx = base + lane;
+                    bool pass = false;
+                    int u = 0;
+                    if (idx < n_live * kR) {
+                        u = (int)list[idx / kR] * kR + idx % kR;   // T0 position index
+                        const int i = u * xth;
+                        const double dC = c_base[i + d] - c_base[i];   // past the grid: sentinel
+                        const int cls = depth_class(dC, inv_d, dmin);
+                        pass = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
+                    }
+                    const unsigned long long mask = __ballot(pass);
+                    if (pass) list[n_live + count + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)u;
+                    count += (unsigned int)__popcll(mask);
+                }
+            }
+            if (lane == 0) rt.singles[row] = count;
+        }
+        __syncthreads();
         if (wave == 0) {  // exclusive scan of the batch counts over the rows
             unsigned int carry = 0;
             for (int r0 = 0; r0 < n_rows; r0 += kWave) {
                 const int row = r0 + lane;
-                const unsigned int mine = row < n_rows ? (rt.live[row] + kWave - 1) / kWave : 0u;
+                unsigned int mine = 0;
+                if (row < n_rows) {
+                    const unsigned int units = rt.singles[row] ? rt.singles[row] : rt.live[row];
+                    mine = (units + kWave - 1) / kWave;
+                }
                 unsigned int incl = mine;
 #pragma unroll
                 for (int dlt = 1; dlt < kWave; dlt <<= 1) {
@@ -1042,11 +1099,14 @@ tls_search_kernel(const SearchArgs a) {
                 const double overshoot = widths_c[k].overshoot, sum_q2 = widths_c[k].sum_q2;
                 const double inv_d = widths_c[k].inv_d, dd = (double)d;
                 const unsigned int slot = (gg - rt.batch_start[row]) * kWave + lane;
-                const bool have = slot < rt.live[row];
-                const int unit = have ? (int)chunk_list[list_base + slot] : 0;
+                const int n_singles = __builtin_amdgcn_readfirstlane((int)rt.singles[row]);
+                const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
+                const bool have = slot < (unsigned int)(n_singles ? n_singles : n_live);
+                // re-listed rows keep their positions behind the chunk entries
+                const int unit = have ? (int)chunk_list[list_base + (n_singles ? n_live : 0) + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
                 const unsigned long long evals_before = n_eval;
-                if (xth <= kMaxTiledStride) {
+                if (xth <= kMaxTiledStride && n_singles == 0) {
                     // kR windows per lane, xth samples apart
                     const int u0 = unit * kR;
                     const int b = u0 * xth;
@@ -1083,7 +1143,7 @@ tls_search_kernel(const SearchArgs a) {
                             consider(best, cl[r], ch[r], b + r * xth, inv_d, dd, dmin, overshoot, Av[r], Bv[r], k, n_eval);
                     }
                 } else {
-                    // wide T0 strides: one window per lane
+                    // wide T0 strides and re-listed sparse rows: one window per lane
                     const int i = unit * xth;
                     const double* e = e_base + i;
                     double B0 = 0, B1 = 0, A0 = 0, A1 = 0;
