@@ -409,7 +409,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // the folded series lives in a per-workgroup HBM slab; phase 3 stages it through LDS in
         // tiles of `tile_len` window-start positions plus a halo of the widest window
         ctx->nb = (int)std::min<int64_t>(n, 16384);
-        const size_t halo = (size_t)W + 4 * tlsdev::kMaxTiledStride + 2 * tlsdev::kU + 4;
+        const size_t halo = (size_t)W + (tlsdev::kR - 1) * tlsdev::kMaxTiledStride + 2 * tlsdev::kU + 4;
         const size_t unit = (size_t)tlsdev::kR * tlsdev::kWave;  // tile bounds: multiples of 320
         // staged per tile: e (or e*w), w for per-point weights, and the prefix sum C if it fits
         size_t buffers = (uniform ? 1 : 2) + 1;

@@ -55,13 +55,16 @@ namespace tlsdev {
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
 constexpr int kPhases = 22;    // fold+count, scan, scatter, rank, gather+patch, cumsum, predicate, chi2
-constexpr int kR = 5;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
+#ifndef TLS_KR
+#define TLS_KR 5
+#endif
+constexpr int kR = TLS_KR;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
 constexpr int kU = 8;          // template taps per unrolled iteration
 constexpr int kSparseRow = 40;      // rows with at most this many live chunks are re-listed position by position
 constexpr int kMaxTiledStride = 5;  // T0 strides up to this use the kR-window dot product
-constexpr int kPadFront = 24;  // zeros in front of every template row (>= (kR-1)*kMaxTiledStride, 64-B multiple)
-constexpr int kPadBack = 40;   // zeros behind every template row (>= 2*kU + (kR-1)*kMaxTiledStride)
-constexpr int kRegionPad = 40; // spare entries behind every folded-series region (>= 2*kU + kR*kMaxTiledStride)
+constexpr int kPadFront = ((kR - 1) * kMaxTiledStride + 7) / 8 * 8;  // zeros in front of every template row (>= (kR-1)*kMaxTiledStride, 64-B multiple)
+constexpr int kPadBack = (2 * kU + (kR - 1) * kMaxTiledStride + 7) / 8 * 8;   // zeros behind every template row (>= 2*kU + (kR-1)*kMaxTiledStride)
+constexpr int kRegionPad = (2 * kU + kR * kMaxTiledStride + 7) / 8 * 8; // spare entries behind every folded-series region (>= 2*kU + kR*kMaxTiledStride)
 constexpr int kCumsumScratchBytes = 1920;  // >= sizeof(CumsumScratch), 16-B multiple
 constexpr int kFixedHeader = 560 + kCumsumScratchBytes;  // wsum[32] | wbest[16] | s_work[12] | cumsum scratch
 
@@ -1111,7 +1114,9 @@ tls_search_kernel(const SearchArgs a) {
                     const int u0 = unit * kR;
                     const int b = u0 * xth;
                     const double* e = e_base + b;
-                    double Bv[kR] = {0, 0, 0, 0, 0}, Av[kR] = {0, 0, 0, 0, 0};
+                    double Bv[kR], Av[kR];
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) { Bv[r] = 0.0; Av[r] = 0.0; }
                     const int Lr = L;
                     if constexpr (UNIFORM_W) {
                         switch (xth) {
