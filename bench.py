@@ -87,9 +87,25 @@ def main():
         args.gpus = world
     n_dev = _lib.device_count()
     ctx = _lib.Context(local_rank % max(n_dev, 1))
+    channel = None
+    collective = "none"
     if world > 1:
-        uid = rendezvous.share_unique_id(rank, world, addr, port, ctx.comm_unique_id)
-        ctx.comm_init(world, rank, uid)
+        # rank 0's RCCL unique id travels over the host channel; every rank then tries to join the
+        # communicator.  If RCCL cannot be brought up on this box on ANY rank, all ranks fall back to
+        # the host channel for the (tiny) result exchange and the output says so.
+        channel = rendezvous.HostChannel(rank, world, addr, port)
+        uid = channel.allgather_bytes(ctx.comm_unique_id() if rank == 0 else b"")[0]
+        ok, why = True, ""
+        try:
+            ctx.comm_init(world, rank, uid)
+        except RuntimeError as exc:
+            ok, why = False, str(exc)
+        if channel.all_true(ok):
+            collective = "rccl"
+        else:
+            collective = "host-tcp fallback (RCCL init failed: %s)" % (why or "on another rank")
+            if ok:
+                ctx.comm_destroy()
 
     # ---- synthetic input, resident in HBM before the timed region --------------------
     seed = rank if args.mode == "survey" else 0
@@ -111,30 +127,42 @@ def main():
     if job_cells is None:
         job_cells = info["grid_cells"] * world  # survey: one full grid per GPU per step
 
+    def barrier():
+        if collective == "rccl":
+            ctx.comm_barrier()
+        elif channel is not None:
+            channel.barrier()
+
+    def reduce_max(v):
+        if collective == "rccl":
+            return ctx.comm_max(v)
+        return channel.max(v) if channel is not None else v
+
     def step():
         ctx.execute()
-        if world > 1:
+        if collective == "rccl":
             ctx.comm_allgather_results(count_per_rank, world)  # results on every rank
+        elif channel is not None:
+            c, r, d = ctx.fetch()
+            channel.allgather_bytes(c.tobytes() + r.tobytes() + d.tobytes())
 
     for _ in range(args.warmup):
         step()
     ctx.synchronize()
     ctx.kernel_timing(reset=True)
-    if world > 1:
-        ctx.comm_barrier()
+    barrier()
     ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     ctx.synchronize()
-    if world > 1:
-        ctx.comm_barrier()
+    barrier()
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.kernel_timing(reset=True)
     if world > 1:
-        elapsed = ctx.comm_max(elapsed)
-        kernel_ms = ctx.comm_max(kernel_ms)
+        elapsed = reduce_max(elapsed)
+        kernel_ms = reduce_max(kernel_ms)
 
     # one counted pass (outside the timed region) for the work statistics
     ctx.execute(count_work=True)
@@ -180,7 +208,7 @@ def main():
                                        "survey mode, one light curve per GPU per step + RCCL "
                                        "all-gather" if args.mode == "survey" else
                                        "period grid sharded over the GPUs + RCCL all-gather"),
-                       "mode": args.mode, "sigma_ppm": 1e6 * (args.sigma or synthetic.CONFIGS[args.config][2]),
+                       "mode": args.mode, "collective": collective, "sigma_ppm": 1e6 * (args.sigma or synthetic.CONFIGS[args.config][2]),
                        "light_curves_per_step": world if args.mode == "survey" else 1,
                        "search_ms_per_light_curve": ms_per_step / (world if args.mode == "survey" else 1),
                        "power_call_wall_ms_per_light_curve": power_wall_ms,
@@ -201,9 +229,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(inp, info["grid_cells"])
         print(json.dumps(out), flush=True)
-    if world > 1:
-        ctx.comm_barrier()
+    barrier()
+    if collective == "rccl":
         ctx.comm_destroy()
+    if channel is not None:
+        channel.close()
     ctx.close()
 
 

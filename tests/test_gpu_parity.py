@@ -331,3 +331,19 @@ def test_too_short_series_is_rejected(gpu):
                   M_star_max=1.0, T0_fit_margin=0.01)
     with pytest.raises(RuntimeError, match="too short"):
         gpu.search(t, y, numpy.full(9, 0.01), numpy.array([0.3]), table, params)
+
+
+def test_survey_batch_equals_individual_searches(gpu):
+    """BASELINE config 5 in miniature: a batch on shared grids == one search per light curve."""
+    from tls_amd import survey
+    t, f0, kw = synthetic.config("k2_90d", seed=0)
+    fluxes = numpy.stack([synthetic.config("k2_90d", seed=s)[1] for s in range(4)])
+    periods, chi2, row, depth = survey.search_batch(t, fluxes, context=gpu, **kw)
+    assert chi2.shape == (4, 9679)
+    for k in (0, 3):
+        inp = synthetic.search_inputs(t, fluxes[k], **kw)
+        one = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+        numpy.testing.assert_array_equal(chi2[k], one[0])
+        numpy.testing.assert_array_equal(row[k], one[1])
+        numpy.testing.assert_array_equal(depth[k], one[2])
+    assert int(numpy.argmin(chi2[0])) == 7738
