@@ -347,3 +347,50 @@ def test_survey_batch_equals_individual_searches(gpu):
         numpy.testing.assert_array_equal(row[k], one[1])
         numpy.testing.assert_array_equal(depth[k], one[2])
     assert int(numpy.argmin(chi2[0])) == 7738
+
+
+def test_randomised_configurations_vs_oracle(gpu, oracle_lib):
+    """Seeded sweep over sizes, cadences, noise levels, weights, T0 strides, depth thresholds and
+    duration-grid steps: resident and tiled kernel variants, dense and strided T0 grids, uniform
+    and per-point weights, all against the oracle."""
+    rng = numpy.random.RandomState(2024)
+    n_cases = 0
+    for case in range(24):
+        span = float(rng.choice([8.0, 20.0, 45.0, 120.0]))
+        cadence = int(rng.choice([24, 48, 96, 200]))
+        n = int(span * cadence)
+        if n < 400 or n > 30000:
+            continue
+        sigma = float(rng.choice([3e-5, 2e-4, 1e-3]))
+        t = numpy.sort(3.0 + rng.uniform(0, span, n)) if case % 3 == 0 else numpy.linspace(3.0, 3.0 + span, n)
+        if case % 4 == 1:  # a gap
+            keep = numpy.ones(n, dtype=bool)
+            keep[n // 3: n // 3 + n // 10] = False
+            t = t[keep]
+        per = float(rng.uniform(1.5, span / 3))
+        from tls_amd import transit_model
+        flux = transit_model.light_curve(t, t[0] + 0.3 * per, per, float(rng.uniform(0.01, 0.08)), 15, 89.5,
+                                         0, 90, [0.4, 0.3], "quadratic")
+        flux = flux + rng.normal(0, sigma, len(t))
+        dy = None
+        if case % 2 == 1:
+            dy = rng.uniform(0.5, 2.0, len(t)) * sigma
+        kwargs = dict(period_min=float(rng.uniform(0.7, 2.0)), period_max=float(rng.uniform(span / 4, span / 2)),
+                      oversampling_factor=int(rng.choice([1, 2, 3])),
+                      duration_grid_step=float(rng.choice([1.05, 1.1, 1.3])),
+                      T0_fit_margin=float(rng.choice([0.0, 0.01, 0.05, 0.1])),
+                      transit_depth_min=float(rng.choice([1e-6, 1e-5, 2e-4])))
+        if kwargs["period_min"] >= kwargs["period_max"]:
+            continue
+        try:
+            inp = synthetic.search_inputs(t, flux, dy, **kwargs)
+        except ValueError:
+            continue  # degenerate template table for this size (the reference raises too)
+        sel = inp["periods"][:: max(1, len(inp["periods"]) // 150)]
+        got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+        want = oracle_search(oracle_lib, inp, periods=sel)
+        assert_parity(got, want, len(inp["t"]))
+        assert got[3]["evaluated_cells"] == int(want[3][1]), (case, kwargs)
+        assert got[3]["inner_steps"] == int(want[3][2]), (case, kwargs)
+        n_cases += 1
+    assert n_cases >= 15

@@ -878,8 +878,10 @@ tls_search_kernel(const SearchArgs a) {
             }
         }
         // sentinels behind C: a window that would start past the end of the T0 grid sees an
-        // absurdly deep "mean" and fails the depth predicate without any bounds test
-        if (tid < kRegionPad) regB[M + 1 + tid] = 1.0e300;
+        // absurdly deep "mean" and fails the depth predicate without any bounds test.  The
+        // sentinels RISE (k * 1e300 at index M + k) so that a window whose both ends lie in the
+        // sentinels (possible for widths below kR) still sees a huge positive sum.
+        if (tid < kRegionPad) regB[M + 1 + tid] = (double)(tid + 1) * 1.0e300;
         __syncthreads();
         pc.mark(5);
         // e = 1 - f in place (uniform weights) or e*w (general weights)
@@ -920,7 +922,7 @@ tls_search_kernel(const SearchArgs a) {
                 const bool in = src < M + 1 + kRegionPad;
                 tile_e[k] = in ? regA[src] : 0.0;
                 if constexpr (!UNIFORM_W) tile_w[k] = in ? regW[src] : 0.0;
-                if constexpr (STAGE_C) tile_c[k] = in ? regB[src] : 1.0e300;
+                if constexpr (STAGE_C) tile_c[k] = in ? regB[src] : (double)(src - M) * 1.0e300;
             }
             for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;
             e_base = tile_e - p_lo;
@@ -941,7 +943,7 @@ tls_search_kernel(const SearchArgs a) {
             for (int tile = wave; unit_lo + tile * kWave < unit_hi; tile += nw) {
                 const int unit = unit_lo + tile * kWave + lane;
                 const int u0 = unit * kR;
-                const int u0c = u0 < M - kR ? u0 : M - kR;
+                const int u0c = u0 < M + 1 ? u0 : M + 1;  // lanes past the row read sentinels and are masked
                 double c_lo[kR];
 #pragma unroll
                 for (int r = 0; r < kR; ++r) c_lo[r] = c_base[u0c + r];
