@@ -349,11 +349,12 @@ def test_survey_batch_equals_individual_searches(gpu):
     assert int(numpy.argmin(chi2[0])) == 7738
 
 
-def test_randomised_configurations_vs_oracle(gpu, oracle_lib):
+@pytest.mark.parametrize("seed", [2024, 7, 99])
+def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
     """Seeded sweep over sizes, cadences, noise levels, weights, T0 strides, depth thresholds and
     duration-grid steps: resident and tiled kernel variants, dense and strided T0 grids, uniform
     and per-point weights, all against the oracle."""
-    rng = numpy.random.RandomState(2024)
+    rng = numpy.random.RandomState(seed)
     n_cases = 0
     for case in range(24):
         span = float(rng.choice([8.0, 20.0, 45.0, 120.0]))
@@ -393,4 +394,4 @@ def test_randomised_configurations_vs_oracle(gpu, oracle_lib):
         assert got[3]["evaluated_cells"] == int(want[3][1]), (case, kwargs)
         assert got[3]["inner_steps"] == int(want[3][2]), (case, kwargs)
         n_cases += 1
-    assert n_cases >= 15
+    assert n_cases >= 12

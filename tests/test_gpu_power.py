@@ -61,3 +61,43 @@ def test_k2_90d_anchor_values():
     numpy.testing.assert_allclose(r.rp_rs, 0.00908039, rtol=1e-6)
     numpy.testing.assert_allclose(r.snr, 14.324393, rtol=1e-6)
     assert len(r.transit_times) == 8
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_power_gpu_equals_power_with_oracle_search(monkeypatch, oracle_lib, seed):
+    """End to end on random small light curves: the drop-in with the HIP search and the device T0
+    fit must return the same results object as the same host code fed by the CPU oracle and the
+    numpy T0 fit (the combination that the reference's own known answers pin)."""
+    from tls_amd import transit_model
+    from tls_amd.stats import t0_fit_residuals_host
+    import warnings
+    rng = numpy.random.RandomState(seed)
+    span = float(rng.choice([15.0, 30.0, 60.0]))
+    n = int(span * rng.choice([24, 48]))
+    t = numpy.linspace(2.0, 2.0 + span, n)
+    per = float(rng.uniform(2.0, span / 4))
+    y = transit_model.light_curve(t, 2.5, per, float(rng.uniform(0.02, 0.07)), 12, 89.8, 0, 90,
+                                  [0.4, 0.3], "quadratic") + rng.normal(0, 3e-4, n)
+    dy = rng.uniform(0.8, 1.3, n) * 3e-4 if seed % 2 else None
+    kwargs = dict(period_min=1.0, period_max=span / 3, oversampling_factor=2,
+                  T0_fit_margin=float(rng.choice([0.01, 0.05])), verbose=False, show_progress_bar=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = make_model(t, y, dy).power(**kwargs)
+
+        def oracle_search_periods(t_, y_, dy_, periods, table, transit_depth_min, R_star_min, R_star_max,
+                                  M_star_min, M_star_max, T0_fit_margin, **_unused):
+            return oracle_lib.search(t_, y_, dy_, periods, table, transit_depth_min, R_star_min, R_star_max,
+                                     M_star_min, M_star_max, T0_fit_margin)[:3]
+
+        monkeypatch.setattr(tls_amd.search, "search_periods", oracle_search_periods)
+        monkeypatch.setattr(tls_amd.search, "t0_fit_residuals",
+                            lambda t_, y_, p_, s_, e_, r_, **kw: t0_fit_residuals_host(t_, y_, p_, s_, e_, r_))
+        want = make_model(t, y, dy).power(**kwargs)
+    assert list(got.keys()) == list(want.keys())
+    for key in pins.SCALARS:
+        numpy.testing.assert_allclose(float(got[key]), float(want[key]), rtol=1e-9, atol=1e-12, err_msg=key)
+    for key in pins.ARRAYS:
+        numpy.testing.assert_allclose(numpy.asarray(got[key], dtype=float), numpy.asarray(want[key], dtype=float),
+                                      rtol=1e-9, atol=1e-11, err_msg=key)
+    assert int(numpy.argmin(got.chi2)) == int(numpy.argmin(want.chi2))
