@@ -395,3 +395,19 @@ def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
         assert got[3]["inner_steps"] == int(want[3][2]), (case, kwargs)
         n_cases += 1
     assert n_cases >= 12
+
+
+@pytest.mark.parametrize("name,stride", [("tess_27d", 60), ("kepler_4yr", 9000)])
+def test_large_series_with_per_point_weights(gpu, oracle_lib, name, stride):
+    """Tiled (non-resident) variant with per-point dy: e*w and w staged per tile; for the
+    Kepler-size window the prefix sum no longer fits next to them and is read from the slab."""
+    t, f, kw = synthetic.config(name)
+    rng = numpy.random.RandomState(17)
+    dy = rng.uniform(0.7, 1.6, len(f)) * synthetic.CONFIGS[name][2]
+    inp = synthetic.search_inputs(t, f, dy, **kw)
+    sel = inp["periods"][::stride]
+    got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+    assert not gpu.plan_info()["resident"]
+    want = oracle_search(oracle_lib, inp, periods=sel)
+    assert_parity(got, want, len(inp["t"]))
+    assert got[3]["evaluated_cells"] == int(want[3][1])
