@@ -94,7 +94,6 @@ struct tls_ctx {
     double S0 = 0, w0 = 1, depth_min = 0;
     tls_counters plan_counters = {0, 0, 0, 0};
     bool counted = false;
-    std::vector<double> h_t;  // kept for tls_update_flux validation (size only)
 
     // per-launch kernel timing (HIP events on the context's stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;

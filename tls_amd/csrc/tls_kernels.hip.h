@@ -10,13 +10,15 @@
 //   phase 4  argmin reduction          core.py:70-74, 183-188
 //
 // Data layout.  The phase-folded series lives in LDS for the whole period ("resident"
-// variant: 16*(N+W+17) bytes, N = points, W = widest trial transit) or, when it does not fit
-// (TESS/Kepler-size N), in a per-workgroup slab of HBM scratch that stays L2/MALL-warm.
+// variant: 16*(N+W+1+kRegionPad) bytes, N = points, W = widest trial transit) or, when it does
+// not fit (TESS/Kepler-size N), in a per-workgroup slab of HBM scratch that stays L2/MALL-warm
+// and is staged through LDS in tiles of window-start positions plus a halo of one window.
 //   regA: f[0..M)  folded flux, patched with its first W samples (M = N+W), later e = 1-f
 //   regB: C[0..M]  sequential prefix sum of f  (during the sort: bucket counters + indices)
 //   regW: w[0..M)  1/dy^2 in folded order (only when the weights are not uniform)
-// Each region has 16 spare entries so that the unrolled dot product may read a few samples
-// past a window; those samples are multiplied by the zero padding of the template rows.
+// Each region has kRegionPad spare entries so that the unrolled dot product may read a few
+// samples past a window (they meet the zero padding of the template rows); behind C the spare
+// entries are rising sentinels that make every window past the T0 grid fail the predicate.
 //
 // Arithmetic.  Everything is fp64 (chi^2 ~ N with the signal in the 6th digit).  For a trial
 // window starting at i with template depth profile q_j = 1 - signal_j and depth scale rs,
@@ -39,7 +41,9 @@
 // reads from LDS feeds 5 FMAs (ds_read_b64 at a lane stride of 40 B is bank-conflict free for
 // consecutive chunks), and the template value is wave-uniform, fetched with scalar loads into
 // SGPRs (the template table is read through the constant address space).  That puts the loop
-// on the fp64 FMA pipe instead of the LDS pipe.
+// on the fp64 FMA pipe instead of the LDS pipe.  Long durations search a strided T0 grid
+// (core.py:50-58): strides 2..5 use the same 5-window form with the windows that far apart;
+// rows left with a handful of live chunks are re-listed and evaluated one window per lane.
 //
 // No MFMA: the contraction is a sliding window with a per-cell scalar, not a GEMM.
 #pragma once
@@ -54,7 +58,7 @@ namespace tlsdev {
 
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
-constexpr int kPhases = 22;    // fold+count, scan, scatter, rank, gather+patch, cumsum, predicate, chi2
+constexpr int kPhases = 22;    // phase-clock slots (tls_amd/_lib.py names them)
 #ifndef TLS_KR
 #define TLS_KR 5
 #endif
