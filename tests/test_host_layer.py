@@ -215,3 +215,16 @@ def test_pink_noise_equals_reference_loop():
         for i in range(n - w + 1):
             total += numpy.std(d[i: i + w]) / w ** 0.5
         assert pink_noise(d, w) == total / (n - w + 1)
+
+
+def test_running_median_fast_path_is_identical():
+    from tls_amd.helpers import running_median
+    rng = numpy.random.RandomState(1)
+    for n, k in ((500, 91), (9679, 91), (200, 31), (120, 30), (64, 7)):
+        data = rng.normal(0, 1, n)
+        idx = numpy.arange(k) + numpy.arange(n - k + 1)[:, None]        # reference helpers.py:95
+        med = numpy.median(data[idx], axis=1)
+        missing = n - len(med)
+        front = int(missing * 0.5)
+        want = numpy.concatenate([numpy.full(front, med[0]), med, numpy.full(missing - front, med[-1])])
+        numpy.testing.assert_array_equal(running_median(data, k), want)

@@ -26,6 +26,7 @@ from .template import TemplateTable, fractional_transit, get_cache
 from .validate import validate_args, validate_inputs
 
 _NAN = numpy.nan
+_GRID_CACHE = {}  # (time span, n, kwargs) -> (periods, durations, lc_cache_overview, lc_arr)
 
 
 class transitleastsquares(object):
@@ -37,6 +38,24 @@ class transitleastsquares(object):
 
     # ------------------------------------------------------------------ search
     def _build_grids(self):
+        """Period grid, duration grid and template table of this search.  They depend only on
+        the time span, the number of points and the keyword arguments, so surveys that call
+        power() on many light curves with shared time stamps get them from a small cache."""
+        key = (len(self.t), float(numpy.min(self.t)), float(numpy.max(self.t)), self.R_star, self.M_star,
+               self.period_min, self.period_max, self.oversampling_factor, self.n_transits_min,
+               self.duration_grid_step, self.per, self.rp, self.a, self.inc, self.ecc, self.w,
+               tuple(self.u), self.limb_dark)
+        hit = _GRID_CACHE.get(key)
+        if hit is None:
+            hit = self._build_grids_uncached()
+            if len(_GRID_CACHE) >= 8:
+                _GRID_CACHE.pop(next(iter(_GRID_CACHE)))
+            _GRID_CACHE[key] = hit
+        elif self.verbose:
+            print("Creating model cache for", str(len(hit[1])), "durations")
+        return hit
+
+    def _build_grids_uncached(self):
         periods = period_grid(
             R_star=self.R_star, M_star=self.M_star,
             time_span=numpy.max(self.t) - numpy.min(self.t),
