@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--sigma", type=float, default=None, help="noise override (e.g. 500e-6)")
     ap.add_argument("--mode", default="survey", choices=["survey", "shard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="1-GPU runs: go through the RCCL code path with a one-rank communicator")
     args = ap.parse_args()
 
     rank, world, local_rank, addr, port = rendezvous.env_layout()
@@ -127,6 +129,10 @@ def main():
     if job_cells is None:
         job_cells = info["grid_cells"] * world  # survey: one full grid per GPU per step
 
+    if world == 1 and args.force_collective:
+        ctx.comm_init(1, 0, ctx.comm_unique_id())
+        collective = "rccl"
+
     def barrier():
         if collective == "rccl":
             ctx.comm_barrier()
@@ -141,7 +147,9 @@ def main():
     def step():
         ctx.execute()
         if collective == "rccl":
-            ctx.comm_allgather_results(count_per_rank, world)  # results on every rank
+            # pack + ncclAllGather are enqueued behind the kernel: every rank holds the whole batch
+            # in HBM, and the next search starts without a host round trip
+            ctx.comm_allgather_device(count_per_rank)
         elif channel is not None:
             c, r, d = ctx.fetch()
             channel.allgather_bytes(c.tobytes() + r.tobytes() + d.tobytes())
@@ -160,6 +168,9 @@ def main():
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.kernel_timing(reset=True)
+    if collective == "rccl":  # outside the timed region: the last gathered batch, on the host
+        g_chi2, g_row, g_depth = ctx.comm_fetch_gathered(count_per_rank, world)
+        assert len(g_chi2) == count_per_rank * world
     if world > 1:
         elapsed = reduce_max(elapsed)
         kernel_ms = reduce_max(kernel_ms)
@@ -195,6 +206,7 @@ def main():
             best = min(best, time.perf_counter() - t1)
         power_wall_ms = 1e3 * best
 
+    out = None
     if rank == 0:
         n = len(inp["t"])
         ms_per_step = 1e3 * elapsed / args.steps
@@ -242,13 +254,26 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(inp, info["grid_cells"])
-        print(json.dumps(out), flush=True)
     barrier()
     if collective == "rccl":
         ctx.comm_destroy()
-    if channel is not None:
-        channel.close()
     ctx.close()
+    # RCCL writes a version banner through C stdio, which is flushed at exit when stdout is a
+    # pipe.  Every rank flushes it now, then all ranks meet on the host channel, and only then
+    # does rank 0 print: the JSON line is the LAST line of the job's combined output.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if channel is not None:
+        channel.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if channel is not None:
+        channel.barrier()
+        channel.close()
 
 
 if __name__ == "__main__":

@@ -146,6 +146,12 @@ int tls_comm_destroy(tls_ctx *ctx);
  * chi2/row/depth in rank order.  One ncclAllGather over a packed 24 B/period buffer. */
 int tls_comm_allgather_results(tls_ctx *ctx, int64_t count_per_rank, double *all_chi2,
                                int64_t *all_row, double *all_depth);
+/* The same in two halves: _device enqueues pack + ncclAllGather on the context's stream and
+ * returns (the gathered batch stays in HBM on every rank, the next search may be enqueued
+ * right behind it); _fetch_gathered copies the most recent gather to the host and unpacks it. */
+int tls_comm_allgather_device(tls_ctx *ctx, int64_t count_per_rank);
+int tls_comm_fetch_gathered(tls_ctx *ctx, int64_t count_per_rank, double *all_chi2,
+                            int64_t *all_row, double *all_depth);
 /* small host-value collectives used by the bench harness (barrier, max over ranks) */
 int tls_comm_barrier(tls_ctx *ctx);
 int tls_comm_max(tls_ctx *ctx, double *value_inout);

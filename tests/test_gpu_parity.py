@@ -260,6 +260,13 @@ def test_single_rank_rccl_allgather(gpu):
         numpy.testing.assert_array_equal(row[:1000], ref[1])
         numpy.testing.assert_array_equal(depth[:1000], ref[2])
         assert numpy.all(chi2[1000:] == 0)
+        # two-step form: gather stays on the device, fetched later
+        gpu.execute()
+        gpu.comm_allgather_device(1024)
+        gpu.execute()                      # the next search may be enqueued right behind it
+        chi2b, rowb, depthb = gpu.comm_fetch_gathered(1024, 1)
+        numpy.testing.assert_array_equal(chi2b, chi2)
+        numpy.testing.assert_array_equal(rowb, row)
         assert gpu.comm_max(3.5) == 3.5
         gpu.comm_barrier()
     finally:

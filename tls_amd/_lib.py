@@ -17,7 +17,7 @@ SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
     "tls_device_name", "tls_search", "tls_prepare", "tls_update_flux", "tls_execute",
     "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_t0_fit", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum",
-    "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results",
+    "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_barrier", "tls_comm_max",
 )
 
@@ -107,6 +107,10 @@ def load():
     lib.tls_comm_destroy.argtypes = [vp]
     lib.tls_comm_allgather_results.restype = ci
     lib.tls_comm_allgather_results.argtypes = [vp, i64, _c_double_p, _c_int64_p, _c_double_p]
+    lib.tls_comm_allgather_device.restype = ci
+    lib.tls_comm_allgather_device.argtypes = [vp, i64]
+    lib.tls_comm_fetch_gathered.restype = ci
+    lib.tls_comm_fetch_gathered.argtypes = [vp, i64, _c_double_p, _c_int64_p, _c_double_p]
     lib.tls_comm_barrier.restype = ci
     lib.tls_comm_barrier.argtypes = [vp]
     lib.tls_comm_max.restype = ci
@@ -284,6 +288,19 @@ class Context(object):
         depth = numpy.empty(total, dtype=numpy.float64)
         self._check(self._lib.tls_comm_allgather_results(self._h, int(count_per_rank), _dp(chi2),
                                                          _ip(row), _dp(depth)))
+        return chi2, row, depth
+
+    def comm_allgather_device(self, count_per_rank):
+        """Enqueue pack + ncclAllGather behind the search; the batch stays device resident."""
+        self._check(self._lib.tls_comm_allgather_device(self._h, int(count_per_rank)))
+
+    def comm_fetch_gathered(self, count_per_rank, n_ranks):
+        total = int(count_per_rank) * int(n_ranks)
+        chi2 = numpy.empty(total, dtype=numpy.float64)
+        row = numpy.empty(total, dtype=numpy.int64)
+        depth = numpy.empty(total, dtype=numpy.float64)
+        self._check(self._lib.tls_comm_fetch_gathered(self._h, int(count_per_rank), _dp(chi2), _ip(row),
+                                                      _dp(depth)))
         return chi2, row, depth
 
     def comm_barrier(self):

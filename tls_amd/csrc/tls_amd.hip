@@ -102,6 +102,7 @@ struct tls_ctx {
     // RCCL
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
+    int64_t gathered_count = 0;
 };
 
 namespace {
@@ -728,7 +729,7 @@ int tls_comm_destroy(tls_ctx* ctx) {
     return TLS_OK;
 }
 
-int tls_comm_allgather_results(tls_ctx* ctx, int64_t count_per_rank, double* all_chi2, int64_t* all_row, double* all_depth) {
+int tls_comm_allgather_device(tls_ctx* ctx, int64_t count_per_rank) {
     if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
     if (!ctx->comm) return fail(ctx, TLS_E_STATE, "tls_comm_init first");
     if (!ctx->executed) return fail(ctx, TLS_E_STATE, "all-gather before tls_execute");
@@ -745,6 +746,18 @@ int tls_comm_allgather_results(tls_ctx* ctx, int64_t count_per_rank, double* all
         TLS_HIP(ctx, hipMemcpyAsync(ctx->d_pack.ptr + 2 * c, ctx->d_depth.ptr, np * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
     TLS_NCCL(ctx, ncclAllGather(ctx->d_pack.ptr, ctx->d_gather.ptr, 3 * c, ncclDouble, ctx->comm, ctx->stream));
+    ctx->gathered_count = (int64_t)c;
+    return TLS_OK;
+}
+
+int tls_comm_fetch_gathered(tls_ctx* ctx, int64_t count_per_rank, double* all_chi2, int64_t* all_row, double* all_depth) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->comm) return fail(ctx, TLS_E_STATE, "tls_comm_init first");
+    if (!all_chi2 || !all_row || !all_depth) return fail(ctx, TLS_E_ARG, "null output");
+    if (ctx->gathered_count != count_per_rank || count_per_rank < 1)
+        return fail(ctx, TLS_E_STATE, "no device-side all-gather of that size to fetch");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t c = (size_t)count_per_rank, R = (size_t)ctx->n_ranks;
     std::vector<double> host(3 * c * R);
     TLS_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_gather.ptr, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -755,6 +768,12 @@ int tls_comm_allgather_results(tls_ctx* ctx, int64_t count_per_rank, double* all
         std::memcpy(all_depth + r * c, blk + 2 * c, c * 8);
     }
     return TLS_OK;
+}
+
+int tls_comm_allgather_results(tls_ctx* ctx, int64_t count_per_rank, double* all_chi2, int64_t* all_row, double* all_depth) {
+    int rc = tls_comm_allgather_device(ctx, count_per_rank);
+    if (rc) return rc;
+    return tls_comm_fetch_gathered(ctx, count_per_rank, all_chi2, all_row, all_depth);
 }
 
 int tls_comm_max(tls_ctx* ctx, double* value_inout) {
