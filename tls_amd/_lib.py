@@ -145,7 +145,6 @@ class Context(object):
             raise RuntimeError("tls_amd: cannot create a GPU context: "
                                + self._lib.tls_last_error(None).decode())
         self.device = int(device)
-        self._keep = None
         self._n_periods = 0
 
     # -- plumbing

@@ -8,7 +8,6 @@ to the MI355X in one batched call through the C ABI (tls_amd.search ->
 libtls_amd.so, include/tls_amd.h).  There is no CPU fallback: without the HIP
 library or a GPU, power() raises.
 """
-import multiprocessing
 import warnings
 
 import numpy
@@ -217,6 +216,3 @@ class transitleastsquares(object):
             _NAN, _NAN, _NAN, _NAN, _NAN, FAP(SDE), _NAN, _NAN, _NAN, periods, zeros,
             numpy.zeros(len(chi2)), 0, chi2, chi2red, _NAN, _NAN, _NAN, _NAN, _NAN, _NAN, _NAN)
 
-
-def cpu_count():
-    return multiprocessing.cpu_count()
