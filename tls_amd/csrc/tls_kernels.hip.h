@@ -989,7 +989,9 @@ tls_search_kernel(const SearchArgs a) {
         pc.mark(13);
         // strided rows (long durations, core.py:50-58): kR strided positions per lane while the
         // stride allows the tiled dot product, else one position per lane
-        for (int k = k_x > k_lo ? k_x : k_lo; k < k_hi; ++k) {
+        // (one row per wave: rows are independent, and a row of a few hundred units would leave
+        // most waves idle if all of them walked it together)
+        for (int k = (k_x > k_lo ? k_x : k_lo) + wave; k < k_hi; k += nw) {
             const int d = widths_c[k].width, xth = widths_c[k].xth, n_pos = widths_c[k].n_pos;
             const int n_units = widths_c[k].n_chunks;
             const double inv_d = widths_c[k].inv_d;
@@ -998,7 +1000,7 @@ tls_search_kernel(const SearchArgs a) {
                 const int span = kR * xth;  // samples between the first windows of two units
                 const int unit_lo = (p_lo + span - 1) / span;
                 const int unit_hi = (p_hi + span - 1) / span < n_units ? (p_hi + span - 1) / span : n_units;
-                for (int tile = wave; unit_lo + tile * kWave < unit_hi; tile += nw) {
+                for (int tile = 0; unit_lo + tile * kWave < unit_hi; ++tile) {
                     const int unit = unit_lo + tile * kWave + lane;
                     const int uc = unit < n_units ? unit : n_units - 1;
                     const double* c0 = c_base + uc * kR * xth;
@@ -1016,7 +1018,7 @@ tls_search_kernel(const SearchArgs a) {
             } else {
                 const int unit_lo = (p_lo + xth - 1) / xth;
                 const int unit_hi = (p_hi + xth - 1) / xth < n_pos ? (p_hi + xth - 1) / xth : n_pos;
-                for (int tile = wave; unit_lo + tile * kWave < unit_hi; tile += nw) {
+                for (int tile = 0; unit_lo + tile * kWave < unit_hi; ++tile) {
                     const int unit = unit_lo + tile * kWave + lane;
                     bool live = false;
                     if (unit < unit_hi) {
