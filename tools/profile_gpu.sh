@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k2 -- $BENCH > "$OUT/trace.log" 2>&1
 # counters in their own passes (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), no trace domains besides kernels
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o k2 -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
