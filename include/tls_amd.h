@@ -95,9 +95,10 @@ int tls_update_flux(tls_ctx *ctx, const double *y, const double *dy);
  * count_work & 1 also accumulates evaluated_cells/inner_steps (slower). */
 int tls_execute(tls_ctx *ctx, int count_work);
 /* developer instrumentation: tls_execute(ctx, 2) makes thread 0 of every workgroup stamp
- * the shader clock at phase boundaries; this returns the per-phase cycle sums (12 slots:
+ * the shader clock at phase boundaries; this returns the per-phase cycle sums (up to 22 slots:
  * fold+count, scan, scatter, rank, gather+patch, cumsum, batch prefix, chi2, e-convert,
- * predicate, then two event counters: cumsum blocks, cumsum fallbacks). */
+ * strided predicate, two event counters (cumsum blocks, cumsum fallbacks), tile staging,
+ * dense predicate, six cumsum sub-phases, two spare; names in tls_amd/_lib.py::phase_cycles). */
 int tls_debug_phase_cycles(tls_ctx *ctx, uint64_t *cycles, int n);
 /* developer/test entry: the kernel's exact parallel evaluation of the sequential fp64 prefix
  * sum (numpy.cumsum order, helpers.py:72) on an arbitrary series of non-negative values;

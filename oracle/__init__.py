@@ -4,4 +4,4 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package (as the checker / the timed CPU baseline).  tls_amd never does.
 See oracle/tls_oracle.c for the reference file:line map and the parity pins.
 """
-from .oracle import OracleLibrary, search, build  # noqa: F401
+from .oracle import OracleLibrary, search, build, usable_cores  # noqa: F401

@@ -21,6 +21,34 @@ def build(fast=False, force=False):
     return path
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU
+    quota (a container that sees 256 CPUs may be throttled to 16 CPUs' worth of time, and 256
+    OpenMP threads under such a quota run slower than 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:            # cgroup v2: "<quota|max> <period>"
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:                                                  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, \
+                    open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+                if q > 0 and per > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.999)))
+    return max(1, n)
+
+
 class OracleLibrary(object):
     def __init__(self, fast=False):
         self.lib = ctypes.CDLL(build(fast=fast))
@@ -55,7 +83,7 @@ class OracleLibrary(object):
             c(table.length, numpy.int64), c(table.width, numpy.int64),
             c(table.overshoot, numpy.float64), len(table.width),
             transit_depth_min, R_star_min, R_star_max, M_star_min, M_star_max, T0_fit_margin,
-            chi2, row, depth, counters, int(n_threads))
+            chi2, row, depth, counters, int(n_threads) if int(n_threads) > 0 else usable_cores())
         if rc != 0:
             raise RuntimeError("tls_oracle_search failed with code %d" % rc)
         return chi2, row, depth, counters

@@ -336,8 +336,9 @@ int tls_oracle_search(const double *t, const double *y, const double *dy, int64_
     }
 
 #ifdef _OPENMP
-    if (n_threads > 0)
-        omp_set_num_threads(n_threads);
+    /* the thread count is a process-wide OpenMP setting: always set it, so that a 1-thread
+     * call does not leak into the next "all threads" call */
+    omp_set_num_threads(n_threads > 0 ? n_threads : omp_get_num_procs());
 #else
     (void)n_threads;
 #endif
