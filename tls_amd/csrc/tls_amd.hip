@@ -76,7 +76,8 @@ struct tls_ctx {
     // device-resident plan
     DevBuf<double> d_t, d_y, d_w, d_periods, d_q, d_q2, d_chi2, d_depth, d_scratch, d_pack, d_gather, d_scalar;
     DevBuf<long long> d_row;
-    DevBuf<int> d_order, d_dlo, d_dhi;
+    DevBuf<int> d_order;
+    DevBuf<tlsdev::PeriodRows> d_rows;
     DevBuf<tlsdev::WidthEntry> d_widths;
     DevBuf<unsigned long long> d_counters, d_phase;
     DevBuf<unsigned int> d_queue, d_lists;
@@ -248,7 +249,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
     tlsdev::SearchArgs a;
     a.t = ctx->d_t.ptr; a.y = ctx->d_y.ptr; a.w = ctx->uniform_w ? nullptr : ctx->d_w.ptr;
-    a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.dlo = ctx->d_dlo.ptr; a.dhi = ctx->d_dhi.ptr;
+    a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.rows = ctx->d_rows.ptr;
     a.widths = ctx->d_widths.ptr; a.q = ctx->d_q.ptr; a.q2 = ctx->uniform_w ? nullptr : ctx->d_q2.ptr;
     a.out_chi2 = ctx->d_chi2.ptr; a.out_row = ctx->d_row.ptr; a.out_depth = ctx->d_depth.ptr;
     a.counters = count_work ? ctx->d_counters.ptr : nullptr;
@@ -337,7 +338,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_t.release(); ctx->d_y.release(); ctx->d_w.release(); ctx->d_periods.release(); ctx->d_q.release();
     ctx->d_chi2.release(); ctx->d_depth.release(); ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_row.release(); ctx->d_order.release();
-    ctx->d_dlo.release(); ctx->d_dhi.release(); ctx->d_widths.release(); ctx->d_counters.release();
+    ctx->d_rows.release(); ctx->d_widths.release(); ctx->d_counters.release();
     ctx->d_queue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     for (auto& evp : ctx->ev_pool) { (void)hipEventDestroy(evp.first); (void)hipEventDestroy(evp.second); }
@@ -370,14 +371,27 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     // per-period duration window (core.py:143-156) and cost
     double t_min = t[0], t_max = t[0];
     for (int64_t i = 1; i < n; ++i) { t_min = std::min(t_min, t[i]); t_max = std::max(t_max, t[i]); }
-    std::vector<int> dlo((size_t)n_periods), dhi((size_t)n_periods), order((size_t)n_periods);
+    std::vector<int> order((size_t)n_periods);
+    std::vector<tlsdev::PeriodRows> prow((size_t)n_periods);
     std::vector<int64_t> cost((size_t)n_periods);
     tls_counters pc = {0, 0, 0, 0};
     const double length = t_max - t_min;
     for (int64_t p = 0; p < n_periods; ++p) {
         const double P = periods[p];
         if (!(P > 0) || !std::isfinite(P)) return fail(ctx, TLS_E_ARG, "periods must be positive and finite");
-        const int64_t c = period_window(widths, params, P, length, n, M, dlo[(size_t)p], dhi[(size_t)p], &pc.pd_pairs);
+        int dlo, dhi;
+        const int64_t c = period_window(widths, params, P, length, n, M, dlo, dhi, &pc.pd_pairs);
+        // the in-range rows of the ascending width table; rows below k_x have T0 stride 1
+        tlsdev::PeriodRows& pr = prow[(size_t)p];
+        const int nw = (int)widths.size();
+        pr.k_lo = 0;
+        while (pr.k_lo < nw && widths[(size_t)pr.k_lo].width < dlo) ++pr.k_lo;
+        pr.k_hi = pr.k_x = pr.k_lo;
+        while (pr.k_hi < nw && widths[(size_t)pr.k_hi].width <= dhi) {
+            if (widths[(size_t)pr.k_hi].xth == 1) pr.k_x = pr.k_hi + 1;
+            ++pr.k_hi;
+        }
+        pr.pad = 0;
         cost[(size_t)p] = c;
         pc.grid_cells += c;
     }
@@ -456,8 +470,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     if (!uniform && (rc = upload(ctx, ctx->d_w, w.data(), (size_t)n))) return rc;
     if ((rc = upload(ctx, ctx->d_periods, periods, (size_t)n_periods))) return rc;
     if ((rc = upload(ctx, ctx->d_order, order.data(), (size_t)n_periods))) return rc;
-    if ((rc = upload(ctx, ctx->d_dlo, dlo.data(), (size_t)n_periods))) return rc;
-    if ((rc = upload(ctx, ctx->d_dhi, dhi.data(), (size_t)n_periods))) return rc;
+    if ((rc = upload(ctx, ctx->d_rows, prow.data(), (size_t)n_periods))) return rc;
     if ((rc = upload(ctx, ctx->d_widths, widths.data(), widths.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_q, q.data(), q.size()))) return rc;
     std::vector<double> q2;

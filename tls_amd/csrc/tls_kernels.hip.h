@@ -75,6 +75,8 @@ constexpr int kFixedHeader = 560 + kCumsumScratchBytes;  // wsum[32] | wbest[16]
 typedef const __attribute__((address_space(4))) double* const_f64_ptr;  // -> s_load, SGPR operands
 struct WidthEntry;
 typedef const __attribute__((address_space(4))) WidthEntry* const_width_ptr;
+struct PeriodRows;
+typedef const __attribute__((address_space(4))) PeriodRows* const_rows_ptr;
 
 // kU consecutive doubles from the folded series.  In LDS the reads are issued as eight
 // ds_read_b64: hipcc would pair them into ds_read2_b64, which moves half the bytes per LDS
@@ -134,14 +136,19 @@ struct WidthEntry {
     double pad;
 };
 
+// In-range widths of one period (core.py:143-156): the contiguous range [k_lo, k_hi) of the
+// ascending width table; rows below k_x have the dense T0 grid (stride 1).  Host-computed.
+struct PeriodRows {
+    int k_lo, k_hi, k_x, pad;
+};
+
 struct SearchArgs {
     const double* t;        // [n]
     const double* y;        // [n]
     const double* w;        // [n] 1/dy^2, or nullptr when all weights equal w0
     const double* periods;  // [n_periods]
     const int* order;       // [n_periods] work order (most expensive first)
-    const int* dlo;         // [n_periods] smallest in-range width (samples), core.py:148
-    const int* dhi;         // [n_periods] largest in-range width, core.py:149
+    const PeriodRows* rows; // [n_periods] in-range rows of the width table (core.py:148-156)
     const WidthEntry* widths;
     const double* q;        // template rows q_j = 1 - signal_j, zero padded front and back
     const double* q2;       // q_j^2, same layout (general weights only)
@@ -813,6 +820,7 @@ tls_search_kernel(const SearchArgs a) {
     }
 
     const const_width_ptr widths_c = (const_width_ptr)a.widths;  // read-only for the whole launch
+    const const_rows_ptr rows_c = (const_rows_ptr)a.rows;
     const const_f64_ptr q_all = (const_f64_ptr)a.q;
     const const_f64_ptr q2_all = (const_f64_ptr)a.q2;
     const double dmin = a.depth_min;
@@ -848,20 +856,13 @@ tls_search_kernel(const SearchArgs a) {
         pc.mark(4);
 
         // in-range widths of this period: a contiguous range [k_lo, k_hi) of the ascending
-        // width table (core.py:148-156); widths below k_x have the dense T0 grid (stride 1)
-        const int dlo = a.dlo[p], dhi = a.dhi[p];
-        if (tid == nt - 1) {
-            int k_lo = 0;
-            while (k_lo < a.n_widths && widths_c[k_lo].width < dlo) ++k_lo;
-            int k_hi = k_lo, k_x = k_lo;
-            while (k_hi < a.n_widths && widths_c[k_hi].width <= dhi) {
-                if (widths_c[k_hi].xth == 1) k_x = k_hi + 1;
-                rt.live[k_hi - k_lo] = 0;
-                ++k_hi;
-            }
-            s_work[1] = k_lo; s_work[2] = k_hi; s_work[3] = k_x;
-        }
-        __syncthreads();
+        // width table (core.py:148-156); widths below k_x have the dense T0 grid (stride 1).
+        // Wave-uniform by construction; say so, or the template taps stop being scalar loads.
+        const int k_lo = __builtin_amdgcn_readfirstlane(rows_c[p].k_lo);
+        const int k_hi = __builtin_amdgcn_readfirstlane(rows_c[p].k_hi);
+        const int k_x = __builtin_amdgcn_readfirstlane(rows_c[p].k_x);
+        const int n_rows = k_hi - k_lo;
+        for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup
         if constexpr (RESIDENT) {
             exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
@@ -894,11 +895,6 @@ tls_search_kernel(const SearchArgs a) {
             if constexpr (!UNIFORM_W) e *= regW[k];
             regA[k] = e;
         }
-        // wave-uniform by construction; say so, or the template taps stop being scalar loads
-        const int k_lo = __builtin_amdgcn_readfirstlane(s_work[1]);
-        const int k_hi = __builtin_amdgcn_readfirstlane(s_work[2]);
-        const int k_x = __builtin_amdgcn_readfirstlane(s_work[3]);
-        const int n_rows = k_hi - k_lo;
         __syncthreads();
         pc.mark(8);
 
@@ -921,6 +917,7 @@ tls_search_kernel(const SearchArgs a) {
             double* tile_w = tile_e + staged;
             double* tile_c = UNIFORM_W ? tile_w : tile_w + staged;
             __syncthreads();  // the previous tile (or the sort histogram) is no longer read
+            pc.mark(20);
             for (int k = tid; k < staged; k += nt) {
                 const int src = p_lo + k;
                 const bool in = src < M + 1 + kRegionPad;
