@@ -226,7 +226,7 @@ class Context(object):
         names = ("fold_count", "scan", "scatter", "rank", "gather_patch", "cumsum", "batch_prefix",
                  "chi2", "e_convert", "predicate_strided", "cumsum_blocks", "cumsum_fallbacks",
                  "tile_staging", "predicate_dense", "cs_A", "cs_B1", "cs_B2", "cs_scan", "cs_D", "cs_E",
-                 "tile_wait", "x21")
+                 "tile_wait", "chi2_wait")
         return dict(zip(names, [int(v) for v in arr]))
 
     def synchronize(self):

@@ -83,7 +83,7 @@ struct tls_ctx {
     DevBuf<unsigned int> d_queue, d_lists;
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
     size_t list_stride = 0;
-    int hdr_bytes = 0, tile_len = 0, tile_halo = 0;
+    int hdr_bytes = 0, tile_len = 0, tile_halo = 0, region_pad = 0;
     bool stage_c = false;
 
     // host-side plan
@@ -176,9 +176,7 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
         const int64_t len = tmpl->length[r];
         if (len < 1 || len > wd) return fail(ctx, TLS_E_ARG, "template row longer than its width");
         tlsdev::WidthEntry we;
-        // rows are stored zero padded (kPadFront before, kPadBack after, then up to a
-        // multiple of 8 doubles) so that the unrolled dot product needs no edge handling
-        we.width = (int)wd; we.row = (int)r; we.q_offset = (int)(q_count + tlsdev::kPadFront); we.q_len = (int)len; we.pad = 0.0;
+        we.width = (int)wd; we.row = (int)r; we.q_len = (int)len; we.reserved = 0;
         we.n_pos = 0; we.n_chunks = 0; we.list_base = 0; we.inv_d = 1.0 / (double)wd;
         we.xth = 1;
         if (margin > 0 && (double)wd > margin) {  // core.py:50-55
@@ -186,15 +184,22 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
             int xth = (int)((double)wd / inv);
             we.xth = xth < 1 ? 1 : xth;
         }
+        we.tiled = tlsdev::row_is_tiled(we.width, we.xth) ? 1 : 0;
+        // rows are stored zero padded (pad_front before, pad_back after, then up to a multiple
+        // of 8 doubles) so that the unrolled dot product needs no edge handling; the pads grow
+        // with the stride of a tiled row (its kR windows reach (kR-1)*xth samples further)
+        const size_t front = (size_t)tlsdev::pad_front(we.tiled ? we.xth : 1);
+        const size_t back = (size_t)tlsdev::pad_back(we.tiled ? we.xth : 1);
+        we.q_offset = (int)(q_count + front);
         we.overshoot = tmpl->overshoot[r];
         double s2 = 0.0;
-        if (q) q->insert(q->end(), (size_t)tlsdev::kPadFront, 0.0);
+        if (q) q->insert(q->end(), front, 0.0);
         for (int64_t j = 0; j < len; ++j) {
             const double qj = 1 - tmpl->values[tmpl->offset[r] + j];  // core.py:68
             if (q) q->push_back(qj);
             s2 += qj * qj;
         }
-        size_t row_total = (size_t)tlsdev::kPadFront + (size_t)len + (size_t)tlsdev::kPadBack;
+        size_t row_total = front + (size_t)len + back;
         row_total = (row_total + 7) / 8 * 8;
         if (q) q->resize(q_count + row_total, 0.0);
         q_count += row_total;
@@ -261,7 +266,8 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     }
     a.queue = ctx->d_queue.ptr;
     a.scratch = ctx->d_scratch.ptr;
-    a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1 + tlsdev::kRegionPad);
+    a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1 + ctx->region_pad);
+    a.region_pad = ctx->region_pad;
     a.chunk_lists = ctx->d_lists.ptr; a.list_stride = (long long)ctx->list_stride; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
@@ -405,7 +411,10 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
 
     // launch geometry
     const size_t regions = uniform ? 2 : 3;
-    const size_t region_doubles = (size_t)(M + 1 + tlsdev::kRegionPad);
+    int widest_stride = 1;  // of the tiled rows: sizes the pads behind the folded series and the tile halo
+    for (const auto& we : widths) if (we.tiled) widest_stride = std::max(widest_stride, we.xth);
+    ctx->region_pad = tlsdev::region_pad_for(widest_stride);
+    const size_t region_doubles = (size_t)(M + 1 + ctx->region_pad);
     // LDS header: fixed part + per-row live counters and batch prefix (+ the batch counter)
     const size_t hdr = ((size_t)tlsdev::kFixedHeader + 4 * (3 * widths.size() + 2) + 15) / 16 * 16;
     const size_t resident_bytes = hdr + regions * 8 * region_doubles;
@@ -422,15 +431,27 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     } else {
         // the folded series lives in a per-workgroup HBM slab; phase 3 stages it through LDS in
         // tiles of `tile_len` window-start positions plus a halo of the widest window
-        ctx->nb = (int)std::min<int64_t>(n, 16384);
-        const size_t halo = (size_t)W + (tlsdev::kR - 1) * tlsdev::kMaxTiledStride + 2 * tlsdev::kU + 4;
+        // sort histogram: one bucket per point while the counters fit the LDS (fewer points per
+        // bucket = fewer comparisons in the in-bucket ranking)
+        ctx->nb = (int)std::min<int64_t>(n, (int64_t)((kLdsPerCU - hdr) / 4));
+        const size_t halo = (size_t)W + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
         const size_t unit = (size_t)tlsdev::kR * tlsdev::kWave;  // tile bounds: multiples of 320
-        // staged per tile: e (or e*w), w for per-point weights, and the prefix sum C if it fits
-        size_t buffers = (uniform ? 1 : 2) + 1;
-        size_t cap_doubles = (kLdsPerCU - hdr) / 8 / buffers;
-        ctx->stage_c = cap_doubles >= halo + unit;
-        if (!ctx->stage_c) { buffers -= 1; cap_doubles = (kLdsPerCU - hdr) / 8 / buffers; }
-        if (cap_doubles < halo + unit) return fail(ctx, TLS_E_ARG, "widest transit window does not fit the LDS tile");
+        // staged per tile: e (or e*w), w for per-point weights, and the prefix sum C if that does
+        // not shrink the tiles too much (C is then read from the HBM slab through L2): with a
+        // window as wide as the LDS (Kepler-size series) most of a tile is halo, and halving the
+        // staged arrays cuts the number of tiles many times over
+        const size_t buffers_c = (uniform ? 1 : 2) + 1, buffers_noc = buffers_c - 1;
+        auto tiles_for = [&](size_t buffers) -> size_t {
+            const size_t cap = (kLdsPerCU - hdr) / 8 / buffers;
+            if (cap < halo + unit) return 0;  // does not fit
+            const size_t cap_tile = (cap - halo) / unit * unit;
+            return ((size_t)M + cap_tile - 1) / cap_tile;
+        };
+        const size_t tiles_c = tiles_for(buffers_c), tiles_noc = tiles_for(buffers_noc);
+        if (tiles_noc == 0) return fail(ctx, TLS_E_ARG, "widest transit window does not fit the LDS tile");
+        ctx->stage_c = tiles_c != 0 && tiles_c <= 4 * tiles_noc;
+        const size_t buffers = ctx->stage_c ? buffers_c : buffers_noc;
+        const size_t cap_doubles = (kLdsPerCU - hdr) / 8 / buffers;
         const size_t cap_tile = (cap_doubles - halo) / unit * unit;
         const size_t n_tiles = ((size_t)M + cap_tile - 1) / cap_tile;
         size_t tile = (((size_t)M + n_tiles - 1) / n_tiles + unit - 1) / unit * unit;
@@ -448,12 +469,11 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     size_t list_cap = 0;
     for (auto& we : widths) {
         const int64_t n_pos = (M - we.width) / we.xth + 1;
-        const int64_t r = we.xth <= tlsdev::kMaxTiledStride ? tlsdev::kR : 1;
+        const int64_t r = we.tiled ? tlsdev::kR : 1;
         we.n_pos = (int)n_pos;
         we.n_chunks = (int)((n_pos + r - 1) / r);
         we.list_base = (int)list_cap;
         we.inv_d = 1.0 / (double)we.width;
-        we.pad = 0.0;
         list_cap += (size_t)we.n_chunks;
     }
     ctx->list_stride = (list_cap + 63) / 64 * 64;

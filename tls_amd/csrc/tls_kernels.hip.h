@@ -10,13 +10,13 @@
 //   phase 4  argmin reduction          core.py:70-74, 183-188
 //
 // Data layout.  The phase-folded series lives in LDS for the whole period ("resident"
-// variant: 16*(N+W+1+kRegionPad) bytes, N = points, W = widest trial transit) or, when it does
+// variant: 16*(N+W+1+region_pad) bytes, N = points, W = widest trial transit) or, when it does
 // not fit (TESS/Kepler-size N), in a per-workgroup slab of HBM scratch that stays L2/MALL-warm
 // and is staged through LDS in tiles of window-start positions plus a halo of one window.
 //   regA: f[0..M)  folded flux, patched with its first W samples (M = N+W), later e = 1-f
 //   regB: C[0..M]  sequential prefix sum of f  (during the sort: bucket counters + indices)
 //   regW: w[0..M)  1/dy^2 in folded order (only when the weights are not uniform)
-// Each region has kRegionPad spare entries so that the unrolled dot product may read a few
+// Each region has region_pad spare entries so that the unrolled dot product may read a few
 // samples past a window (they meet the zero padding of the template rows); behind C the spare
 // entries are rising sentinels that make every window past the T0 grid fail the predicate.
 //
@@ -65,10 +65,18 @@ constexpr int kPhases = 22;    // phase-clock slots (tls_amd/_lib.py names them)
 constexpr int kR = TLS_KR;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
 constexpr int kU = 8;          // template taps per unrolled iteration
 constexpr int kSparseRow = 40;      // rows with at most this many live chunks are re-listed position by position
-constexpr int kMaxTiledStride = 5;  // T0 strides up to this use the kR-window dot product
-constexpr int kPadFront = ((kR - 1) * kMaxTiledStride + 7) / 8 * 8;  // zeros in front of every template row (>= (kR-1)*kMaxTiledStride, 64-B multiple)
-constexpr int kPadBack = (2 * kU + (kR - 1) * kMaxTiledStride + 7) / 8 * 8;   // zeros behind every template row (>= 2*kU + (kR-1)*kMaxTiledStride)
-constexpr int kRegionPad = (2 * kU + kR * kMaxTiledStride + 7) / 8 * 8; // spare entries behind every folded-series region (>= 2*kU + kR*kMaxTiledStride)
+constexpr int kMaxTiledStride = 5;  // T0 strides up to this have a dot product with compile-time tap offsets
+constexpr int kMaxRuntimeStride = 128;  // larger strides (only with a huge T0_fit_margin) go one window per lane
+// A row is "tiled" (kR windows per lane share every folded sample) when its stride is small
+// against its width: the kR windows then overlap almost completely.
+__host__ __device__ constexpr bool row_is_tiled(int width, int xth) {
+    return xth <= kMaxTiledStride || (xth <= kMaxRuntimeStride && 8 * xth <= width);
+}
+// zeros in front of / behind a template row whose windows are `xth` samples apart, and the spare
+// entries behind every folded-series region for the widest tiled stride `xs` of the plan
+__host__ __device__ constexpr int pad_front(int xth) { return ((kR - 1) * (xth > kMaxTiledStride ? xth : kMaxTiledStride) + 7) / 8 * 8; }
+__host__ __device__ constexpr int pad_back(int xth) { return (2 * kU + (kR - 1) * (xth > kMaxTiledStride ? xth : kMaxTiledStride) + 7) / 8 * 8; }
+__host__ __device__ constexpr int region_pad_for(int xs) { return (2 * kU + kR * (xs > kMaxTiledStride ? xs : kMaxTiledStride) + 7) / 8 * 8; }
 constexpr int kCumsumScratchBytes = 1920;  // >= sizeof(CumsumScratch), 16-B multiple
 constexpr int kFixedHeader = 560 + kCumsumScratchBytes;  // wsum[32] | wbest[16] | s_work[12] | cumsum scratch
 
@@ -128,12 +136,13 @@ struct WidthEntry {
     int q_len;        // len(signal) (== width in practice)
     int xth;          // T0 stride (core.py:50-55)
     int n_pos;        // trial T0 positions u = 0..n_pos-1, window start i = u*xth <= M-d
-    int n_chunks;     // phase-3 work units of this width: ceil(n_pos/kR) if xth == 1, else n_pos
+    int n_chunks;     // phase-3 work units of this width: ceil(n_pos/kR) if tiled, else n_pos
     int list_base;    // start of this width's live-unit list inside a workgroup's list slab
     double overshoot; // lc_cache_overview["overshoot"][row]
     double sum_q2;    // sum_j q_j^2 (uniform-weight case: A(i) = w0 * sum_q2)
     double inv_d;     // 1/d
-    double pad;
+    int tiled;        // row_is_tiled(width, xth)
+    int reserved;
 };
 
 // In-range widths of one period (core.py:143-156): the contiguous range [k_lo, k_hi) of the
@@ -170,6 +179,7 @@ struct SearchArgs {
     int hdr_bytes;          // LDS header: fixed part + per-row tables (16-B multiple)
     int tile_len;           // non-resident: window-start positions per LDS tile (multiple of 320)
     int tile_halo;          // non-resident: samples staged behind a tile (widest window + slack)
+    int region_pad;         // spare entries behind every folded-series region (region_pad_for)
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period, double epoch) {
@@ -563,36 +573,47 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
         __syncthreads();
         cpc.mark(17);
         // ---- D: wave 0 chains the binade changes in fp64 and verifies the prediction ----
+        // Inside a verified binade the whole segment behind change j adds the INTEGER t_j (chosen
+        // by the parity of the start mantissa) times the ulp, and S0 + t_j < 2^53 makes that
+        // one exact fp64 addition: the chain is two additions per change, everything else is
+        // prepared per lane in parallel.
         if (wave == 0) {
             const int n_proc = n_seg < kMaxSeg ? n_seg : kMaxSeg;
-            // lane j holds change j: its element, addend, predicted binade and segment map
+            // lane j holds change j: its element, addend, predicted binade and segment step
             int my_c = 0, my_m = 0;
-            double my_f = 0.0;
-            ParityInc my_T; my_T.i0 = 0; my_T.i1 = 0;
-            if (lane < n_proc) { my_c = cs->tab_c[lane]; my_m = cs->tab_m[lane]; my_T = cs->tab_T[lane]; my_f = f[my_c]; }
+            double my_f = 0.0, my_t0 = 0.0, my_t1 = 0.0, my_lim = 0.0;
+            if (lane < n_proc) {
+                my_c = cs->tab_c[lane]; my_m = cs->tab_m[lane]; my_f = f[my_c];
+                const ParityInc T = cs->tab_T[lane];
+                // t * 2^(m-52): exact while t < 2^53; a larger t only has to push the sum out of
+                // the binade, which it does after any rounding
+                my_t0 = ldexp((double)T.i0, my_m - 52);
+                my_t1 = ldexp((double)T.i1, my_m - 52);
+                my_lim = ldexp(1.0, my_m + 1);
+            }
             double s_end = s0;
             int ok = 0, fail_k = kb;
             double fail_s = 0.0;
             bool failed = false;
             for (int j = 0; j < n_proc; ++j) {
-                const int c = lane_value(my_c, j);
                 const double s_new = s_end + lane_value(my_f, j);  // the sequential step itself
-                long long S0;
-                const int m = unbiased_exponent(s_new, &S0);
-                if (m != lane_value(my_m, j)) { failed = true; fail_k = c; fail_s = s_end; break; }
-                const long long t0 = lane_value(my_T.i0, j), t1 = lane_value(my_T.i1, j);
-                const long long S_end = S0 + ((S0 & 1) ? t1 : t0);
-                if (lane == j) { my_f = s_new; my_T.i0 = S0; }  // keep C[c+1] and the start mantissa
-                if (S_end >= kBinadeEnd) { failed = true; fail_k = c + 1; fail_s = s_new; ok = -(j + 1); break; }
+                const long long sb = __double_as_longlong(s_new);
+                const int es = (int)((sb >> 52) & 0x7ff);
+                const int m = es ? es - 1023 : -1022;
+                if (m != lane_value(my_m, j)) { failed = true; fail_k = lane_value(my_c, j); fail_s = s_end; break; }
+                if (lane == j) my_f = s_new;  // keep C[c+1]
+                s_end = s_new + ((sb & 1) ? lane_value(my_t1, j) : lane_value(my_t0, j));
+                if (!(s_end < lane_value(my_lim, j))) {
+                    failed = true; fail_k = lane_value(my_c, j) + 1; fail_s = s_new; ok = -(j + 1); break;
+                }
                 ok = j + 1;
-                s_end = binade_value(S_end, m);
             }
             if (!failed && n_seg > n_proc) { fail_k = cs->tab_c[n_proc]; fail_s = s_end; }
             // a change whose own step verified still gets its C value, even if its segment failed
             const int n_written = ok >= 0 ? ok : -ok;
             if (ok < 0) ok = -ok - 1;
             if (lane < n_written) C[my_c + 1] = my_f;
-            if (lane < ok) cs->tab_S[lane] = my_T.i0;
+            if (lane < ok) { long long S0; unbiased_exponent(my_f, &S0); cs->tab_S[lane] = S0; }
             if (lane == 0) { cs->n_ok = ok; cs->fail_k = fail_k; cs->fail_s = fail_s; }
         }
         __syncthreads();
@@ -723,6 +744,60 @@ __device__ __forceinline__ void dot_windows_weighted(const double* ew, const dou
     }
 }
 
+// The same for any stride (long durations of long light curves: xth = int(d * T0_fit_margin),
+// core.py:50-55): window r reads its own tap stream q[t - r*xth], still wave-uniform scalars.
+template <bool IN_LDS>
+__device__ __forceinline__ void dot_windows_rt(const double* e, const_f64_ptr q, int L, int xth, double (&B)[kR]) {
+    const int S = (kR - 1) * xth;
+    for (int t0 = 0; t0 < L + S; t0 += kU) {
+        // all kR tap blocks are requested before the folded samples: one wait per iteration
+        double taps[kR][kU];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const const_f64_ptr qr = q + (t0 - r * xth);
+#pragma unroll
+            for (int u = 0; u < kU; ++u) taps[r][u] = qr[u];
+        }
+        double x[kU];
+        load_taps<IN_LDS>(e + t0, x);
+#pragma unroll
+        for (int r = 0; r < kR; ++r)
+#pragma unroll
+            for (int u = 0; u < kU; ++u) B[r] = fma(taps[r][u], x[u], B[r]);
+    }
+}
+template <bool IN_LDS>
+__device__ __forceinline__ void dot_windows_weighted_rt(const double* ew, const double* w, const_f64_ptr q,
+                                                        const_f64_ptr q2, int L, int xth, double (&B)[kR], double (&A)[kR]) {
+    const int S = (kR - 1) * xth;
+    for (int t0 = 0; t0 < L + S; t0 += kU) {
+        double taps[kR][kU], x[kU];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const const_f64_ptr qr = q + (t0 - r * xth);
+#pragma unroll
+            for (int u = 0; u < kU; ++u) taps[r][u] = qr[u];
+        }
+        load_taps<IN_LDS>(ew + t0, x);
+#pragma unroll
+        for (int r = 0; r < kR; ++r)
+#pragma unroll
+            for (int u = 0; u < kU; ++u) B[r] = fma(taps[r][u], x[u], B[r]);
+        // the kR tap blocks of q^2 reuse the same scalar registers
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const const_f64_ptr pr = q2 + (t0 - r * xth);
+#pragma unroll
+            for (int u = 0; u < kU; ++u) taps[r][u] = pr[u];
+        }
+        load_taps<IN_LDS>(w + t0, x);
+#pragma unroll
+        for (int r = 0; r < kR; ++r)
+#pragma unroll
+            for (int u = 0; u < kU; ++u) A[r] = fma(taps[r][u], x[u], A[r]);
+    }
+}
+
 // Fold `t` at (period, epoch) and produce the STABLE ascending order of the phases
 // (numpy.argsort(kind="mergesort"), core.py:119-120 / stats.py:178-179): perm[k] = original index
 // of the k-th smallest phase.  Bucket sort: histogram of floor(phase*nb) with LDS atomics, scan,
@@ -780,7 +855,8 @@ tls_search_kernel(const SearchArgs a) {
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform by construction
     const int n = a.n, W = a.W, M = a.M, nb = a.nb;
-    const int RS = M + 1 + kRegionPad;  // region stride in doubles
+    const int region_pad = a.region_pad;
+    const int RS = M + 1 + region_pad;  // region stride in doubles
 
     // ---- memory carve-up -----------------------------------------------------------
     unsigned int* wsum = reinterpret_cast<unsigned int*>(smem);            // 32 words
@@ -814,7 +890,7 @@ tls_search_kernel(const SearchArgs a) {
     double* ph_orig = regA;  // phase by ORIGINAL index during the sort
 
     // the spare entries behind each region are only ever multiplied by zero: make them finite
-    for (int k = tid; k < kRegionPad; k += nt) {
+    for (int k = tid; k < region_pad; k += nt) {
         regA[M + 1 + k] = 0.0;
         if constexpr (!UNIFORM_W) regW[M + 1 + k] = 0.0;
     }
@@ -886,7 +962,7 @@ tls_search_kernel(const SearchArgs a) {
         // absurdly deep "mean" and fails the depth predicate without any bounds test.  The
         // sentinels RISE (k * 1e300 at index M + k) so that a window whose both ends lie in the
         // sentinels (possible for widths below kR) still sees a huge positive sum.
-        if (tid < kRegionPad) regB[M + 1 + tid] = (double)(tid + 1) * 1.0e300;
+        for (int k = tid; k < region_pad; k += nt) regB[M + 1 + k] = (double)(k + 1) * 1.0e300;
         __syncthreads();
         pc.mark(5);
         // e = 1 - f in place (uniform weights) or e*w (general weights)
@@ -920,7 +996,7 @@ tls_search_kernel(const SearchArgs a) {
             pc.mark(20);
             for (int k = tid; k < staged; k += nt) {
                 const int src = p_lo + k;
-                const bool in = src < M + 1 + kRegionPad;
+                const bool in = src < M + 1 + region_pad;
                 tile_e[k] = in ? regA[src] : 0.0;
                 if constexpr (!UNIFORM_W) tile_w[k] = in ? regW[src] : 0.0;
                 if constexpr (STAGE_C) tile_c[k] = in ? regB[src] : (double)(src - M) * 1.0e300;
@@ -993,7 +1069,7 @@ tls_search_kernel(const SearchArgs a) {
             const int n_units = widths_c[k].n_chunks;
             const double inv_d = widths_c[k].inv_d;
             unsigned int* list = chunk_list + widths_c[k].list_base;
-            if (xth <= kMaxTiledStride) {
+            if (widths_c[k].tiled) {
                 const int span = kR * xth;  // samples between the first windows of two units
                 const int unit_lo = (p_lo + span - 1) / span;
                 const int unit_hi = (p_hi + span - 1) / span < n_units ? (p_hi + span - 1) / span : n_units;
@@ -1039,7 +1115,7 @@ tls_search_kernel(const SearchArgs a) {
             const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
             const int xth = widths_c[k].xth, n_units = widths_c[k].n_chunks;
             unsigned int count = 0;
-            if (xth <= kMaxTiledStride && n_live > 0 && n_live <= kSparseRow && n_units >= (kR + 1) * kSparseRow) {
+            if (widths_c[k].tiled && n_live > 0 && n_live <= kSparseRow && n_units >= (kR + 1) * kSparseRow) {
                 const int d = widths_c[k].width;
                 const double inv_d = widths_c[k].inv_d;
                 unsigned int* list = chunk_list + widths_c[k].list_base;
@@ -1106,6 +1182,7 @@ tls_search_kernel(const SearchArgs a) {
                 const int q_offset = widths_c[k].q_offset, list_base = widths_c[k].list_base;
                 const double overshoot = widths_c[k].overshoot, sum_q2 = widths_c[k].sum_q2;
                 const double inv_d = widths_c[k].inv_d, dd = (double)d;
+                const int tiled = widths_c[k].tiled;
                 const unsigned int slot = (gg - rt.batch_start[row]) * kWave + lane;
                 const int n_singles = __builtin_amdgcn_readfirstlane((int)rt.singles[row]);
                 const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
@@ -1114,7 +1191,7 @@ tls_search_kernel(const SearchArgs a) {
                 const int unit = have ? (int)chunk_list[list_base + (n_singles ? n_live : 0) + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
                 const unsigned long long evals_before = n_eval;
-                if (xth <= kMaxTiledStride && n_singles == 0) {
+                if (tiled && n_singles == 0) {
                     // kR windows per lane, xth samples apart
                     const int u0 = unit * kR;
                     const int b = u0 * xth;
@@ -1129,7 +1206,8 @@ tls_search_kernel(const SearchArgs a) {
                             case 2: dot_windows<true, 2>(e, q, Lr, Bv); break;
                             case 3: dot_windows<true, 3>(e, q, Lr, Bv); break;
                             case 4: dot_windows<true, 4>(e, q, Lr, Bv); break;
-                            default: dot_windows<true, 5>(e, q, Lr, Bv); break;
+                            case 5: dot_windows<true, 5>(e, q, Lr, Bv); break;
+                            default: dot_windows_rt<true>(e, q, Lr, xth, Bv); break;
                         }
 #pragma unroll
                         for (int r = 0; r < kR; ++r) Av[r] = sum_q2;
@@ -1141,7 +1219,8 @@ tls_search_kernel(const SearchArgs a) {
                             case 2: dot_windows_weighted<true, 2>(e, wv, q, q2, Lr, Bv, Av); break;
                             case 3: dot_windows_weighted<true, 3>(e, wv, q, q2, Lr, Bv, Av); break;
                             case 4: dot_windows_weighted<true, 4>(e, wv, q, q2, Lr, Bv, Av); break;
-                            default: dot_windows_weighted<true, 5>(e, wv, q, q2, Lr, Bv, Av); break;
+                            case 5: dot_windows_weighted<true, 5>(e, wv, q, q2, Lr, Bv, Av); break;
+                            default: dot_windows_weighted_rt<true>(e, wv, q, q2, Lr, xth, Bv, Av); break;
                         }
                     }
                     if (have) {
@@ -1190,9 +1269,10 @@ tls_search_kernel(const SearchArgs a) {
                 n_steps += (n_eval - evals_before) * (unsigned long long)L;
             }
         }
+        pc.mark(7);
         }  // position tiles
         __syncthreads();
-        pc.mark(7);
+        pc.mark(21);
 
         // ---- phase 4: argmin over the workgroup --------------------------------------
 #pragma unroll
