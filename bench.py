@@ -69,8 +69,15 @@ def cpu_baseline(inp, grid_cells, budget_s=20.0):
             stride = max(1, int(numpy.ceil(dt * grid_cells / max(cells, 1) / budget)))
             sample = periods[::stride]
             dt, cells = timed(lib, sample, n_threads)
-        return cells / dt, "%d of %d periods (every %d%s) of the same light curve, %.1f s" % (
-            len(sample), len(periods), stride, "th" if stride > 1 else "st", dt)
+        reps = 1
+        if stride == 1 and dt < 0.25 * budget:   # the whole grid is quick on this host: repeat it
+            reps = max(1, min(50, int(0.5 * budget / dt)))
+            t_all = 0.0
+            for _ in range(reps):
+                t_all += timed(lib, sample, n_threads)[0]
+            dt = t_all / reps
+        return cells / dt, "%d of %d periods (every %d%s) of the same light curve, %d x %.2f s" % (
+            len(sample), len(periods), stride, "th" if stride > 1 else "st", reps, dt)
 
     strict = oracle.OracleLibrary()
     value, what = bounded(strict, 0, budget_s)
