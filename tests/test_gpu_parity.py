@@ -3,6 +3,8 @@ outputs of the unmodified reference.  Tolerance from BASELINE.json `north_star`:
 chi2 within 1e-6 relative, argmin period index exact.  In practice the kernels
 agree to ~1e-13; the asserts below use 1e-9 so that a real regression is caught,
 and the 1e-6 contract is asserted separately."""
+import os
+
 import numpy
 import pytest
 
@@ -97,7 +99,7 @@ def test_tess_2min_vs_oracle_sample(gpu, oracle_lib):
     inp = _inputs("tess_27d")
     got = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
     assert not gpu.plan_info()["resident"]
-    sel = numpy.arange(0, len(inp["periods"]), 25)
+    sel = numpy.arange(0, len(inp["periods"]), int(os.environ.get("TLS_TESS_STRIDE", 25)))  # 1: the whole grid
     want = oracle_search(oracle_lib, inp, periods=inp["periods"][sel])
     assert_parity(tuple(a[sel] for a in got[:3]), want, len(inp["t"]))
     assert len(inp["periods"]) == 2459
@@ -107,7 +109,7 @@ def test_kepler_4yr_sample_vs_oracle(gpu, oracle_lib):
     """BASELINE config 3 (N=70128, W=8416), a spread sample of its 182k periods."""
     inp = _inputs("kepler_4yr")
     assert len(inp["periods"]) == 182388
-    sel = inp["periods"][::6000]
+    sel = inp["periods"][::int(os.environ.get("TLS_KEPLER_STRIDE", 6000))]
     got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
     want = oracle_search(oracle_lib, inp, periods=sel)
     assert_parity(got, want, len(inp["t"]))
@@ -356,7 +358,17 @@ def test_survey_batch_equals_individual_searches(gpu):
     assert int(numpy.argmin(chi2[0])) == 7738
 
 
-@pytest.mark.parametrize("seed", [2024, 7, 99])
+# TLS_FUZZ_SEEDS="100-140" (or "5,6,7") adds seeds for a one-off longer sweep
+def _extra_seeds():
+    spec = os.environ.get("TLS_FUZZ_SEEDS", "")
+    out = []
+    for part in filter(None, spec.split(",")):
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+@pytest.mark.parametrize("seed", [2024, 7, 99] + _extra_seeds())
 def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
     """Seeded sweep over sizes, cadences, noise levels, weights, T0 strides, depth thresholds and
     duration-grid steps: resident and tiled kernel variants, dense and strided T0 grids, uniform
