@@ -39,6 +39,8 @@ def test_hip_matches_reference_goldens(gpu, name):
     chi2, row, depth, counters = gpu.search(g["t"], g["y"], g["dy"], g["periods"], table, params,
                                             count_work=True)
     assert_parity((chi2, row, depth), (g["chi2"], g["row"], g["depth"]), len(g["t"]))
+    plain = gpu.search(g["t"], g["y"], g["dy"], g["periods"], table, params)   # may take the pruning kernel
+    assert_parity(plain[:3], (g["chi2"], g["row"], g["depth"]), len(g["t"]))
 
 
 def _inputs(name, **over):
@@ -412,6 +414,9 @@ def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
         assert_parity(got, want, len(inp["t"]))
         assert got[3]["evaluated_cells"] == int(want[3][1]), (case, kwargs)
         assert got[3]["inner_steps"] == int(want[3][2]), (case, kwargs)
+        # the uncounted call may take the pruning kernel (noisy cases; TLS_PRUNE=1 forces it)
+        plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+        assert_parity(plain, want, len(inp["t"]))
         n_cases += 1
     assert n_cases >= 12
 
@@ -430,3 +435,22 @@ def test_large_series_with_per_point_weights(gpu, oracle_lib, name, stride):
     want = oracle_search(oracle_lib, inp, periods=sel)
     assert_parity(got, want, len(inp["t"]))
     assert got[3]["evaluated_cells"] == int(want[3][1])
+
+
+@pytest.mark.parametrize("name,sigma,stride", [("k2_90d", None, 3), ("k2_90d", 500e-6, 3), ("k2_90d", 3000e-6, 7),
+                                               ("tutorial01", 300e-6, 5), ("tess_27d", 1000e-6, 20),
+                                               ("kepler_4yr", 500e-6, 9000)])
+def test_pruning_kernel_is_exact(gpu, name, sigma, stride, monkeypatch):
+    """The branch-and-bound variant (cell_bound in tls_kernels.hip.h) only skips cells that cannot
+    win: per period it must return the same bits as the plain kernel, whatever the noise level and
+    however aggressively it is switched on (TLS_PRUNE / TLS_PRUNE_MIN_LIVE are read at prepare time)."""
+    inp = _inputs(name, sigma=sigma)
+    sel = inp["periods"][::stride]
+    monkeypatch.setenv("TLS_PRUNE", "0")
+    plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+    monkeypatch.setenv("TLS_PRUNE", "1")
+    for min_live in ("0", "4000"):
+        monkeypatch.setenv("TLS_PRUNE_MIN_LIVE", min_live)
+        pruned = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+        for x, y in zip(plain[:3], pruned[:3]):
+            numpy.testing.assert_array_equal(x, y)

@@ -83,7 +83,10 @@ struct tls_ctx {
     DevBuf<unsigned int> d_queue, d_lists;
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
     size_t list_stride = 0;
-    int hdr_bytes = 0, tile_len = 0, tile_halo = 0, region_pad = 0;
+    int hdr_bytes = 0, tile_len = 0, tile_halo = 0, region_pad = 0, p2_shift = 4;
+    bool prune_kernel = false;        // launch the pruning variant (pruning_pays)
+    std::vector<tlsdev::WidthEntry> host_widths;  // kept for tls_update_flux's pruning decision
+    long long prune_min_live = 4000;  // live units per period (tile) from which pruning pays; TLS_PRUNE_MIN_LIVE overrides
     bool stage_c = false;
 
     // host-side plan
@@ -176,7 +179,7 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
         const int64_t len = tmpl->length[r];
         if (len < 1 || len > wd) return fail(ctx, TLS_E_ARG, "template row longer than its width");
         tlsdev::WidthEntry we;
-        we.width = (int)wd; we.row = (int)r; we.q_len = (int)len; we.reserved = 0;
+        we.width = (int)wd; we.row = (int)r; we.q_len = (int)len;
         we.n_pos = 0; we.n_chunks = 0; we.list_base = 0; we.inv_d = 1.0 / (double)wd;
         we.xth = 1;
         if (margin > 0 && (double)wd > margin) {  // core.py:50-55
@@ -192,13 +195,26 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
         const size_t back = (size_t)tlsdev::pad_back(we.tiled ? we.xth : 1);
         we.q_offset = (int)(q_count + front);
         we.overshoot = tmpl->overshoot[r];
-        double s2 = 0.0;
+        double s2 = 0.0, s1 = 0.0;
         if (q) q->insert(q->end(), front, 0.0);
         for (int64_t j = 0; j < len; ++j) {
             const double qj = 1 - tmpl->values[tmpl->offset[r] + j];  // core.py:68
             if (q) q->push_back(qj);
             s2 += qj * qj;
+            s1 += qj;
         }
+        // constants of the pruning bound (cell_bound in tls_kernels.hip.h), rounded outwards
+        double vq = 0.0;
+        for (int64_t j = 0; j < len; ++j) {
+            const double dq = (1 - tmpl->values[tmpl->offset[r] + j]) - s1 / (double)len;
+            vq += dq * dq;
+        }
+        we.var_q = vq * (1 + 1e-12);
+        we.k_mono = s1 - we.overshoot * s2;
+        we.prunable = (len == wd && we.k_mono >= 0 && we.overshoot > 0 && params->transit_depth_min >= 0) ? 1 : 0;
+        we.k_mono *= (1 + 1e-12);
+        we.c_proxy = 4 * we.overshoot * we.k_mono;
+        we.reserved = 0.0;
         size_t row_total = front + (size_t)len + back;
         row_total = (row_total + 7) / 8 * 8;
         if (q) q->resize(q_count + row_total, 0.0);
@@ -207,6 +223,21 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
         widths.push_back(we);
     }
     return TLS_OK;
+}
+
+// Pruning pays when most trial cells pass the depth predicate (core.py:58), i.e. when the noise of
+// a window mean, sigma/sqrt(d), is large against transit_depth_min.  Expected passing fraction of a
+// flat, white light curve, averaged over the trial widths; the pruning kernel is used above 0.25.
+// TLS_PRUNE=0/1 forces the choice (tests run both).
+bool pruning_pays(const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min) {
+    if (const char* env = std::getenv("TLS_PRUNE")) return std::atoi(env) != 0;
+    if (!(sigma > 0) || widths.empty()) return false;
+    double acc = 0.0;
+    for (const auto& we : widths) {
+        if (!we.prunable) return false;
+        acc += 0.5 * std::erfc(depth_min * std::sqrt((double)we.width) / sigma / std::sqrt(2.0));
+    }
+    return acc / (double)widths.size() >= 0.25;
 }
 
 // In-range width window of one period (core.py:143-156) and its trial-cell count.
@@ -229,9 +260,9 @@ int64_t period_window(const std::vector<tlsdev::WidthEntry>& widths, const tls_p
     return c;
 }
 
-template <bool RES, bool UNI, bool STAGE_C, typename IdxT>
+template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false>
 hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
-    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT>;
+    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
@@ -268,20 +299,27 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     a.scratch = ctx->d_scratch.ptr;
     a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1 + ctx->region_pad);
     a.region_pad = ctx->region_pad;
-    a.chunk_lists = ctx->d_lists.ptr; a.list_stride = (long long)ctx->list_stride; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
+    a.chunk_lists = ctx->d_lists.ptr; a.list_stride = 2 * (long long)ctx->list_stride; a.list_cap = (long long)ctx->list_stride;
+    a.prune_min_live = ctx->prune_min_live; a.p2_shift = ctx->p2_shift; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
     hipError_t e;
+    // pruning variant: uniform weights, noisy enough that most trial cells pass the depth predicate,
+    // and not while the evaluated cells are being counted (counting means evaluating all of them)
+    const bool prune = ctx->uniform_w && ctx->prune_kernel && !count_work;
     if (ctx->resident)
-        e = ctx->uniform_w ? launch_variant<true, true, false, unsigned short>(ctx, a)
-                           : launch_variant<true, false, false, unsigned short>(ctx, a);
+        e = !ctx->uniform_w ? launch_variant<true, false, false, unsigned short>(ctx, a)
+            : prune ? launch_variant<true, true, false, unsigned short, true>(ctx, a)
+                    : launch_variant<true, true, false, unsigned short>(ctx, a);
     else if (ctx->stage_c)
-        e = ctx->uniform_w ? launch_variant<false, true, true, unsigned int>(ctx, a)
-                           : launch_variant<false, false, true, unsigned int>(ctx, a);
+        e = !ctx->uniform_w ? launch_variant<false, false, true, unsigned int>(ctx, a)
+            : prune ? launch_variant<false, true, true, unsigned int, true>(ctx, a)
+                    : launch_variant<false, true, true, unsigned int>(ctx, a);
     else
-        e = ctx->uniform_w ? launch_variant<false, true, false, unsigned int>(ctx, a)
-                           : launch_variant<false, false, false, unsigned int>(ctx, a);
+        e = !ctx->uniform_w ? launch_variant<false, false, false, unsigned int>(ctx, a)
+            : prune ? launch_variant<false, true, false, unsigned int, true>(ctx, a)
+                    : launch_variant<false, true, false, unsigned int>(ctx, a);
     if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     ctx->executed = true;
     ctx->counted = count_work;
@@ -477,11 +515,17 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         list_cap += (size_t)we.n_chunks;
     }
     ctx->list_stride = (list_cap + 63) / 64 * 64;
-    TLS_HIP(ctx, ctx->d_lists.reserve((size_t)ctx->blocks * ctx->list_stride));
+    // two arrays per workgroup: the live units and (pruning) the bound of each
+    TLS_HIP(ctx, ctx->d_lists.reserve((size_t)ctx->blocks * 2 * ctx->list_stride));
+    if (const char* env = std::getenv("TLS_PRUNE_MIN_LIVE")) ctx->prune_min_live = std::atoll(env);
+    ctx->p2_shift = 4;  // block length of the coarse prefix sum of e^2: at most kP2MaxBlocks blocks
+    while ((((size_t)M + ((size_t)1 << ctx->p2_shift) - 1) >> ctx->p2_shift) > (size_t)tlsdev::kP2MaxBlocks) ++ctx->p2_shift;
 
     ctx->n = (int)n; ctx->W = (int)W; ctx->M = (int)M; ctx->n_periods = (int)n_periods;
     ctx->n_widths = (int)widths.size();
     ctx->uniform_w = uniform; ctx->w0 = w0; ctx->S0 = S0; ctx->depth_min = params->transit_depth_min;
+    ctx->host_widths = widths;
+    ctx->prune_kernel = uniform && pruning_pays(widths, dy[0], params->transit_depth_min);
     ctx->plan_counters = pc;
 
     int rc;
@@ -521,6 +565,7 @@ int tls_update_flux(tls_ctx* ctx, const double* y, const double* dy) {
     if (uniform != ctx->uniform_w)
         return fail(ctx, TLS_E_STATE, "weight structure (uniform / per-point dy) differs from the prepared search");
     ctx->w0 = w0; ctx->S0 = S0;
+    ctx->prune_kernel = uniform && pruning_pays(ctx->host_widths, dy[0], ctx->depth_min);
     int rc;
     if ((rc = upload(ctx, ctx->d_y, y, (size_t)ctx->n))) return rc;
     if (!uniform && (rc = upload(ctx, ctx->d_w, w.data(), (size_t)ctx->n))) return rc;

@@ -62,6 +62,9 @@ constexpr int kPhases = 22;    // phase-clock slots (tls_amd/_lib.py names them)
 #ifndef TLS_KR
 #define TLS_KR 5
 #endif
+#ifndef TLS_PRUNE
+#define TLS_PRUNE 1   // exact branch-and-bound pruning of trial cells (uniform weights), see cell_bound()
+#endif
 constexpr int kR = TLS_KR;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
 constexpr int kU = 8;          // template taps per unrolled iteration
 constexpr int kSparseRow = 40;      // rows with at most this many live chunks are re-listed position by position
@@ -77,6 +80,7 @@ __host__ __device__ constexpr bool row_is_tiled(int width, int xth) {
 __host__ __device__ constexpr int pad_front(int xth) { return ((kR - 1) * (xth > kMaxTiledStride ? xth : kMaxTiledStride) + 7) / 8 * 8; }
 __host__ __device__ constexpr int pad_back(int xth) { return (2 * kU + (kR - 1) * (xth > kMaxTiledStride ? xth : kMaxTiledStride) + 7) / 8 * 8; }
 __host__ __device__ constexpr int region_pad_for(int xs) { return (2 * kU + kR * (xs > kMaxTiledStride ? xs : kMaxTiledStride) + 7) / 8 * 8; }
+constexpr int kP2MaxBlocks = 236;  // blocks of the coarse prefix sum of e^2 (it lives in the cumsum scratch)
 constexpr int kCumsumScratchBytes = 1920;  // >= sizeof(CumsumScratch), 16-B multiple
 constexpr int kFixedHeader = 560 + kCumsumScratchBytes;  // wsum[32] | wbest[16] | s_work[12] | cumsum scratch
 
@@ -142,7 +146,11 @@ struct WidthEntry {
     double sum_q2;    // sum_j q_j^2 (uniform-weight case: A(i) = w0 * sum_q2)
     double inv_d;     // 1/d
     int tiled;        // row_is_tiled(width, xth)
-    int reserved;
+    int prunable;     // cell_bound() is valid for this row (q_len == width, k_mono >= 0, depth_min >= 0)
+    double var_q;     // sum_j (q_j - mean q)^2
+    double k_mono;    // sum_j q_j - overshoot * sum_j q_j^2
+    double c_proxy;   // 4 * overshoot * k_mono: c_proxy * mean^2 ranks the cells of all rows by promise
+    double reserved;
 };
 
 // In-range widths of one period (core.py:143-156): the contiguous range [k_lo, k_hi) of the
@@ -171,6 +179,9 @@ struct SearchArgs {
     unsigned int* chunk_lists;  // per-workgroup lists of live chunks (phase 3a -> 3b)
     long long scratch_stride;   // doubles per slab
     long long list_stride;      // entries per workgroup
+    long long list_cap;         // entries of one array: live units | their bounds (float)
+    long long prune_min_live;   // prune a period (tile) only when at least this many units are live
+    int p2_shift;               // log2 of the block length of the coarse prefix sum of e^2 (pruning bound)
     double depth_min;
     double S0;
     double w0;
@@ -673,6 +684,35 @@ struct RowTables {
     unsigned int* next_batch;   // [1]      dynamic batch counter
 };
 
+// Branch-and-bound pruning (uniform weights).  For a window with mean depth m (= 1 - dC/d) the
+// statistic is  -stat = rs*(2B - rs*A),  rs = 2*m*overshoot,  B = sum_j q_j e_j.  Splitting
+// q and e into mean and fluctuation,  B = m*sum(q) + sum (q_j - qbar)(e_j - m),  and Cauchy-Schwarz
+// bounds the second term by sqrt(var_q * V),  V = sum (e_j - m)^2 = sum e_j^2 - d*m^2.  Hence
+//     -stat <= U = 4*ov*m*(m*k_mono + sqrt(var_q*V)),   k_mono = sum(q) - ov*sum(q^2) >= 0,
+// which increases with m and with V.  For a chunk of kR windows m is taken from the deepest
+// window, V from the shallowest one, and sum e^2 from a coarse (block-granular, hence
+// over-estimating) prefix sum.  A cell whose bound is below a statistic that some evaluated cell
+// has already reached cannot win (strict '<', core.py:70-74): skipping it leaves the result
+// unchanged.  All roundings go upwards (the float steps are inflated by 1e-6).
+__device__ __forceinline__ float cell_bound(double dC_min, double dC_max, double dd, double inv_d, double ov,
+                                            double k_mono, double var_q, double e2) {
+    const double m_hi = fma(-dC_min, inv_d, 1.0);
+    if (!(m_hi > 0.0)) return -INFINITY;
+    const double m_lo = fmax(fma(-dC_max, inv_d, 1.0), 0.0);
+    const double V = fmax(fma(-dd * m_lo, m_lo, e2), 0.0) * (1.0 + 1e-6) + 1e-9 * e2;
+    const float f = sqrtf((float)(var_q * V)) * (1.0f + 1e-6f);
+    const double U = 4.0 * ov * m_hi * fma(m_hi, k_mono, (double)f);
+    return (float)(U * (1.0 + 1e-6));
+}
+
+// sum of e^2 over [lo, hi) from the coarse prefix sum, rounded outwards to whole blocks
+__device__ __forceinline__ double coarse_e2(const double* P2, int lo, int hi, int shift, int n_blocks) {
+    int b_lo = lo >> shift, b_hi = (hi + (1 << shift) - 1) >> shift;
+    b_lo = b_lo < n_blocks ? b_lo : n_blocks;
+    b_hi = b_hi < n_blocks ? b_hi : n_blocks;
+    return P2[b_hi] - P2[b_lo];
+}
+
 // Candidate evaluation shared by all dot-product variants: given the dot products of one
 // T0 position, apply the predicate, form the statistic and keep the lane's best.  Positions
 // past the end of the T0 grid read the +huge sentinels behind C and fail the predicate.
@@ -847,7 +887,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
     pc.mark(3);
 }
 
-template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT>
+template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false>
 __global__ void __launch_bounds__(1024, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -863,6 +903,14 @@ tls_search_kernel(const SearchArgs a) {
     Best* wbest = reinterpret_cast<Best*>(smem + 128);                      // kMaxWaves * 24 B
     int* s_work = reinterpret_cast<int*>(smem + 128 + kMaxWaves * sizeof(Best));  // [4]
     CumsumScratch* cumsum_scratch = reinterpret_cast<CumsumScratch*>(smem + 560);
+    // the pruning variant is a separate instantiation: its extra state costs the plain variant 3-8 %
+    // when both live in one kernel, and the host knows from the noise level which one pays
+    constexpr bool PRUNE = UNIFORM_W && WITH_PRUNING && (TLS_PRUNE != 0);
+    // coarse prefix sum of e^2 for the pruning bound; the cumsum scratch is dead by the time it is built
+    double* P2 = reinterpret_cast<double*>(cumsum_scratch);
+    static_assert(kCumsumScratchBytes >= 8 * (kP2MaxBlocks + 1), "coarse prefix sum does not fit the cumsum scratch");
+    // counting the evaluated cells (tls_execute(ctx, 1)) means evaluating all of them
+    const bool prune_on = PRUNE && a.counters == nullptr;
     static_assert(sizeof(CumsumScratch) <= kCumsumScratchBytes, "cumsum scratch does not fit its slot");
     RowTables rt;
     rt.live = reinterpret_cast<unsigned int*>(smem + kFixedHeader);
@@ -977,6 +1025,7 @@ tls_search_kernel(const SearchArgs a) {
         Best best;
         best.stat = INFINITY; best.td = 0.0; best.k = 0x7fffffff; best.i = 0x7fffffff;
         unsigned long long n_eval = 0, n_steps = 0;
+        bool p2_ready = false;
         // ---- phase 3 runs over TILES of window-start positions [p_lo, p_hi).  Resident variant:
         // one tile, the folded series already sits in LDS.  Otherwise the series is in the HBM slab
         // and each tile (+ halo = widest window) is staged into LDS first; windows are owned by the
@@ -1106,19 +1155,197 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
         pc.mark(9);
-        // Sparse rows: a handful of live chunks would still occupy a whole 64-lane batch with kR
-        // FMAs per tap.  Re-list such rows position by position (only the positions that pass the
-        // predicate) behind their chunk list; phase 3b then runs them one window per lane, which
-        // costs a fraction of the tiled form when most lanes would idle.
+        // ---- pruning (exact): drop the units that cannot win before they reach phase 3b ------------
+        // Worth its passes only when many cells passed the depth predicate (noisy light curves):
+        // decided per period (and tile) from the number of live units.
+        double T = -INFINITY;
+        bool prune_now = false;
+        int p2_blocks = 0;
+        float* const ulist = reinterpret_cast<float*>(chunk_list + a.list_cap);   // bound of every live unit
+        if (prune_on) {
+            unsigned int total_live = 0;
+#pragma unroll 1
+            for (int row = 0; row < n_rows; ++row) total_live += rt.live[row];
+            total_live = (unsigned int)__builtin_amdgcn_readfirstlane((int)total_live);  // uniform: keep it scalar
+            prune_now = (long long)total_live >= a.prune_min_live;
+        }
+        if (prune_now) {
+            // (1) coarse prefix sum of e^2: P2[b] = sum of e_k^2 over k < b * 2^p2_shift
+            if (!p2_ready) {   // once per period, by the first tile that prunes
+                p2_ready = true;
+                const int sh = a.p2_shift, G = 1 << sh;
+                p2_blocks = (M + G - 1) >> sh;
+                if (G <= kWave) {   // short blocks: one thread each
+#pragma unroll 1
+                    for (int b = tid; b < p2_blocks; b += nt) {
+                        const int hi = (b + 1) * G < M ? (b + 1) * G : M;
+                        double acc = 0.0;
+#pragma unroll 4
+                        for (int kk = b * G; kk < hi; ++kk) acc = fma(regA[kk], regA[kk], acc);
+                        P2[b + 1] = acc;
+                    }
+                } else {            // long blocks (series in the HBM slab): one wave each, coalesced
+#pragma unroll 1
+                    for (int b = wave; b < p2_blocks; b += nw) {
+                        const int hi = (b + 1) * G < M ? (b + 1) * G : M;
+                        double acc = 0.0;
+#pragma unroll 2
+                        for (int kk = b * G + lane; kk < hi; kk += kWave) acc = fma(regA[kk], regA[kk], acc);
+#pragma unroll
+                        for (int delta = kWave / 2; delta > 0; delta >>= 1) acc += __shfl_down(acc, delta, kWave);
+                        if (lane == 0) P2[b + 1] = acc;
+                    }
+                }
+                __syncthreads();
+                if (wave == 0) {    // inclusive scan of at most kP2MaxBlocks block sums
+                    const int per = (p2_blocks + kWave - 1) / kWave;
+                    const int lo = lane * per < p2_blocks ? lane * per : p2_blocks;
+                    const int hi = lo + per < p2_blocks ? lo + per : p2_blocks;
+                    double local = 0.0;
+#pragma unroll 1
+                    for (int b = lo; b < hi; ++b) local += P2[b + 1];
+                    double incl = local;
+#pragma unroll
+                    for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+                        const double o = __shfl_up(incl, dlt, kWave);
+                        if (lane >= dlt) incl += o;
+                    }
+                    double run = incl - local;
+#pragma unroll 1
+                    for (int b = lo; b < hi; ++b) { run += P2[b + 1]; P2[b + 1] = run; }
+                    if (lane == 0) P2[0] = 0.0;
+                }
+                __syncthreads();
+            }
+            p2_blocks = (M + (1 << a.p2_shift) - 1) >> a.p2_shift;
+            // (2) the bound of every live unit; each wave remembers its most promising one
+            float cand_u = -INFINITY;
+            int cand_k = 0x7fffffff, cand_unit = 0;
+            for (int row = wave; row < n_rows; row += nw) {
+                const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
+                const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
+                const int xth = widths_c[k].xth, tiled = widths_c[k].tiled, d = widths_c[k].width;
+                const int list_base = widths_c[k].list_base, prunable = widths_c[k].prunable;
+                const double inv_d = widths_c[k].inv_d, dd = (double)d;
+                const double ov = widths_c[k].overshoot, k_mono = widths_c[k].k_mono, var_q = widths_c[k].var_q;
+                const int reach = tiled ? (kR - 1) * xth + d : d;   // samples covered by the windows of a unit
+                const int step = tiled ? kR * xth : xth;            // samples between two units
+#pragma unroll 1
+                for (int base = 0; base < n_live; base += kWave) {
+                    const int idx = base + lane;
+                    if (idx < n_live) {
+                        const int unit = (int)chunk_list[list_base + idx];
+                        const int b = unit * step;
+                        double dC_min = c_base[b + d] - c_base[b], dC_max = dC_min;
+                        if (tiled) {
+#pragma unroll
+                            for (int r = 1; r < kR; ++r) {
+                                const double dC = c_base[b + r * xth + d] - c_base[b + r * xth];
+                                dC_min = fmin(dC_min, dC); dC_max = fmax(dC_max, dC);
+                            }
+                        }
+                        float u = INFINITY;   // rows without a valid bound are always evaluated
+                        if (prunable) {
+                            u = cell_bound(dC_min, dC_max, dd, inv_d, ov, k_mono, var_q,
+                                           coarse_e2(P2, b, b + reach, a.p2_shift, p2_blocks));
+                            if (u > cand_u) { cand_u = u; cand_k = k; cand_unit = unit; }
+                        }
+                        ulist[list_base + idx] = u;
+                    }
+                }
+            }
+            // (3) each wave evaluates its candidate exactly (lanes over the template taps)
+#pragma unroll
+            for (int delta = kWave / 2; delta > 0; delta >>= 1) {
+                const float ou_ = __shfl_down(cand_u, delta, kWave);
+                const int ok_ = __shfl_down(cand_k, delta, kWave), on_ = __shfl_down(cand_unit, delta, kWave);
+                const bool take = ou_ > cand_u || (ou_ == cand_u && (ok_ < cand_k || (ok_ == cand_k && on_ < cand_unit)));
+                if (take) { cand_u = ou_; cand_k = ok_; cand_unit = on_; }
+            }
+            const int ck = __builtin_amdgcn_readfirstlane(cand_k);
+            const int cu = __builtin_amdgcn_readfirstlane(cand_unit);
+            // The candidate's statistic only sets the threshold: its taps are summed in another order
+            // than phase 3b uses, so it may differ from the reported value in the last bits.  The
+            // cell itself survives the threshold and is evaluated again by 3b like any other.
+            Best trial;
+            trial.stat = INFINITY; trial.td = 0.0; trial.k = 0x7fffffff; trial.i = 0x7fffffff;
+            if (ck < k_hi) {  // this wave has a candidate
+                const int d = widths_c[ck].width, L = widths_c[ck].q_len, xth = widths_c[ck].xth;
+                const int tiled = widths_c[ck].tiled, q_offset = widths_c[ck].q_offset;
+                const double overshoot = widths_c[ck].overshoot, sum_q2 = widths_c[ck].sum_q2;
+                const double inv_d = widths_c[ck].inv_d;
+                const int n_win = tiled ? kR : 1;
+                const int i0 = tiled ? cu * kR * xth : cu * xth;   // first sample of the first window
+                const double* qv = a.q + q_offset;
+                double Bc[kR];
+#pragma unroll
+                for (int r = 0; r < kR; ++r) Bc[r] = 0.0;
+#pragma unroll 2
+                for (int tt = lane; tt < L; tt += kWave) {
+                    const double qt = qv[tt];
+#pragma unroll
+                    for (int r = 0; r < kR; ++r)
+                        if (r < n_win) Bc[r] = fma(qt, e_base[i0 + r * xth + tt], Bc[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < kR; ++r)
+#pragma unroll
+                    for (int delta = kWave / 2; delta > 0; delta >>= 1) Bc[r] += __shfl_down(Bc[r], delta, kWave);
+                // lane r takes window r: the same bookkeeping as any evaluated cell
+                double Bmine = 0.0;
+#pragma unroll
+                for (int r = 0; r < kR; ++r) { const double v = lane_value(Bc[r], 0); if (lane == r) Bmine = v; }
+                if (lane < n_win) {
+                    const int i = i0 + lane * xth;
+                    unsigned long long ignored = 0;
+                    consider(trial, c_base[i], c_base[i + d], i, inv_d, (double)d, dmin, overshoot, sum_q2, Bmine, ck, ignored);
+                }
+            }
+            // (4) T = the best statistic any evaluated cell has reached (this and earlier tiles)
+            // loosened by far more than the summation-order difference (1e-12 relative)
+            const double loose = trial.stat < 0.0 ? trial.stat * (1.0 - 1e-12) : trial.stat * (1.0 + 1e-12);
+            double mstat = fmin(best.stat, loose);   // best: cells evaluated by 3b in earlier tiles
+#pragma unroll
+            for (int delta = kWave / 2; delta > 0; delta >>= 1) mstat = fmin(mstat, __shfl_down(mstat, delta, kWave));
+            if (lane == 0) wbest[wave].stat = mstat;   // wbest is idle until phase 4
+            __syncthreads();
+            double g = wbest[0].stat;
+            for (int v = 1; v < nw; ++v) g = fmin(g, wbest[v].stat);
+            T = lane_value(-g, 0);                     // uniform (scalar registers); -inf while nothing has been evaluated
+        }
+        // Per row: (5) keep the units whose bound reaches T, then re-list SPARSE rows.  A handful of
+        // live chunks would still occupy a whole 64-lane batch with kR FMAs per tap, so such rows
+        // are listed position by position (only positions that pass the predicate and the bound)
+        // behind their chunk entries; phase 3b then runs them one window per lane, which costs a
+        // fraction of the tiled form when most lanes would idle.
         for (int row = wave; row < n_rows; row += nw) {
             const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
-            const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
-            const int xth = widths_c[k].xth, n_units = widths_c[k].n_chunks;
+            int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
+            const int xth = widths_c[k].xth, n_units = widths_c[k].n_chunks, tiled = widths_c[k].tiled;
+            const int d = widths_c[k].width, list_base = widths_c[k].list_base;
+            const double inv_d = widths_c[k].inv_d, dd = (double)d;
+            const bool bound_row = prune_now && widths_c[k].prunable;
+            const double ov = widths_c[k].overshoot, k_mono = widths_c[k].k_mono, var_q = widths_c[k].var_q;
+            unsigned int* list = chunk_list + list_base;
+            if (bound_row && n_live > 0) {
+                // compaction in place: a 64-entry group is read before anything at or behind it is written
+                int n_sel = 0;
+#pragma unroll 1
+                for (int base = 0; base < n_live; base += kWave) {
+                    const int idx = base + lane;
+                    const bool valid = idx < n_live;
+                    const unsigned int unit = valid ? list[idx] : 0u;
+                    const bool sel = valid && (double)ulist[list_base + idx] >= T;
+                    const unsigned long long mask = __ballot(sel);
+                    if (sel) list[n_sel + __popcll(mask & ((1ull << lane) - 1ull))] = unit;
+                    n_sel += __popcll(mask);
+                }
+                n_live = n_sel;
+                __threadfence_block();   // the re-listing below reads entries other lanes have just moved
+            }
             unsigned int count = 0;
-            if (widths_c[k].tiled && n_live > 0 && n_live <= kSparseRow && n_units >= (kR + 1) * kSparseRow) {
-                const int d = widths_c[k].width;
-                const double inv_d = widths_c[k].inv_d;
-                unsigned int* list = chunk_list + widths_c[k].list_base;
+            if (tiled && n_live > 0 && n_live <= kSparseRow && n_units >= (kR + 1) * kSparseRow) {
+#pragma unroll 1
                 for (int base = 0; base < n_live * kR; base += kWave) {
                     const int idx = base + lane;
                     bool pass = false;
@@ -1128,14 +1355,18 @@ tls_search_kernel(const SearchArgs a) {
                         const int i = u * xth;
                         const double dC = c_base[i + d] - c_base[i];   // past the grid: sentinel
                         const int cls = depth_class(dC, inv_d, dmin);
-                        pass = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
+                        pass = cls > 0 || (cls < 0 && depth_exact(dC, dd, dmin));
+                        if (bound_row && pass)
+                            pass = (double)cell_bound(dC, dC, dd, inv_d, ov, k_mono, var_q,
+                                                      coarse_e2(P2, i, i + d, a.p2_shift, p2_blocks)) >= T;
                     }
                     const unsigned long long mask = __ballot(pass);
                     if (pass) list[n_live + count + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)u;
                     count += (unsigned int)__popcll(mask);
                 }
+                if (count == 0) n_live = 0;   // every window of every selected chunk was pruned
             }
-            if (lane == 0) rt.singles[row] = count;
+            if (lane == 0) { rt.live[row] = (unsigned int)n_live; rt.singles[row] = count; }
         }
         __syncthreads();
         if (wave == 0) {  // exclusive scan of the batch counts over the rows
@@ -1241,11 +1472,11 @@ tls_search_kernel(const SearchArgs a) {
                             double x[kU];
                             load_taps<true>(e + t0, x);
                             const const_f64_ptr qs = q + t0;
+                            // one accumulator, taps in order: the same rounding as the kR-window form, so a
+                            // cell has ONE value whether its row runs tiled or re-listed (pruning moves rows
+                            // between the two); the other waves of the SIMD hide the FMA latency
 #pragma unroll
-                            for (int u = 0; u < kU; u += 2) {
-                                B0 = fma(qs[u], x[u], B0);
-                                B1 = fma(qs[u + 1], x[u + 1], B1);
-                            }
+                            for (int u = 0; u < kU; ++u) B0 = fma(qs[u], x[u], B0);
                         }
                         A0 = sum_q2;
                     } else {
@@ -1258,10 +1489,7 @@ tls_search_kernel(const SearchArgs a) {
                             const const_f64_ptr qs = q + t0;
                             const const_f64_ptr ps = q2 + t0;
 #pragma unroll
-                            for (int u = 0; u < kU; u += 2) {
-                                B0 = fma(qs[u], x[u], B0);         A0 = fma(ps[u], z[u], A0);
-                                B1 = fma(qs[u + 1], x[u + 1], B1); A1 = fma(ps[u + 1], z[u + 1], A1);
-                            }
+                            for (int u = 0; u < kU; ++u) { B0 = fma(qs[u], x[u], B0); A0 = fma(ps[u], z[u], A0); }
                         }
                     }
                     if (have) consider(best, c_base[i], c_base[i + d], i, inv_d, dd, dmin, overshoot, A0 + A1, B0 + B1, k, n_eval);
