@@ -92,13 +92,15 @@ int tls_prepare(tls_ctx *ctx, const double *t, const double *y, const double *dy
  * survey mode streams many light curves through one prepared plan. */
 int tls_update_flux(tls_ctx *ctx, const double *y, const double *dy);
 /* execute: enqueue the search kernels on the context's stream (asynchronous).
- * count_work & 1 also accumulates evaluated_cells/inner_steps (slower). */
+ * count_work & 1 also accumulates evaluated_cells/inner_steps (slower: counting means evaluating
+ * every cell that passes the depth predicate, so the pruning kernel variant is not used). */
 int tls_execute(tls_ctx *ctx, int count_work);
 /* developer instrumentation: tls_execute(ctx, 2) makes thread 0 of every workgroup stamp
- * the shader clock at phase boundaries; this returns the per-phase cycle sums (up to 22 slots:
+ * the shader clock at phase boundaries; this returns the per-phase cycle sums (up to 26 slots:
  * fold+count, scan, scatter, rank, gather+patch, cumsum, batch prefix, chi2, e-convert,
  * strided predicate, two event counters (cumsum blocks, cumsum fallbacks), tile staging,
- * dense predicate, six cumsum sub-phases, two spare; names in tls_amd/_lib.py::phase_cycles). */
+ * dense predicate, six cumsum sub-phases, two barrier waits, four pruning steps; names in
+ * tls_amd/_lib.py::phase_cycles). */
 int tls_debug_phase_cycles(tls_ctx *ctx, uint64_t *cycles, int n);
 /* developer/test entry: the kernel's exact parallel evaluation of the sequential fp64 prefix
  * sum (numpy.cumsum order, helpers.py:72) on an arbitrary series of non-negative values;

@@ -221,12 +221,12 @@ class Context(object):
     def phase_cycles(self):
         """Developer instrumentation: per-phase shader-cycle sums of the last
         execute(phase_clock=True)."""
-        arr = (ctypes.c_uint64 * 22)()
-        self._check(self._lib.tls_debug_phase_cycles(self._h, arr, 22))
+        arr = (ctypes.c_uint64 * 26)()
+        self._check(self._lib.tls_debug_phase_cycles(self._h, arr, 26))
         names = ("fold_count", "scan", "scatter", "rank", "gather_patch", "cumsum", "batch_prefix",
                  "chi2", "e_convert", "predicate_strided", "cumsum_blocks", "cumsum_fallbacks",
                  "tile_staging", "predicate_dense", "cs_A", "cs_B1", "cs_B2", "cs_scan", "cs_D", "cs_E",
-                 "tile_wait", "chi2_wait")
+                 "tile_wait", "chi2_wait", "prune_e2", "prune_bounds", "prune_incumbent", "select_relist")
         return dict(zip(names, [int(v) for v in arr]))
 
     def synchronize(self):

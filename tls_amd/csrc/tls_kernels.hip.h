@@ -58,7 +58,7 @@ namespace tlsdev {
 
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
-constexpr int kPhases = 22;    // phase-clock slots (tls_amd/_lib.py names them)
+constexpr int kPhases = 26;    // phase-clock slots (tls_amd/_lib.py names them)
 #ifndef TLS_KR
 #define TLS_KR 5
 #endif
@@ -1218,6 +1218,7 @@ tls_search_kernel(const SearchArgs a) {
                 __syncthreads();
             }
             p2_blocks = (M + (1 << a.p2_shift) - 1) >> a.p2_shift;
+            pc.mark(22);
             // (2) the bound of every live unit; each wave remembers its most promising one
             float cand_u = -INFINITY;
             int cand_k = 0x7fffffff, cand_unit = 0;
@@ -1230,12 +1231,21 @@ tls_search_kernel(const SearchArgs a) {
                 const double ov = widths_c[k].overshoot, k_mono = widths_c[k].k_mono, var_q = widths_c[k].var_q;
                 const int reach = tiled ? (kR - 1) * xth + d : d;   // samples covered by the windows of a unit
                 const int step = tiled ? kR * xth : xth;            // samples between two units
+                // kGroups groups of 64 entries per step: their list reads (HBM/L2 latency) and LDS
+                // reads are in flight together
+                constexpr int kGroups = 4;
 #pragma unroll 1
-                for (int base = 0; base < n_live; base += kWave) {
-                    const int idx = base + lane;
-                    if (idx < n_live) {
-                        const int unit = (int)chunk_list[list_base + idx];
-                        const int b = unit * step;
+                for (int base = 0; base < n_live; base += kGroups * kWave) {
+                    int unit[kGroups];
+#pragma unroll
+                    for (int j = 0; j < kGroups; ++j) {
+                        const int idx = base + j * kWave + lane;
+                        unit[j] = idx < n_live ? (int)chunk_list[list_base + idx] : 0;
+                    }
+                    float u[kGroups];
+#pragma unroll
+                    for (int j = 0; j < kGroups; ++j) {
+                        const int b = unit[j] * step;
                         double dC_min = c_base[b + d] - c_base[b], dC_max = dC_min;
                         if (tiled) {
 #pragma unroll
@@ -1244,16 +1254,22 @@ tls_search_kernel(const SearchArgs a) {
                                 dC_min = fmin(dC_min, dC); dC_max = fmax(dC_max, dC);
                             }
                         }
-                        float u = INFINITY;   // rows without a valid bound are always evaluated
-                        if (prunable) {
-                            u = cell_bound(dC_min, dC_max, dd, inv_d, ov, k_mono, var_q,
-                                           coarse_e2(P2, b, b + reach, a.p2_shift, p2_blocks));
-                            if (u > cand_u) { cand_u = u; cand_k = k; cand_unit = unit; }
+                        u[j] = INFINITY;   // rows without a valid bound are always evaluated
+                        if (prunable)
+                            u[j] = cell_bound(dC_min, dC_max, dd, inv_d, ov, k_mono, var_q,
+                                              coarse_e2(P2, b, b + reach, a.p2_shift, p2_blocks));
+                    }
+#pragma unroll
+                    for (int j = 0; j < kGroups; ++j) {
+                        const int idx = base + j * kWave + lane;
+                        if (idx < n_live) {
+                            if (prunable && u[j] > cand_u) { cand_u = u[j]; cand_k = k; cand_unit = unit[j]; }
+                            ulist[list_base + idx] = u[j];
                         }
-                        ulist[list_base + idx] = u;
                     }
                 }
             }
+            pc.mark(23);
             // (3) each wave evaluates its candidate exactly (lanes over the template taps)
 #pragma unroll
             for (int delta = kWave / 2; delta > 0; delta >>= 1) {
@@ -1312,6 +1328,7 @@ tls_search_kernel(const SearchArgs a) {
             double g = wbest[0].stat;
             for (int v = 1; v < nw; ++v) g = fmin(g, wbest[v].stat);
             T = lane_value(-g, 0);                     // uniform (scalar registers); -inf while nothing has been evaluated
+            pc.mark(24);
         }
         // Per row: (5) keep the units whose bound reaches T, then re-list SPARSE rows.  A handful of
         // live chunks would still occupy a whole 64-lane batch with kR FMAs per tap, so such rows
@@ -1330,15 +1347,25 @@ tls_search_kernel(const SearchArgs a) {
             if (bound_row && n_live > 0) {
                 // compaction in place: a 64-entry group is read before anything at or behind it is written
                 int n_sel = 0;
+                constexpr int kGroups = 4;   // reads of several groups in flight together
 #pragma unroll 1
-                for (int base = 0; base < n_live; base += kWave) {
-                    const int idx = base + lane;
-                    const bool valid = idx < n_live;
-                    const unsigned int unit = valid ? list[idx] : 0u;
-                    const bool sel = valid && (double)ulist[list_base + idx] >= T;
-                    const unsigned long long mask = __ballot(sel);
-                    if (sel) list[n_sel + __popcll(mask & ((1ull << lane) - 1ull))] = unit;
-                    n_sel += __popcll(mask);
+                for (int base = 0; base < n_live; base += kGroups * kWave) {
+                    unsigned int unit[kGroups];
+                    float u[kGroups];
+#pragma unroll
+                    for (int j = 0; j < kGroups; ++j) {
+                        const int idx = base + j * kWave + lane;
+                        const bool valid = idx < n_live;
+                        unit[j] = valid ? list[idx] : 0u;
+                        u[j] = valid ? ulist[list_base + idx] : -INFINITY;
+                    }
+#pragma unroll
+                    for (int j = 0; j < kGroups; ++j) {
+                        const bool sel = (double)u[j] >= T;   // invalid lanes hold -inf
+                        const unsigned long long mask = __ballot(sel);
+                        if (sel) list[n_sel + __popcll(mask & ((1ull << lane) - 1ull))] = unit[j];
+                        n_sel += __popcll(mask);
+                    }
                 }
                 n_live = n_sel;
                 __threadfence_block();   // the re-listing below reads entries other lanes have just moved
@@ -1368,6 +1395,7 @@ tls_search_kernel(const SearchArgs a) {
             }
             if (lane == 0) { rt.live[row] = (unsigned int)n_live; rt.singles[row] = count; }
         }
+        pc.mark(25);
         __syncthreads();
         if (wave == 0) {  // exclusive scan of the batch counts over the rows
             unsigned int carry = 0;
