@@ -754,13 +754,18 @@ template <bool IN_LDS, int XTH>
 __device__ __forceinline__ void dot_windows(const double* e, const_f64_ptr q, int L, double (&B)[kR]) {
     constexpr int S = (kR - 1) * XTH;
     for (int t0 = 0; t0 < L + S; t0 += kU) {
+        // the taps are requested BEFORE the folded samples: load_taps ends in a wait for both, so the
+        // scalar-cache latency (about 10 % of the tap loads miss it) overlaps the LDS latency
+        const const_f64_ptr qs = q + (t0 - S);  // qs[m] = q_ext[t0 - S + m]
+        double taps[kU + S];
+#pragma unroll
+        for (int m = 0; m < kU + S; ++m) taps[m] = qs[m];
         double x[kU];
         load_taps<IN_LDS>(e + t0, x);
-        const const_f64_ptr qs = q + (t0 - S);  // qs[m] = q_ext[t0 - S + m]
 #pragma unroll
         for (int u = 0; u < kU; ++u)
 #pragma unroll
-            for (int r = 0; r < kR; ++r) B[r] = fma(qs[u + S - r * XTH], x[u], B[r]);
+            for (int r = 0; r < kR; ++r) B[r] = fma(taps[u + S - r * XTH], x[u], B[r]);
     }
 }
 // the same with per-sample weights: B over e*w with taps q, A over w with taps q^2
@@ -769,18 +774,24 @@ __device__ __forceinline__ void dot_windows_weighted(const double* ew, const dou
                                                      const_f64_ptr q2, int L, double (&B)[kR], double (&A)[kR]) {
     constexpr int S = (kR - 1) * XTH;
     for (int t0 = 0; t0 < L + S; t0 += kU) {
-        double x[kU], z[kU];
-        load_taps<IN_LDS>(ew + t0, x);
-        load_taps<IN_LDS>(w + t0, z);
         const const_f64_ptr qs = q + (t0 - S);
         const const_f64_ptr ps = q2 + (t0 - S);
+        double taps[kU + S], x[kU];
+#pragma unroll
+        for (int m = 0; m < kU + S; ++m) taps[m] = qs[m];
+        load_taps<IN_LDS>(ew + t0, x);
 #pragma unroll
         for (int u = 0; u < kU; ++u)
 #pragma unroll
-            for (int r = 0; r < kR; ++r) {
-                B[r] = fma(qs[u + S - r * XTH], x[u], B[r]);
-                A[r] = fma(ps[u + S - r * XTH], z[u], A[r]);
-            }
+            for (int r = 0; r < kR; ++r) B[r] = fma(taps[u + S - r * XTH], x[u], B[r]);
+        // the taps of q^2 reuse the scalar registers
+#pragma unroll
+        for (int m = 0; m < kU + S; ++m) taps[m] = ps[m];
+        load_taps<IN_LDS>(w + t0, x);
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+            for (int r = 0; r < kR; ++r) A[r] = fma(taps[u + S - r * XTH], x[u], A[r]);
     }
 }
 
@@ -1497,14 +1508,16 @@ tls_search_kernel(const SearchArgs a) {
                     double B0 = 0, B1 = 0, A0 = 0, A1 = 0;
                     if constexpr (UNIFORM_W) {
                         for (int t0 = 0; t0 < L; t0 += kU) {
-                            double x[kU];
-                            load_taps<true>(e + t0, x);
                             const const_f64_ptr qs = q + t0;
+                            double taps[kU], x[kU];
+#pragma unroll
+                            for (int u = 0; u < kU; ++u) taps[u] = qs[u];   // requested before the samples
+                            load_taps<true>(e + t0, x);
                             // one accumulator, taps in order: the same rounding as the kR-window form, so a
                             // cell has ONE value whether its row runs tiled or re-listed (pruning moves rows
                             // between the two); the other waves of the SIMD hide the FMA latency
 #pragma unroll
-                            for (int u = 0; u < kU; ++u) B0 = fma(qs[u], x[u], B0);
+                            for (int u = 0; u < kU; ++u) B0 = fma(taps[u], x[u], B0);
                         }
                         A0 = sum_q2;
                     } else {
