@@ -166,6 +166,16 @@ def test_update_flux_equals_fresh_prepare(gpu):
     swapped = gpu.fetch()
     for x, y in zip(fresh[:3], swapped):
         numpy.testing.assert_array_equal(x, y)
+    # a much noisier light curve through the same plan: the host re-decides between the plain and
+    # the pruning kernel from the new noise level, results as from a fresh prepare
+    _, f2, _ = synthetic.config("k2_90d", seed=2, sigma=800e-6)
+    i2 = synthetic.search_inputs(t, f2, **kw)
+    fresh = gpu.search(i2["t"], i2["y"], i2["dy"], sel, i2["table"], i2["params"])
+    gpu.prepare(i0["t"], i0["y"], i0["dy"], sel, i0["table"], i0["params"])
+    gpu.update_flux(i2["y"], i2["dy"])
+    gpu.execute()
+    for x, y in zip(fresh[:3], gpu.fetch()):
+        numpy.testing.assert_array_equal(x, y)
 
 
 # ---- edge cases ---------------------------------------------------------------------------
