@@ -83,6 +83,17 @@ int tls_search(tls_ctx *ctx, const double *t, const double *y, const double *dy,
                const tls_params *params, double *out_chi2, int64_t *out_row,
                double *out_depth, tls_counters *counters);
 
+/* ---- survey mode: many light curves on the SAME time stamps, grids and template ---- */
+/* y and dy hold n_curves rows of n values (row-major); the outputs n_curves rows of n_periods.
+ * The plan is prepared once (tls_prepare with the first curve) and every further curve only
+ * replaces the flux and weights (tls_update_flux), exactly as the staged calls below would.
+ * All curves must have the same weight structure (all uniform dy or all per-point dy).
+ * Replaces one main.py:140-196 pass per light curve (BASELINE config 5). */
+int tls_search_batch(tls_ctx *ctx, const double *t, const double *y, const double *dy, int64_t n,
+                     int64_t n_curves, const double *periods, int64_t n_periods,
+                     const tls_template *tmpl, const tls_params *params, double *out_chi2,
+                     int64_t *out_row, double *out_depth);
+
 /* ---- staged search: same result, inputs resident in HBM between the stages ------ */
 /* prepare: validate, build the device-side work list, upload everything. */
 int tls_prepare(tls_ctx *ctx, const double *t, const double *y, const double *dy, int64_t n,

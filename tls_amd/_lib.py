@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libtls_amd.so")
 # every symbol include/tls_amd.h declares (tests check the export list against the header)
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
-    "tls_device_name", "tls_search", "tls_prepare", "tls_update_flux", "tls_execute",
+    "tls_device_name", "tls_search", "tls_search_batch", "tls_prepare", "tls_update_flux", "tls_execute",
     "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_t0_fit", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_barrier", "tls_comm_max",
@@ -73,6 +73,9 @@ def load():
     lib.tls_search.restype = ci
     lib.tls_search.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, _c_double_p, i64,
                                tp, pp, _c_double_p, _c_int64_p, _c_double_p, cp]
+    lib.tls_search_batch.restype = ci
+    lib.tls_search_batch.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, i64, _c_double_p, i64,
+                                     tp, pp, _c_double_p, _c_int64_p, _c_double_p]
     lib.tls_prepare.restype = ci
     lib.tls_prepare.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, _c_double_p, i64,
                                 tp, pp]
@@ -187,6 +190,25 @@ class Context(object):
         return self.fetch(with_counters=True)
 
     # -- staged
+    def search_batch(self, t, y_batch, dy_batch, periods, table, params):
+        """Survey mode: chi2, row, depth of shape [n_curves, n_periods] for light curves that share
+        t, the grids and the template table (tls_search_batch)."""
+        t, periods = _f8(t), _f8(periods)
+        y_batch = numpy.ascontiguousarray(y_batch, dtype=numpy.float64)
+        dy_batch = numpy.ascontiguousarray(dy_batch, dtype=numpy.float64)
+        if y_batch.ndim != 2 or y_batch.shape != dy_batch.shape or y_batch.shape[1] != len(t):
+            raise ValueError("y_batch and dy_batch must both have shape [n_curves, len(t)]")
+        arrays, tm, pr = self._pack(table, params)
+        n_c, n_p = y_batch.shape[0], len(periods)
+        chi2 = numpy.empty((n_c, n_p), dtype=numpy.float64)
+        row = numpy.empty((n_c, n_p), dtype=numpy.int64)
+        depth = numpy.empty((n_c, n_p), dtype=numpy.float64)
+        self._check(self._lib.tls_search_batch(self._h, _dp(t), _dp(y_batch), _dp(dy_batch), len(t), n_c,
+                                               _dp(periods), n_p, ctypes.byref(tm), ctypes.byref(pr),
+                                               _dp(chi2), _ip(row), _dp(depth)))
+        self._n_periods = n_p
+        return chi2, row, depth
+
     def prepare(self, t, y, dy, periods, table, params):
         t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)
         if not (t.ndim == y.ndim == dy.ndim == 1 and len(t) == len(y) == len(dy)):

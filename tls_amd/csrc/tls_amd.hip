@@ -760,6 +760,24 @@ int tls_search(tls_ctx* ctx, const double* t, const double* y, const double* dy,
     return tls_fetch(ctx, out_chi2, out_row, out_depth, counters);
 }
 
+int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n, int64_t n_curves,
+                     const double* periods, int64_t n_periods, const tls_template* tmpl, const tls_params* params,
+                     double* out_chi2, int64_t* out_row, double* out_depth) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (n_curves < 0) return fail(ctx, TLS_E_ARG, "negative number of light curves");
+    if (n_curves == 0) return TLS_OK;
+    if (!y || !dy || !out_chi2 || !out_row || !out_depth) return fail(ctx, TLS_E_ARG, "null argument");
+    int rc = tls_prepare(ctx, t, y, dy, n, periods, n_periods, tmpl, params);
+    if (rc) return rc;
+    for (int64_t c = 0; c < n_curves; ++c) {
+        if (c > 0 && (rc = tls_update_flux(ctx, y + c * n, dy + c * n))) return rc;
+        if ((rc = tls_execute(ctx, 0))) return rc;
+        if ((rc = tls_fetch(ctx, out_chi2 + c * n_periods, out_row + c * n_periods, out_depth + c * n_periods, nullptr)))
+            return rc;
+    }
+    return TLS_OK;
+}
+
 int tls_grid_cells(const double* t, int64_t n, const double* periods, int64_t n_periods, const tls_template* tmpl,
                    const tls_params* params, int64_t* cells_per_period) {
     if (!t || !periods || !cells_per_period || n < 3 || n_periods < 0) {

@@ -1,7 +1,7 @@
 """Survey mode (BASELINE config 5): many light curves on the SAME time stamps, grids and
-template searched back to back on one GPU.  The plan (period list, duration windows, template
-rows, work queue order) is prepared once; per light curve only the flux (and weights) are
-re-uploaded (`tls_update_flux`) before the search kernel runs again.
+template searched back to back on one GPU by ONE C-ABI call (`tls_search_batch`).  The plan (period
+list, duration windows, template rows, work queue order) is prepared once; per light curve only
+the flux (and weights) are re-uploaded before the search kernel runs again.
 
 Across GPUs the light curves are simply dealt to the ranks (one process per GPU); see bench.py.
 """
@@ -27,19 +27,16 @@ def search_batch(t, flux_batch, dy_batch=None, context=None, device=None, **powe
     inp = synthetic.search_inputs(t, flux_batch[0], first_dy, **power_kwargs)
     if len(inp["t"]) != len(t):
         raise ValueError("light curves must be cleaned before a batched search")
-    ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
-    n_p = len(inp["periods"])
-    chi2 = numpy.empty((len(flux_batch), n_p))
-    row = numpy.empty((len(flux_batch), n_p), dtype=numpy.int64)
-    depth = numpy.empty((len(flux_batch), n_p))
-    for k, flux in enumerate(flux_batch):
-        if k > 0:
-            if dy_batch is None:
-                dy = numpy.full(len(flux), numpy.std(flux))          # validate.py:39-40
-            else:
-                dy = numpy.asarray(dy_batch[k], dtype=numpy.float64)
-                dy = dy / numpy.mean(dy)                             # validate.py:18
-            ctx.update_flux(flux, dy)
-        ctx.execute()
-        chi2[k], row[k], depth[k] = ctx.fetch()
+    # dy exactly as validate.py would hand it to every single search (validate.py:18,39-40)
+    dy_rows = numpy.empty_like(flux_batch)
+    dy_rows[0] = inp["dy"]
+    for k in range(1, len(flux_batch)):
+        if dy_batch is None:
+            dy_rows[k] = numpy.std(flux_batch[k])
+        else:
+            dy = numpy.asarray(dy_batch[k], dtype=numpy.float64)
+            dy_rows[k] = dy / numpy.mean(dy)
+    y_rows = flux_batch.copy()
+    y_rows[0] = inp["y"]
+    chi2, row, depth = ctx.search_batch(inp["t"], y_rows, dy_rows, inp["periods"], inp["table"], inp["params"])
     return inp["periods"], chi2, row, depth
