@@ -370,6 +370,32 @@ def test_survey_batch_equals_individual_searches(gpu):
     assert int(numpy.argmin(chi2[0])) == 7738
 
 
+@pytest.mark.parametrize("name,n_curves,stride,per_point", [("k2_90d", 35, 40, False), ("k2_90d", 5, 40, True),
+                                                             ("tess_27d", 3, 100, False), ("tess_27d", 2, 100, True)])
+def test_search_batch_groups_weights_and_tiled_layout(gpu, name, n_curves, stride, per_point):
+    """tls_search_batch shares the fold + sort of a period between the curves of a launch group:
+    more curves than one group holds, per-point weights, and the HBM-slab layout all return what a
+    search per light curve returns, bit for bit."""
+    t, f0, kw = synthetic.config(name, seed=0)
+    rng = numpy.random.RandomState(5)
+    inputs = []
+    for s in range(n_curves):
+        f = synthetic.config(name, seed=s, sigma=synthetic.CONFIGS[name][2] * (1 + s % 3))[1]
+        dy = rng.uniform(0.6, 1.7, len(f)) * synthetic.CONFIGS[name][2] if per_point else None
+        inputs.append(synthetic.search_inputs(t, f, dy, **kw))
+    first = inputs[0]
+    sel = first["periods"][::stride]
+    y = numpy.stack([i["y"] for i in inputs])
+    dy = numpy.stack([i["dy"] for i in inputs])
+    chi2, row, depth = gpu.search_batch(first["t"], y, dy, sel, first["table"], first["params"])
+    assert chi2.shape == (n_curves, len(sel))
+    for k in sorted({0, 1, n_curves // 2, n_curves - 1}):
+        one = gpu.search(first["t"], inputs[k]["y"], inputs[k]["dy"], sel, first["table"], first["params"])
+        numpy.testing.assert_array_equal(chi2[k], one[0])
+        numpy.testing.assert_array_equal(row[k], one[1])
+        numpy.testing.assert_array_equal(depth[k], one[2])
+
+
 # TLS_FUZZ_SEEDS="100-140" (or "5,6,7") adds seeds for a one-off longer sweep
 def _extra_seeds():
     spec = os.environ.get("TLS_FUZZ_SEEDS", "")

@@ -80,7 +80,9 @@ struct tls_ctx {
     DevBuf<tlsdev::PeriodRows> d_rows;
     DevBuf<tlsdev::WidthEntry> d_widths;
     DevBuf<unsigned long long> d_counters, d_phase;
-    DevBuf<unsigned int> d_queue, d_lists;
+    DevBuf<unsigned int> d_queue, d_lists, d_perm;
+    DevBuf<double> d_curve_S0, d_curve_w0;   // survey batches
+    int batch_curves = 1;                    // light curves the next launch searches (tls_search_batch)
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
     size_t list_stride = 0;
     int hdr_bytes = 0, tile_len = 0, tile_halo = 0, region_pad = 0, p2_shift = 4;
@@ -305,6 +307,8 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     a.chunk_lists = ctx->d_lists.ptr; a.list_stride = 2 * (long long)ctx->list_stride; a.list_cap = (long long)ctx->list_stride;
     a.prune_min_live = ctx->prune_min_live; a.p2_shift = ctx->p2_shift; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
+    a.n_curves = ctx->batch_curves; a.curve_S0 = ctx->d_curve_S0.ptr; a.curve_w0 = ctx->d_curve_w0.ptr;
+    a.perm_scratch = ctx->d_perm.ptr;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
     hipError_t e;
@@ -386,7 +390,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_chi2.release(); ctx->d_depth.release(); ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_row.release(); ctx->d_order.release();
     ctx->d_rows.release(); ctx->d_widths.release(); ctx->d_counters.release();
-    ctx->d_queue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release();
+    ctx->d_queue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     for (auto& evp : ctx->ev_pool) { (void)hipEventDestroy(evp.first); (void)hipEventDestroy(evp.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -767,14 +771,50 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
     if (n_curves < 0) return fail(ctx, TLS_E_ARG, "negative number of light curves");
     if (n_curves == 0) return TLS_OK;
     if (!y || !dy || !out_chi2 || !out_row || !out_depth) return fail(ctx, TLS_E_ARG, "null argument");
-    int rc = tls_prepare(ctx, t, y, dy, n, periods, n_periods, tmpl, params);
+    int rc = tls_prepare(ctx, t, y, dy, n, periods, n_periods, tmpl, params);   // the plan, from the first curve
     if (rc) return rc;
-    for (int64_t c = 0; c < n_curves; ++c) {
-        if (c > 0 && (rc = tls_update_flux(ctx, y + c * n, dy + c * n))) return rc;
-        if ((rc = tls_execute(ctx, 0))) return rc;
-        if ((rc = tls_fetch(ctx, out_chi2 + c * n_periods, out_row + c * n_periods, out_depth + c * n_periods, nullptr)))
-            return rc;
+    if (n_periods == 0) return TLS_OK;
+    // Curves go to the device in groups: ONE launch searches a whole group, and inside the kernel
+    // the fold + sort of a period is done once for all curves of the group (it depends on t only).
+    const int64_t group = 32;
+    const size_t np = (size_t)n_periods, nn = (size_t)n;
+    std::vector<double> w, w_all, S0s, w0s;
+    for (int64_t c0 = 0; c0 < n_curves; c0 += group) {
+        const int64_t gc = std::min(group, n_curves - c0);
+        S0s.assign((size_t)gc, 0.0); w0s.assign((size_t)gc, 1.0);
+        if (!ctx->uniform_w) w_all.resize((size_t)gc * nn);
+        double sigma_sum = 0.0;
+        for (int64_t c = 0; c < gc; ++c) {
+            bool uniform; double w0, S0;
+            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0);
+            if (uniform != ctx->uniform_w)
+                return fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy");
+            S0s[(size_t)c] = S0; w0s[(size_t)c] = w0;
+            if (!uniform) std::copy(w.begin(), w.end(), w_all.begin() + (size_t)c * nn);
+            sigma_sum += dy[(c0 + c) * n];
+        }
+        if ((rc = upload(ctx, ctx->d_y, y + c0 * n, (size_t)gc * nn))) return rc;
+        if (!ctx->uniform_w && (rc = upload(ctx, ctx->d_w, w_all.data(), (size_t)gc * nn))) return rc;
+        if ((rc = upload(ctx, ctx->d_curve_S0, S0s.data(), (size_t)gc))) return rc;
+        if ((rc = upload(ctx, ctx->d_curve_w0, w0s.data(), (size_t)gc))) return rc;
+        TLS_HIP(ctx, ctx->d_chi2.reserve((size_t)gc * np));
+        TLS_HIP(ctx, ctx->d_row.reserve((size_t)gc * np));
+        TLS_HIP(ctx, ctx->d_depth.reserve((size_t)gc * np));
+        TLS_HIP(ctx, ctx->d_perm.reserve((size_t)ctx->blocks * nn));
+        ctx->S0 = S0s[0]; ctx->w0 = w0s[0];
+        ctx->prune_kernel = ctx->uniform_w && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident);
+        ctx->batch_curves = (int)gc;
+        rc = enqueue(ctx, false);
+        ctx->batch_curves = 1;
+        if (rc) return rc;
+        TLS_HIP(ctx, hipMemcpyAsync(out_chi2 + c0 * n_periods, ctx->d_chi2.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(out_row + c0 * n_periods, ctx->d_row.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(out_depth + c0 * n_periods, ctx->d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors above are reused by the next group
     }
+    // the context keeps the plan, but its device buffers now hold a group of curves: a staged
+    // execute must be preceded by tls_update_flux or a new tls_prepare
+    ctx->executed = false;
     return TLS_OK;
 }
 

@@ -179,6 +179,11 @@ struct SearchArgs {
     unsigned int* chunk_lists;  // per-workgroup lists of live chunks (phase 3a -> 3b)
     long long scratch_stride;   // doubles per slab
     long long list_stride;      // entries per workgroup
+    // survey mode: n_curves light curves on the same time stamps share the fold + sort of a period
+    int n_curves;               // >= 1; curve c reads y + c*n (w + c*n), writes out_* + c*n_periods
+    const double* curve_S0;     // [n_curves] S0 per curve (n_curves > 1; else S0 / w0 below)
+    const double* curve_w0;     // [n_curves]
+    unsigned int* perm_scratch; // [blocks][n] the sort permutation of the period in flight (n_curves > 1)
     long long list_cap;         // entries of one array: live units | their bounds (float)
     long long prune_min_live;   // prune a period (tile) only when at least this many units are live
     int p2_shift;               // log2 of the block length of the coarse prefix sum of e^2 (pruning bound)
@@ -974,11 +979,22 @@ tls_search_kernel(const SearchArgs a) {
 
         // ---- phase 1: fold + stable sort by phase ----------------------------------
         fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc);
+        // survey mode: the permutation depends on (t, period) only, so every light curve of the
+        // batch reuses it; it must outlive the prefix sum that overwrites its LDS home
+        const IdxT* perm_use = perm;
+        if (a.n_curves > 1) {
+            IdxT* perm_g = reinterpret_cast<IdxT*>(a.perm_scratch + (long long)blockIdx.x * n);
+            for (int k = tid; k < n; k += nt) perm_g[k] = perm[k];
+            perm_use = perm_g;
+            __syncthreads();
+        }
+        for (int curve = 0; curve < a.n_curves; ++curve) {
+        const double* y_c = a.y + (long long)curve * n;
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on
         for (int k = tid; k < n; k += nt) {
-            const int i = (int)perm[k];
-            regA[k] = a.y[i];
-            if constexpr (!UNIFORM_W) regW[k] = a.w[i];
+            const int i = (int)perm_use[k];
+            regA[k] = y_c[i];
+            if constexpr (!UNIFORM_W) regW[k] = a.w[(long long)curve * n + i];
         }
         __syncthreads();
         // ---- phase 2: patch (core.py:126-132) and sequential cumsum ----------------
@@ -1559,8 +1575,10 @@ tls_search_kernel(const SearchArgs a) {
             long long row = 0;
             if (n_rows > 0) {
                 // uniform weights: A,B were accumulated without the common factor w0
-                const double scale = UNIFORM_W ? a.w0 : 1.0;
-                const double stat = (g.stat < INFINITY) ? a.S0 + scale * g.stat : INFINITY;
+                const double w0_c = a.n_curves > 1 ? a.curve_w0[curve] : a.w0;
+                const double S0_c = a.n_curves > 1 ? a.curve_S0[curve] : a.S0;
+                const double scale = UNIFORM_W ? w0_c : 1.0;
+                const double stat = (g.stat < INFINITY) ? S0_c + scale * g.stat : INFINITY;
                 if (stat < datapoints) {
                     chi2 = stat; row = a.widths[g.k].row; depth = 1.0 - g.td;  // core.py:72-74
                 } else {
@@ -1569,9 +1587,10 @@ tls_search_kernel(const SearchArgs a) {
                     chi2 = datapoints; row = a.widths[k_lo].row; depth = 0.0;
                 }
             }
-            a.out_chi2[p] = chi2;
-            a.out_row[p] = row;
-            a.out_depth[p] = depth;
+            const long long o = (long long)curve * a.n_periods + p;
+            a.out_chi2[o] = chi2;
+            a.out_row[o] = row;
+            a.out_depth[o] = depth;
         }
         if (a.counters) {
 #pragma unroll
@@ -1585,6 +1604,7 @@ tls_search_kernel(const SearchArgs a) {
             }
         }
         __syncthreads();
+        }  // light curves of the batch
     }
 }
 
