@@ -42,8 +42,15 @@
 // consecutive chunks), and the template value is wave-uniform, fetched with scalar loads into
 // SGPRs (the template table is read through the constant address space).  That puts the loop
 // on the fp64 FMA pipe instead of the LDS pipe.  Long durations search a strided T0 grid
-// (core.py:50-58): strides 2..5 use the same 5-window form with the windows that far apart;
-// rows left with a handful of live chunks are re-listed and evaluated one window per lane.
+// (core.py:50-58): strides 2..5 use the same 5-window form with the windows that far apart,
+// larger strides a runtime-stride form with one scalar tap stream per window; rows left with a
+// handful of live chunks are re-listed and evaluated one window per lane.
+//
+// Variants (template parameters): RESIDENT / tiled series, UNIFORM_W / per-point weights, STAGE_C
+// (tiled: prefix sum staged into LDS or read from the slab), WITH_PRUNING (noisy light curves: an
+// exact branch-and-bound step drops the cells that cannot win before phase 3b, see cell_bound).
+// Survey batches (SearchArgs::n_curves > 1): the fold + sort of a period is shared by all light
+// curves of the launch; phases 2-4 run per curve.
 //
 // No MFMA: the contraction is a sliding window with a per-cell scalar, not a GEMM.
 #pragma once
