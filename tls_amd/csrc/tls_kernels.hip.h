@@ -339,17 +339,58 @@ __device__ __forceinline__ double binade_value(long long S, int m) {
 constexpr int kCumsumChunk = 8192;  // non-resident variant: elements scanned per LDS round trip
 constexpr int kMaxSeg = 32;   // binade changes handled per block by the one-pass variant
 constexpr int kPerMax = 16;   // elements per thread and block in the one-pass variant
+// The one-pass variant keeps the same parity maps in fp64.  In the binade [2^m, 2^(m+1)) let
+// c0 = 2^m (even mantissa) and c1 = c0 + ulp (odd).  The hardware rounds c0 + f and c1 + f on the
+// same grid, with the same tie rule, as it rounds S + f for any even / odd S of that binade, so
+//     i0 = (c0 + f) - c0,   i1 = (c1 + f) - c1
+// ARE the two increments (exact multiples of the ulp) -- four flops instead of forty integer
+// instructions; the parity of a partial sum is bit 0 of c0 + increment.  A value >= 2^m marks a
+// step that cannot stay inside the binade from any start ("saturated"); sums of steps are exact
+// below 2^(m+1) and stay >= 2^m once they got there, so the verification in phase D sees them.
+struct StepD {
+    double i0, i1;
+};
+struct BinadeD {              // constants of one binade
+    double c0, c1, lim, sat;  // 2^m, 2^m + ulp, 2^m (largest valid increment is below), 2^(m+1)
+};
+__device__ __forceinline__ BinadeD binade_constants(int m) {   // m in [-1022, 1023]
+    BinadeD b;
+    const long long bits = (long long)(m + 1023) << 52;
+    b.c0 = __longlong_as_double(bits);
+    b.c1 = __longlong_as_double(bits + 1);
+    b.lim = b.c0;
+    b.sat = m < 1023 ? __longlong_as_double((long long)(m + 1024) << 52) : INFINITY;
+    return b;
+}
+__device__ __forceinline__ StepD step_of(double f, const BinadeD& b) {
+    StepD t;
+    if (!(f < b.lim)) { t.i0 = b.sat; t.i1 = b.sat; return t; }
+    t.i0 = (b.c0 + f) - b.c0;
+    t.i1 = (b.c1 + f) - b.c1;
+    return t;
+}
+__device__ __forceinline__ int mantissa_bit0(double x) { return (int)(__double_as_longlong(x) & 1LL); }
+// x, then y (both steps of the binade b); the result saturates
+__device__ __forceinline__ StepD compose(const StepD& x, const StepD& y, const BinadeD& b) {
+    const double s0 = x.i0 + (mantissa_bit0(b.c0 + x.i0) ? y.i1 : y.i0);
+    const double s1 = x.i1 + (mantissa_bit0(b.c0 + x.i1) ? y.i0 : y.i1);   // odd start: parity flipped
+    StepD z;
+    z.i0 = s0 < b.lim ? s0 : b.sat;
+    z.i1 = s1 < b.lim ? s1 : b.sat;
+    return z;
+}
+
 struct SegAcc {               // scan element of the one-pass variant
-    ParityInc map;            // composite step since the last binade change (or since the start)
+    StepD map;                // composite step since the last binade change (or since the start)
     int cnt;                  // binade changes so far
     int reset;                // 1 if a binade change lies inside
 };
 struct CumsumScratch {
     ParityInc wave_tot[kMaxWaves];
     SegAcc seg_tot[kMaxWaves];
-    ParityInc tab_T[kMaxSeg];       // composite step of the segment behind binade change j
-    long long tab_S[kMaxSeg];       // integer mantissa the segment starts from
-    double dtot[kMaxWaves];
+    StepD tab_T[kMaxSeg];           // composite step of the segment behind binade change j
+    double tab_S[kMaxSeg];          // running sum the segment starts from
+    double dtot[kMaxWaves];         // phase A: wave totals; afterwards (as int) the binade each wave ends in
     double state_s;                 // running sum at state_k
     double fail_s;
     int tab_c[kMaxSeg + 1];         // element index of binade change j
@@ -456,11 +497,12 @@ __device__ __forceinline__ void sequential_cumsum_by_binade(const double* f, dou
     }
 }
 
-__device__ __forceinline__ SegAcc seg_combine(const SegAcc& x, const SegAcc& y) {  // x, then y
+// x, then y; `b` is the binade y's elements live in (only used when y holds no binade change)
+__device__ __forceinline__ SegAcc seg_combine(const SegAcc& x, const SegAcc& y, const BinadeD& b) {
     SegAcc z;
     z.cnt = x.cnt + y.cnt;
     z.reset = x.reset | y.reset;
-    z.map = y.reset ? y.map : compose(x.map, y.map);
+    z.map = y.reset ? y.map : compose(x.map, y.map, b);
     return z;
 }
 
@@ -491,7 +533,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
         const int lo = k0 + tid * per < kb ? k0 + tid * per : kb;
         const int hi = lo + per < kb ? lo + per : kb;
         // ---- A: re-associated prefix sum P[k] (sum before element k) into C[k0..kb] ----
-        if (tid < kMaxSeg) { cs->tab_T[tid].i0 = 0; cs->tab_T[tid].i1 = 0; }
+        if (tid < kMaxSeg) { cs->tab_T[tid].i0 = 0.0; cs->tab_T[tid].i1 = 0.0; }
         double local = 0.0;
         for (int k = lo; k < hi; ++k) local += f[k];
         double incl = local;
@@ -515,7 +557,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
         unsigned int crossmask = 0;   // bit e: element lo+e changes the binade (or opens the block)
         int m_lo = 0;
         {
-            int m_k = lo < hi ? unbiased_exponent(C[lo], nullptr) : 0;
+            int m_k = unbiased_exponent(C[lo], nullptr);   // lo == kb for the idle threads behind the block
             m_lo = m_k;
             for (int k = lo; k < hi; ++k) {
                 const int m_next = unbiased_exponent(C[k + 1], nullptr);
@@ -538,22 +580,26 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
         cpc.mark(15);
         // ---- B2: one walk over the elements: step maps, tables of the binade changes ----
         SegAcc acc; acc.cnt = n_cross_local; acc.reset = n_cross_local > 0;
-        ParityInc head; head.i0 = 0; head.i1 = 0;   // composite in front of the first change in my slice
+        StepD head; head.i0 = 0.0; head.i1 = 0.0;   // composite in front of the first change in my slice
+        const BinadeD b_lo = binade_constants(m_lo);  // the binade my slice starts in
+        int m_hi = m_lo;                              // ... and the one it ends in
         {
-            ParityInc seg; seg.i0 = 0; seg.i1 = 0;  // composite since the last change (or since lo)
-            int j = cnt_pre - 1, m_k = m_lo;
+            StepD seg; seg.i0 = 0.0; seg.i1 = 0.0;    // composite since the last change (or since lo)
+            int j = cnt_pre - 1;
+            BinadeD bk = b_lo;
             bool first = true;
             for (int k = lo; k < hi; ++k) {
                 if ((crossmask >> (k - lo)) & 1u) {
                     if (first) { head = seg; first = false; }
                     else if (j >= 0 && j < kMaxSeg) cs->tab_T[j] = seg;  // a segment inside my slice
                     ++j;
-                    m_k = unbiased_exponent(C[k + 1], nullptr);
+                    m_hi = unbiased_exponent(C[k + 1], nullptr);
+                    bk = binade_constants(m_hi);
                     if (j <= kMaxSeg) cs->tab_c[j] = k;
-                    if (j < kMaxSeg) cs->tab_m[j] = m_k;
-                    seg.i0 = 0; seg.i1 = 0;
+                    if (j < kMaxSeg) cs->tab_m[j] = m_hi;
+                    seg.i0 = 0.0; seg.i1 = 0.0;
                 } else {
-                    seg = compose_local(seg, addend_step(f[k], m_k));
+                    seg = compose(seg, step_of(f[k], bk), bk);
                 }
             }
             if (first) head = seg;
@@ -561,6 +607,8 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
         }
         cpc.mark(16);
         SegAcc inc = acc;
+        // a lane's accumulated range holds no binade change <=> all of it lies in the binade its own
+        // slice starts in, and so does the tail of whatever is composed in front of it
 #pragma unroll
         for (int dlt = 1; dlt < kWave; dlt <<= 1) {
             SegAcc o;
@@ -568,38 +616,38 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             o.map.i1 = __shfl_up(inc.map.i1, dlt, kWave);
             o.cnt = __shfl_up(inc.cnt, dlt, kWave);
             o.reset = __shfl_up(inc.reset, dlt, kWave);
-            if (lane >= dlt) inc = seg_combine(o, inc);
+            if (lane >= dlt) inc = seg_combine(o, inc, b_lo);
         }
-        if (lane == kWave - 1) cs->seg_tot[wave] = inc;
+        int* const wave_end_m = reinterpret_cast<int*>(cs->dtot);   // dtot is idle since the end of phase A
+        if (lane == kWave - 1) { cs->seg_tot[wave] = inc; wave_end_m[wave] = m_hi; }
         __syncthreads();
-        SegAcc pre; pre.map.i0 = 0; pre.map.i1 = 0; pre.cnt = 0; pre.reset = 0;
-        for (int v = 0; v < wave; ++v) pre = seg_combine(pre, cs->seg_tot[v]);
+        SegAcc pre; pre.map.i0 = 0.0; pre.map.i1 = 0.0; pre.cnt = 0; pre.reset = 0;
+        for (int v = 0; v < wave; ++v) pre = seg_combine(pre, cs->seg_tot[v], binade_constants(wave_end_m[v]));
         {
             SegAcc ex;
             ex.map.i0 = __shfl_up(inc.map.i0, 1, kWave);
             ex.map.i1 = __shfl_up(inc.map.i1, 1, kWave);
             ex.cnt = __shfl_up(inc.cnt, 1, kWave);
             ex.reset = __shfl_up(inc.reset, 1, kWave);
-            if (lane == 0) { ex.map.i0 = 0; ex.map.i1 = 0; ex.cnt = 0; ex.reset = 0; }
-            pre = seg_combine(pre, ex);
+            if (lane == 0) { ex.map.i0 = 0.0; ex.map.i1 = 0.0; ex.cnt = 0; ex.reset = 0; }
+            pre = seg_combine(pre, ex, b_lo);   // ex ends where my slice starts
         }
         // segments that reach into my slice from the left, and the last one of the block
         if (lo < hi) {
             const int j_in = cnt_pre - 1;
             if (n_cross_local > 0) {
-                if (j_in >= 0 && j_in < kMaxSeg) cs->tab_T[j_in] = compose(pre.map, head);
+                if (j_in >= 0 && j_in < kMaxSeg) cs->tab_T[j_in] = compose(pre.map, head, b_lo);
                 if (hi == kb) { const int j = cnt_pre + n_cross_local - 1; if (j < kMaxSeg) cs->tab_T[j] = acc.map; }
             } else if (hi == kb && j_in >= 0 && j_in < kMaxSeg) {
-                cs->tab_T[j_in] = compose(pre.map, head);
+                cs->tab_T[j_in] = compose(pre.map, head, b_lo);
             }
         }
         __syncthreads();
         cpc.mark(17);
         // ---- D: wave 0 chains the binade changes in fp64 and verifies the prediction ----
-        // Inside a verified binade the whole segment behind change j adds the INTEGER t_j (chosen
-        // by the parity of the start mantissa) times the ulp, and S0 + t_j < 2^53 makes that
-        // one exact fp64 addition: the chain is two additions per change, everything else is
-        // prepared per lane in parallel.
+        // Inside a verified binade the whole segment behind change j adds the step t_j (chosen by the
+        // parity of the start mantissa), and staying below 2^(m+1) makes that one exact fp64
+        // addition: the chain is two additions per change.
         if (wave == 0) {
             const int n_proc = n_seg < kMaxSeg ? n_seg : kMaxSeg;
             // lane j holds change j: its element, addend, predicted binade and segment step
@@ -607,12 +655,10 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             double my_f = 0.0, my_t0 = 0.0, my_t1 = 0.0, my_lim = 0.0;
             if (lane < n_proc) {
                 my_c = cs->tab_c[lane]; my_m = cs->tab_m[lane]; my_f = f[my_c];
-                const ParityInc T = cs->tab_T[lane];
-                // t * 2^(m-52): exact while t < 2^53; a larger t only has to push the sum out of
-                // the binade, which it does after any rounding
-                my_t0 = ldexp((double)T.i0, my_m - 52);
-                my_t1 = ldexp((double)T.i1, my_m - 52);
-                my_lim = ldexp(1.0, my_m + 1);
+                // a saturated step (>= 2^m) pushes any sum of the binade to 2^(m+1) or beyond
+                my_t0 = cs->tab_T[lane].i0;
+                my_t1 = cs->tab_T[lane].i1;
+                my_lim = binade_constants(my_m).sat;
             }
             double s_end = s0;
             int ok = 0, fail_k = kb;
@@ -636,7 +682,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             const int n_written = ok >= 0 ? ok : -ok;
             if (ok < 0) ok = -ok - 1;
             if (lane < n_written) C[my_c + 1] = my_f;
-            if (lane < ok) { long long S0; unbiased_exponent(my_f, &S0); cs->tab_S[lane] = S0; }
+            if (lane < ok) cs->tab_S[lane] = my_f;
             if (lane == 0) { cs->n_ok = ok; cs->fail_k = fail_k; cs->fail_s = fail_s; }
         }
         __syncthreads();
@@ -645,21 +691,21 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
         {
             const int n_ok = cs->n_ok;
             int j = cnt_pre - 1;
-            long long S = 0;
-            int m_k = m_lo;
+            double S = 0.0;
+            BinadeD bk = b_lo;
             if (j >= 0 && j < n_ok) {
-                const long long S0 = cs->tab_S[j];
-                S = S0 + ((S0 & 1) ? pre.map.i1 : pre.map.i0);
-                m_k = cs->tab_m[j];
+                const double S0 = cs->tab_S[j];
+                S = S0 + (mantissa_bit0(S0) ? pre.map.i1 : pre.map.i0);
+                bk = binade_constants(cs->tab_m[j]);
             }
             for (int k = lo; k < hi; ++k) {
                 if ((crossmask >> (k - lo)) & 1u) {
                     ++j;
-                    if (j < n_ok) { S = cs->tab_S[j]; m_k = cs->tab_m[j]; }
+                    if (j < n_ok) { S = cs->tab_S[j]; bk = binade_constants(cs->tab_m[j]); }
                 } else if (j < n_ok) {
-                    const ParityInc t = addend_step(f[k], m_k);
-                    S += (S & 1) ? t.i1 : t.i0;
-                    C[k + 1] = binade_value(S, m_k);
+                    const StepD t = step_of(f[k], bk);
+                    S += mantissa_bit0(S) ? t.i1 : t.i0;
+                    C[k + 1] = S;
                 }
             }
         }
