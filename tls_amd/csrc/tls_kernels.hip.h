@@ -660,29 +660,41 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
                 my_t1 = cs->tab_T[lane].i1;
                 my_lim = binade_constants(my_m).sat;
             }
+            // The chain itself is two additions and a parity select per change; every lane runs it
+            // (uniform values), lane j keeps the three values of step j, and the checks happen
+            // afterwards, all steps at once.
             double s_end = s0;
-            int ok = 0, fail_k = kb;
-            double fail_s = 0.0;
-            bool failed = false;
+            double keep_prev = 0.0, keep_new = 0.0, keep_end = 0.0;
             for (int j = 0; j < n_proc; ++j) {
                 const double s_new = s_end + lane_value(my_f, j);  // the sequential step itself
-                const long long sb = __double_as_longlong(s_new);
-                const int es = (int)((sb >> 52) & 0x7ff);
-                const int m = es ? es - 1023 : -1022;
-                if (m != lane_value(my_m, j)) { failed = true; fail_k = lane_value(my_c, j); fail_s = s_end; break; }
-                if (lane == j) my_f = s_new;  // keep C[c+1]
-                s_end = s_new + ((sb & 1) ? lane_value(my_t1, j) : lane_value(my_t0, j));
-                if (!(s_end < lane_value(my_lim, j))) {
-                    failed = true; fail_k = lane_value(my_c, j) + 1; fail_s = s_new; ok = -(j + 1); break;
-                }
-                ok = j + 1;
+                const double t = mantissa_bit0(s_new) ? lane_value(my_t1, j) : lane_value(my_t0, j);
+                const double s_nxt = s_new + t;
+                if (lane == j) { keep_prev = s_end; keep_new = s_new; keep_end = s_nxt; }
+                s_end = s_nxt;
             }
-            if (!failed && n_seg > n_proc) { fail_k = cs->tab_c[n_proc]; fail_s = s_end; }
+            // verification: the predicted binade of every segment start, the segment staying inside it
+            bool bad_exp = false, bad_lim = false;
+            if (lane < n_proc) {
+                const long long sb = __double_as_longlong(keep_new);
+                const int es = (int)((sb >> 52) & 0x7ff);
+                bad_exp = (es ? es - 1023 : -1022) != my_m;
+                bad_lim = !(keep_end < my_lim);
+            }
+            const unsigned long long bad = __ballot(bad_exp || bad_lim);
+            int ok = n_proc, n_written = n_proc, fail_k = kb;
+            double fail_s = 0.0;
+            if (bad) {
+                const int jf = __ffsll((long long)bad) - 1;   // everything behind the first failure is void
+                const bool exp_failed = (__ballot(bad_exp) >> jf) & 1ull;
+                ok = jf;
+                if (exp_failed) { n_written = jf; fail_k = lane_value(my_c, jf); fail_s = lane_value(keep_prev, jf); }
+                else { n_written = jf + 1; fail_k = lane_value(my_c, jf) + 1; fail_s = lane_value(keep_new, jf); }
+            } else if (n_seg > n_proc) {
+                fail_k = cs->tab_c[n_proc]; fail_s = s_end;
+            }
             // a change whose own step verified still gets its C value, even if its segment failed
-            const int n_written = ok >= 0 ? ok : -ok;
-            if (ok < 0) ok = -ok - 1;
-            if (lane < n_written) C[my_c + 1] = my_f;
-            if (lane < ok) cs->tab_S[lane] = my_f;
+            if (lane < n_written) C[my_c + 1] = keep_new;
+            if (lane < ok) cs->tab_S[lane] = keep_new;
             if (lane == 0) { cs->n_ok = ok; cs->fail_k = fail_k; cs->fail_s = fail_s; }
         }
         __syncthreads();
