@@ -1055,11 +1055,25 @@ tls_search_kernel(const SearchArgs a) {
         }
         for (int curve = 0; curve < a.n_curves; ++curve) {
         const double* y_c = a.y + (long long)curve * n;
-        // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on
-        for (int k = tid; k < n; k += nt) {
-            const int i = (int)perm_use[k];
-            regA[k] = y_c[i];
-            if constexpr (!UNIFORM_W) regW[k] = a.w[(long long)curve * n + i];
+        // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  Three
+        // elements per step: their global reads (L2 latency) are in flight together -- the compiler
+        // cannot overlap them itself, the LDS store of one may alias the index read of the next
+        for (int k = tid; k < n; k += 3 * nt) {
+            const int k1 = k + nt, k2 = k + 2 * nt;
+            const int i0 = (int)perm_use[k];
+            const int i1 = k1 < n ? (int)perm_use[k1] : i0;
+            const int i2 = k2 < n ? (int)perm_use[k2] : i0;
+            const double v0 = y_c[i0], v1 = y_c[i1], v2 = y_c[i2];
+            if constexpr (!UNIFORM_W) {
+                const double* w_c = a.w + (long long)curve * n;
+                const double u0 = w_c[i0], u1 = w_c[i1], u2 = w_c[i2];
+                regW[k] = u0;
+                if (k1 < n) regW[k1] = u1;
+                if (k2 < n) regW[k2] = u2;
+            }
+            regA[k] = v0;
+            if (k1 < n) regA[k1] = v1;
+            if (k2 < n) regA[k2] = v2;
         }
         __syncthreads();
         // ---- phase 2: patch (core.py:126-132) and sequential cumsum ----------------
