@@ -245,6 +245,16 @@ bool pruning_pays(const std::vector<tlsdev::WidthEntry>& widths, double sigma, d
     return acc / (double)widths.size() >= 0.25;
 }
 
+// scatter of the flux itself: the noise estimate behind pruning_pays (a caller's dy may be in
+// arbitrary units -- validate.py:18 normalises it by its mean -- so it says nothing about the noise)
+double flux_scatter(const double* y, int64_t n) {
+    long double m = 0.0L, v = 0.0L;
+    for (int64_t i = 0; i < n; ++i) m += y[i];
+    m /= (long double)n;
+    for (int64_t i = 0; i < n; ++i) v += (y[i] - m) * (y[i] - m);
+    return (double)std::sqrt((double)(v / (long double)n));
+}
+
 // In-range width window of one period (core.py:143-156) and its trial-cell count.
 int64_t period_window(const std::vector<tlsdev::WidthEntry>& widths, const tls_params* params, double P,
                       double length, int64_t n, int64_t M, int& lo_out, int& hi_out, int64_t* pairs) {
@@ -532,7 +542,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->n_widths = (int)widths.size();
     ctx->uniform_w = uniform; ctx->w0 = w0; ctx->S0 = S0; ctx->depth_min = params->transit_depth_min;
     ctx->host_widths = widths;
-    ctx->prune_kernel = uniform && pruning_pays(widths, dy[0], params->transit_depth_min, ctx->resident);
+    ctx->prune_kernel = uniform && pruning_pays(widths, flux_scatter(y, n), params->transit_depth_min, ctx->resident);
     ctx->plan_counters = pc;
 
     int rc;
@@ -572,7 +582,7 @@ int tls_update_flux(tls_ctx* ctx, const double* y, const double* dy) {
     if (uniform != ctx->uniform_w)
         return fail(ctx, TLS_E_STATE, "weight structure (uniform / per-point dy) differs from the prepared search");
     ctx->w0 = w0; ctx->S0 = S0;
-    ctx->prune_kernel = uniform && pruning_pays(ctx->host_widths, dy[0], ctx->depth_min, ctx->resident);
+    ctx->prune_kernel = uniform && pruning_pays(ctx->host_widths, flux_scatter(y, ctx->n), ctx->depth_min, ctx->resident);
     int rc;
     if ((rc = upload(ctx, ctx->d_y, y, (size_t)ctx->n))) return rc;
     if (!uniform && (rc = upload(ctx, ctx->d_w, w.data(), (size_t)ctx->n))) return rc;
@@ -791,7 +801,7 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
                 return fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy");
             S0s[(size_t)c] = S0; w0s[(size_t)c] = w0;
             if (!uniform) std::copy(w.begin(), w.end(), w_all.begin() + (size_t)c * nn);
-            sigma_sum += dy[(c0 + c) * n];
+            sigma_sum += flux_scatter(y + (c0 + c) * n, n);
         }
         if ((rc = upload(ctx, ctx->d_y, y + c0 * n, (size_t)gc * nn))) return rc;
         if (!ctx->uniform_w && (rc = upload(ctx, ctx->d_w, w_all.data(), (size_t)gc * nn))) return rc;
