@@ -80,7 +80,7 @@ struct tls_ctx {
     DevBuf<tlsdev::PeriodRows> d_rows;
     DevBuf<tlsdev::WidthEntry> d_widths;
     DevBuf<unsigned long long> d_counters, d_phase;
-    DevBuf<unsigned int> d_queue, d_lists, d_perm;
+    DevBuf<unsigned int> d_queue, d_squeue, d_lists, d_perm;   // d_squeue: the search kernel's self-rewinding queue
     DevBuf<double> d_curve_S0, d_curve_w0;   // survey batches
     int batch_curves = 1;                    // light curves the next launch searches (tls_search_batch)
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
@@ -295,7 +295,6 @@ hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
 }
 
 int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
-    TLS_HIP(ctx, hipMemsetAsync(ctx->d_queue.ptr, 0, sizeof(unsigned int), ctx->stream));
     if (count_work)
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
     tlsdev::SearchArgs a;
@@ -310,7 +309,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_phase.ptr, 0, tlsdev::kPhases * sizeof(unsigned long long), ctx->stream));
         a.phase_cycles = ctx->d_phase.ptr;
     }
-    a.queue = ctx->d_queue.ptr;
+    a.queue = ctx->d_squeue.ptr;
     a.scratch = ctx->d_scratch.ptr;
     a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1 + ctx->region_pad);
     a.region_pad = ctx->region_pad;
@@ -400,7 +399,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_chi2.release(); ctx->d_depth.release(); ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_row.release(); ctx->d_order.release();
     ctx->d_rows.release(); ctx->d_widths.release(); ctx->d_counters.release();
-    ctx->d_queue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
+    ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     for (auto& evp : ctx->ev_pool) { (void)hipEventDestroy(evp.first); (void)hipEventDestroy(evp.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -565,6 +564,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     TLS_HIP(ctx, ctx->d_depth.reserve((size_t)n_periods));
     TLS_HIP(ctx, ctx->d_counters.reserve(2));
     TLS_HIP(ctx, ctx->d_queue.reserve(1));
+    TLS_HIP(ctx, ctx->d_squeue.reserve(2));
+    TLS_HIP(ctx, hipMemsetAsync(ctx->d_squeue.ptr, 0, 2 * sizeof(unsigned int), ctx->stream));  // the kernel rewinds it itself
     // the host staging vectors die at return: wait for the copies
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->prepared = true;

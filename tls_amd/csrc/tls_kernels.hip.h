@@ -181,7 +181,7 @@ struct SearchArgs {
     double* out_depth;      // [n_periods]
     unsigned long long* counters;      // [2] evaluated cells, inner steps (nullptr: off)
     unsigned long long* phase_cycles;  // [kPhases] shader cycles per phase (nullptr: off)
-    unsigned int* queue;    // work-queue head
+    unsigned int* queue;        // [2] next work item, workgroups done (both 0 at launch, rewound by the kernel)
     double* scratch;        // non-resident: per-workgroup slabs of the folded series
     unsigned int* chunk_lists;  // per-workgroup lists of live chunks (phase 3a -> 3b)
     long long scratch_stride;   // doubles per slab
@@ -1036,7 +1036,15 @@ tls_search_kernel(const SearchArgs a) {
         __syncthreads();
         const int work = __builtin_amdgcn_readfirstlane(s_work[0]);
         __syncthreads();
-        if (work >= a.n_periods) break;
+        if (work >= a.n_periods) {
+            // the last workgroup to leave rewinds the queue for the next launch (no memset between
+            // two searches of a prepared plan); queue[1] counts the workgroups that are done
+            if (tid == 0) {
+                __threadfence();
+                if (atomicAdd(a.queue + 1, 1u) == gridDim.x - 1) { atomicExch(a.queue, 0u); atomicExch(a.queue + 1, 0u); }
+            }
+            break;
+        }
         const int p = a.order[work];
         const double period = a.periods[p];
         PhaseClock pc;
@@ -1700,7 +1708,7 @@ struct T0FitArgs {
     const double* signal;   // [dur] template scaled to the fitted depth
     const double* epochs;   // [n_epochs] trial T0 values
     double* residuals;      // [n_epochs]
-    unsigned int* queue;
+    unsigned int* queue;        // work-queue head (zeroed by the host before the launch)
     double* scratch;        // non-resident slabs: 3*n doubles per workgroup
     long long scratch_stride;
     double period;
