@@ -11,8 +11,9 @@ A "step" is one pass of the hot path over one batch of synthetic input that is a
 resident in HBM: the full period x duration x T0 grid search of BASELINE.json's config 2 (90 d,
 30-min cadence, default grids: 9679 periods, 8.77e8 trial cells).
   * survey mode (default; BASELINE config 5): every GPU searches one light curve per step
-    (its own seed) and the per-period (chi2, row, depth) triples are all-gathered over RCCL so
-    that every rank holds the whole batch -> per-GPU work is fixed, "scaling": "weak".
+    (its own seed); the per-period (chi2, row, depth) triples of all K steps are exchanged with
+    ONE RCCL all-gather at the end of the timed region, so that every rank holds the whole
+    batch -> per-GPU work is fixed, "scaling": "weak".
   * shard mode (BASELINE config 4 layout): ONE light curve per step, its period grid block-
     partitioned over the GPUs by cumulative cell cost, one RCCL all-gather at the end
     -> "scaling": "strong".
@@ -200,31 +201,52 @@ def main():
             return ctx.comm_max(v)
         return channel.max(v) if channel is not None else v
 
-    def step():
+    # Survey mode exchanges the results of all K steps with ONE all-gather at the end of the timed
+    # region (north_star: "a single RCCL all-gather ... at the end"): per step the triples are only
+    # parked in a slot of a device buffer, so no rank waits for another between two light curves.
+    # Shard mode searches one light curve per step across all ranks, so its gather is per step.
+    staged = collective == "rccl" and args.mode == "survey"
+    n_slots = max(args.steps, 1)
+
+    def step(i):
         ctx.execute()
-        if collective == "rccl":
-            # pack + ncclAllGather are enqueued behind the kernel: every rank holds the whole batch
+        if staged:
+            ctx.comm_stage_results(count_per_rank, i % n_slots, n_slots)
+        elif collective == "rccl":
+            # pack + ncclAllGather are enqueued behind the kernel: every rank holds the whole result
             # in HBM, and the next search starts without a host round trip
             ctx.comm_allgather_device(count_per_rank)
         elif channel is not None:
             c, r, d = ctx.fetch()
             channel.allgather_bytes(c.tobytes() + r.tobytes() + d.tobytes())
 
-    for _ in range(args.warmup):
-        step()
+    def finish():
+        if staged:
+            ctx.comm_allgather_staged(count_per_rank, n_slots)
+
+    if staged:   # every slot holds a result before the first gather ships the whole buffer
+        for i in range(n_slots):
+            step(i)
+    for i in range(args.warmup):
+        step(i)
+    finish()
     ctx.synchronize()
     ctx.kernel_timing(reset=True)
     barrier()
     ctx.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    finish()
     ctx.synchronize()
     barrier()
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.kernel_timing(reset=True)
-    if collective == "rccl":  # outside the timed region: the last gathered batch, on the host
+    if staged:  # outside the timed region: one gathered slot on the host
+        g_chi2, g_row, g_depth = ctx.comm_fetch_staged(count_per_rank, n_slots, n_slots - 1, world)
+        assert len(g_chi2) == count_per_rank * world
+    elif collective == "rccl":
         g_chi2, g_row, g_depth = ctx.comm_fetch_gathered(count_per_rank, world)
         assert len(g_chi2) == count_per_rank * world
     if world > 1:
@@ -287,8 +309,8 @@ def main():
                                    "light curve; %s" % (
                                        args.config, n, len(periods), inp["table"].n_rows,
                                        info["grid_cells"] if args.mode == "survey" else job_cells,
-                                       "survey mode, one light curve per GPU per step + RCCL "
-                                       "all-gather" if args.mode == "survey" else
+                                       "survey mode, one light curve per GPU per step, one RCCL "
+                                       "all-gather of all steps' results at the end" if args.mode == "survey" else
                                        "period grid sharded over the GPUs + RCCL all-gather"),
                        "mode": args.mode, "collective": collective, "sigma_ppm": 1e6 * (args.sigma or synthetic.CONFIGS[args.config][2]),
                        "light_curves_per_step": world if args.mode == "survey" else 1,

@@ -166,6 +166,14 @@ int tls_comm_allgather_results(tls_ctx *ctx, int64_t count_per_rank, double *all
 int tls_comm_allgather_device(tls_ctx *ctx, int64_t count_per_rank);
 int tls_comm_fetch_gathered(tls_ctx *ctx, int64_t count_per_rank, double *all_chi2,
                             int64_t *all_row, double *all_depth);
+/* Survey mode (every rank searches its own light curves): stage the latest results as slot
+ * `slot` of `n_slots` with device copies on the stream -- no communication, no rank waits for
+ * another -- and exchange all slots with ONE ncclAllGather at the end; _fetch_staged copies one
+ * slot of that gather (n_ranks*count_per_rank entries, rank order) to the host. */
+int tls_comm_stage_results(tls_ctx *ctx, int64_t count_per_rank, int64_t slot, int64_t n_slots);
+int tls_comm_allgather_staged(tls_ctx *ctx, int64_t count_per_rank, int64_t n_slots);
+int tls_comm_fetch_staged(tls_ctx *ctx, int64_t count_per_rank, int64_t n_slots, int64_t slot,
+                          double *all_chi2, int64_t *all_row, double *all_depth);
 /* small host-value collectives used by the bench harness (barrier, max over ranks) */
 int tls_comm_barrier(tls_ctx *ctx);
 int tls_comm_max(tls_ctx *ctx, double *value_inout);

@@ -283,6 +283,21 @@ def test_single_rank_rccl_allgather(gpu):
         numpy.testing.assert_array_equal(rowb, row)
         assert gpu.comm_max(3.5) == 3.5
         gpu.comm_barrier()
+        # survey form: results of several searches parked in slots, ONE all-gather at the end
+        other = dict(inp["params"], transit_depth_min=3e-5)
+        ref2 = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], other)
+        gpu.comm_stage_results(1024, 1, 3)
+        gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+        gpu.comm_stage_results(1024, 0, 3)
+        gpu.comm_stage_results(1024, 2, 3)
+        gpu.comm_allgather_staged(1024, 3)
+        for slot, want in ((0, ref), (1, ref2), (2, ref)):
+            got = gpu.comm_fetch_staged(1024, 3, slot, 1)
+            for x, y in zip(got, want[:3]):
+                numpy.testing.assert_array_equal(x[:1000], y)
+                assert numpy.all(x[1000:] == 0)
+        with pytest.raises(RuntimeError):
+            gpu.comm_fetch_gathered(1024, 1)   # the last gather was a staged one
     finally:
         gpu.comm_destroy()
 

@@ -18,6 +18,7 @@ SYMBOLS = (
     "tls_device_name", "tls_search", "tls_search_batch", "tls_prepare", "tls_update_flux", "tls_execute",
     "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_t0_fit", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
+    "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
     "tls_comm_barrier", "tls_comm_max",
 )
 
@@ -114,6 +115,12 @@ def load():
     lib.tls_comm_allgather_device.argtypes = [vp, i64]
     lib.tls_comm_fetch_gathered.restype = ci
     lib.tls_comm_fetch_gathered.argtypes = [vp, i64, _c_double_p, _c_int64_p, _c_double_p]
+    lib.tls_comm_stage_results.restype = ci
+    lib.tls_comm_stage_results.argtypes = [vp, i64, i64, i64]
+    lib.tls_comm_allgather_staged.restype = ci
+    lib.tls_comm_allgather_staged.argtypes = [vp, i64, i64]
+    lib.tls_comm_fetch_staged.restype = ci
+    lib.tls_comm_fetch_staged.argtypes = [vp, i64, i64, i64, _c_double_p, _c_int64_p, _c_double_p]
     lib.tls_comm_barrier.restype = ci
     lib.tls_comm_barrier.argtypes = [vp]
     lib.tls_comm_max.restype = ci
@@ -314,6 +321,23 @@ class Context(object):
     def comm_allgather_device(self, count_per_rank):
         """Enqueue pack + ncclAllGather behind the search; the batch stays device resident."""
         self._check(self._lib.tls_comm_allgather_device(self._h, int(count_per_rank)))
+
+    def comm_stage_results(self, count_per_rank, slot, n_slots):
+        """Survey mode: park the latest results as slot `slot` (device copies, no communication)."""
+        self._check(self._lib.tls_comm_stage_results(self._h, int(count_per_rank), int(slot), int(n_slots)))
+
+    def comm_allgather_staged(self, count_per_rank, n_slots):
+        """ONE ncclAllGather of all staged slots, enqueued on the search stream."""
+        self._check(self._lib.tls_comm_allgather_staged(self._h, int(count_per_rank), int(n_slots)))
+
+    def comm_fetch_staged(self, count_per_rank, n_slots, slot, n_ranks):
+        n = int(count_per_rank) * int(n_ranks)
+        chi2 = numpy.empty(n, dtype=numpy.float64)
+        row = numpy.empty(n, dtype=numpy.int64)
+        depth = numpy.empty(n, dtype=numpy.float64)
+        self._check(self._lib.tls_comm_fetch_staged(self._h, int(count_per_rank), int(n_slots), int(slot),
+                                                    _dp(chi2), _ip(row), _dp(depth)))
+        return chi2, row, depth
 
     def comm_fetch_gathered(self, count_per_rank, n_ranks):
         total = int(count_per_rank) * int(n_ranks)

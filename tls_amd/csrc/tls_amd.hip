@@ -74,7 +74,7 @@ struct tls_ctx {
     int n_cu = 0;
 
     // device-resident plan
-    DevBuf<double> d_t, d_y, d_w, d_periods, d_q, d_q2, d_chi2, d_depth, d_scratch, d_pack, d_gather, d_scalar;
+    DevBuf<double> d_t, d_y, d_w, d_periods, d_q, d_q2, d_chi2, d_depth, d_scratch, d_pack, d_gather, d_scalar, d_stage;
     DevBuf<long long> d_row;
     DevBuf<int> d_order;
     DevBuf<tlsdev::PeriodRows> d_rows;
@@ -397,7 +397,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_t.release(); ctx->d_y.release(); ctx->d_w.release(); ctx->d_periods.release(); ctx->d_q.release();
     ctx->d_chi2.release(); ctx->d_depth.release(); ctx->d_scratch.release(); ctx->d_pack.release();
-    ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_row.release(); ctx->d_order.release();
+    ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release(); ctx->d_row.release(); ctx->d_order.release();
     ctx->d_rows.release(); ctx->d_widths.release(); ctx->d_counters.release();
     ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
@@ -916,6 +916,58 @@ int tls_comm_fetch_gathered(tls_ctx* ctx, int64_t count_per_rank, double* all_ch
         std::memcpy(all_chi2 + r * c, blk, c * 8);
         std::memcpy(all_row + r * c, blk + c, c * 8);  // int64 bit patterns travel as 8-byte words
         std::memcpy(all_depth + r * c, blk + 2 * c, c * 8);
+    }
+    return TLS_OK;
+}
+
+int tls_comm_stage_results(tls_ctx* ctx, int64_t count_per_rank, int64_t slot, int64_t n_slots) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->executed) return fail(ctx, TLS_E_STATE, "staging before tls_execute");
+    if (count_per_rank < ctx->n_periods || count_per_rank < 1 || n_slots < 1 || slot < 0 || slot >= n_slots)
+        return fail(ctx, TLS_E_ARG, "bad slot layout");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t c = (size_t)count_per_rank, np = (size_t)ctx->n_periods;
+    TLS_HIP(ctx, ctx->d_stage.reserve(3 * c * (size_t)n_slots));
+    double* dst = ctx->d_stage.ptr + 3 * c * (size_t)slot;   // [chi2 | row | depth] of this slot, 24 B per period
+    if (np < c) TLS_HIP(ctx, hipMemsetAsync(dst, 0, 3 * c * 8, ctx->stream));
+    if (np) {
+        TLS_HIP(ctx, hipMemcpyAsync(dst, ctx->d_chi2.ptr, np * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(dst + c, ctx->d_row.ptr, np * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(dst + 2 * c, ctx->d_depth.ptr, np * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return TLS_OK;
+}
+
+int tls_comm_allgather_staged(tls_ctx* ctx, int64_t count_per_rank, int64_t n_slots) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->comm) return fail(ctx, TLS_E_STATE, "tls_comm_init first");
+    if (count_per_rank < 1 || n_slots < 1) return fail(ctx, TLS_E_ARG, "bad slot layout");
+    const size_t per_rank = 3 * (size_t)count_per_rank * (size_t)n_slots;
+    if (ctx->d_stage.cap < per_rank) return fail(ctx, TLS_E_STATE, "nothing staged for that layout");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    TLS_HIP(ctx, ctx->d_gather.reserve(per_rank * (size_t)ctx->n_ranks));
+    TLS_NCCL(ctx, ncclAllGather(ctx->d_stage.ptr, ctx->d_gather.ptr, per_rank, ncclDouble, ctx->comm, ctx->stream));
+    ctx->gathered_count = -(int64_t)per_rank;   // marks a staged gather (tls_comm_fetch_gathered refuses it)
+    return TLS_OK;
+}
+
+int tls_comm_fetch_staged(tls_ctx* ctx, int64_t count_per_rank, int64_t n_slots, int64_t slot, double* all_chi2,
+                          int64_t* all_row, double* all_depth) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!ctx->comm) return fail(ctx, TLS_E_STATE, "tls_comm_init first");
+    if (!all_chi2 || !all_row || !all_depth) return fail(ctx, TLS_E_ARG, "null output");
+    if (count_per_rank < 1 || n_slots < 1 || slot < 0 || slot >= n_slots) return fail(ctx, TLS_E_ARG, "bad slot layout");
+    const size_t c = (size_t)count_per_rank, R = (size_t)ctx->n_ranks, per_rank = 3 * c * (size_t)n_slots;
+    if (ctx->gathered_count != -(int64_t)per_rank) return fail(ctx, TLS_E_STATE, "no staged all-gather of that layout to fetch");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> host(3 * c);
+    for (size_t r = 0; r < R; ++r) {
+        TLS_HIP(ctx, hipMemcpyAsync(host.data(), ctx->d_gather.ptr + r * per_rank + 3 * c * (size_t)slot, 3 * c * 8,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(all_chi2 + r * c, host.data(), c * 8);
+        std::memcpy(all_row + r * c, host.data() + c, c * 8);  // int64 bit patterns travel as 8-byte words
+        std::memcpy(all_depth + r * c, host.data() + 2 * c, c * 8);
     }
     return TLS_OK;
 }
