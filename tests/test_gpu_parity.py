@@ -27,7 +27,12 @@ def assert_parity(got, want, n_points, tight=RTOL_TIGHT):
     numpy.testing.assert_array_equal(row, orow)
     numpy.testing.assert_allclose(depth, odepth, rtol=0, atol=1e-12)
     if finite.any():
-        assert int(numpy.argmin(chi2)) == int(numpy.argmin(ochi2))
+        # the argmin period index is exact -- unless two trial periods tie to within the 1e-13
+        # agreement of the two arithmetics (seen in the randomised sweep: two near-identical periods
+        # at the end of a short grid); then either index is the minimum
+        ia, ib = int(numpy.nanargmin(numpy.where(finite, chi2, numpy.inf))), int(numpy.nanargmin(numpy.where(finite, ochi2, numpy.inf)))
+        if ia != ib:
+            assert abs(ochi2[ia] - ochi2[ib]) <= 1e-11 * abs(ochi2[ib]), (ia, ib, ochi2[ia], ochi2[ib])
     # exactly N where nothing beat the straight line (core.py:46)
     numpy.testing.assert_array_equal(chi2 == n_points, ochi2 == n_points)
 
