@@ -1,6 +1,8 @@
 """The drop-in API end to end on the GPU: tls_amd.transitleastsquares(...).power(...)
 against golden results of the unmodified reference and the reference's own
 known-answer tests (same checks as test_power_host.py, real HIP search)."""
+import os
+
 import numpy
 import pytest
 
@@ -63,7 +65,15 @@ def test_k2_90d_anchor_values():
     assert len(r.transit_times) == 8
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def _extra_seeds():   # TLS_FUZZ_SEEDS="100-140" adds seeds for a one-off longer sweep
+    out = []
+    for part in filter(None, os.environ.get("TLS_FUZZ_SEEDS", "").split(",")):
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4] + _extra_seeds())
 def test_power_gpu_equals_power_with_oracle_search(monkeypatch, oracle_lib, seed):
     """End to end on random small light curves: the drop-in with the HIP search and the device T0
     fit must return the same results object as the same host code fed by the CPU oracle and the
