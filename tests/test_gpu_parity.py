@@ -432,6 +432,7 @@ def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
     duration-grid steps: resident and tiled kernel variants, dense and strided T0 grids, uniform
     and per-point weights, all against the oracle."""
     rng = numpy.random.RandomState(seed)
+    extreme = bool(os.environ.get("TLS_FUZZ_EXTREME"))   # one-off sweeps: unusual parameter values too
     n_cases = 0
     for case in range(24):
         span = float(rng.choice([8.0, 20.0, 45.0, 120.0]))
@@ -455,9 +456,9 @@ def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
             dy = rng.uniform(0.5, 2.0, len(t)) * sigma
         kwargs = dict(period_min=float(rng.uniform(0.7, 2.0)), period_max=float(rng.uniform(span / 4, span / 2)),
                       oversampling_factor=int(rng.choice([1, 2, 3])),
-                      duration_grid_step=float(rng.choice([1.05, 1.1, 1.3])),
-                      T0_fit_margin=float(rng.choice([0.0, 0.01, 0.05, 0.1])),
-                      transit_depth_min=float(rng.choice([1e-6, 1e-5, 2e-4])))
+                      duration_grid_step=float(rng.choice([1.05, 1.1, 1.3] + ([1.02] if extreme else []))),
+                      T0_fit_margin=float(rng.choice([0.0, 0.01, 0.05, 0.1] + ([0.3, 0.7, 1.0] if extreme else []))),
+                      transit_depth_min=float(rng.choice([1e-6, 1e-5, 2e-4] + ([0.0, 1e-8] if extreme else []))))
         if kwargs["period_min"] >= kwargs["period_max"]:
             continue
         try:
