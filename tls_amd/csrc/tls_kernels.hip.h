@@ -1116,6 +1116,12 @@ tls_search_kernel(const SearchArgs a) {
                 exact_sequential_cumsum(f_l, c_l, len, cumsum_scratch, a.phase_cycles, carry);
                 __syncthreads();
                 for (int k = tid; k <= len; k += nt) regB[c0 + k] = c_l[k];
+                // e = 1 - f (or e*w) goes back to the slab from the LDS copy: one pass less over HBM
+                for (int k = tid; k < len; k += nt) {
+                    double e = 1.0 - f_l[k];
+                    if constexpr (!UNIFORM_W) e *= regW[c0 + k];
+                    regA[c0 + k] = e;
+                }
                 carry = c_l[len];
                 __syncthreads();
             }
@@ -1127,11 +1133,14 @@ tls_search_kernel(const SearchArgs a) {
         for (int k = tid; k < region_pad; k += nt) regB[M + 1 + k] = (double)(k + 1) * 1.0e300;
         __syncthreads();
         pc.mark(5);
-        // e = 1 - f in place (uniform weights) or e*w (general weights)
-        for (int k = tid; k < M; k += nt) {
-            double e = 1.0 - regA[k];
-            if constexpr (!UNIFORM_W) e *= regW[k];
-            regA[k] = e;
+        // e = 1 - f in place (uniform weights) or e*w (general weights); the tiled variant has done
+        // it chunk by chunk above
+        if constexpr (RESIDENT) {
+            for (int k = tid; k < M; k += nt) {
+                double e = 1.0 - regA[k];
+                if constexpr (!UNIFORM_W) e *= regW[k];
+                regA[k] = e;
+            }
         }
         __syncthreads();
         pc.mark(8);
