@@ -250,6 +250,28 @@ def test_commensurate_periods_cluster_the_phases(gpu, oracle_lib):
     assert_parity(got, want, n)
 
 
+def test_tiled_sort_ties_order_and_clustered_phases(gpu, oracle_lib):
+    """The HBM-slab variant sorts in two levels (fold_and_sort_tiled): unsorted input, exact ties and
+    its fallback (phases piled into a few bins by periods commensurate with the cadence) must all
+    give the stable order of the reference."""
+    n = 19440
+    t = 3.0 + numpy.arange(n) / 720.0            # exact binary-friendly 2-min cadence
+    rng = numpy.random.RandomState(3)
+    y = 1 + rng.normal(0, 2e-4, n)
+    y[(t % 3.7) < 0.08] -= 1.5e-3
+    shuffle = rng.permutation(n)
+    t, y = t[shuffle], y[shuffle]
+    t[500:520] = t[500]                           # exact ties
+    t[9000] = t[42]
+    inp = synthetic.search_inputs(t, y, period_max=9.0)
+    periods = numpy.sort(numpy.concatenate([inp["periods"][::120], [0.025, 0.05, 0.75, 1.0, 2.5, 3.7, 8.0]]))  # 0.025, 0.05: 18 and 36 distinct phases -> the fallback
+    got = gpu.search(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"], count_work=True)
+    assert not gpu.plan_info()["resident"]
+    want = oracle_search(oracle_lib, inp, periods=periods)
+    assert_parity(got, want, len(inp["t"]))
+    assert got[3]["evaluated_cells"] == int(want[3][1])
+
+
 def test_bad_arguments_raise(gpu):
     inp = _inputs("k2_90d")
     with pytest.raises(RuntimeError):

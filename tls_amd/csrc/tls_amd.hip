@@ -82,6 +82,7 @@ struct tls_ctx {
     DevBuf<unsigned long long> d_counters, d_phase;
     DevBuf<unsigned int> d_queue, d_squeue, d_lists, d_perm;   // d_squeue: the search kernel's self-rewinding queue
     DevBuf<double> d_curve_S0, d_curve_w0;   // survey batches
+    bool sort2 = false;                      // tiled variant: two-level sort
     int batch_curves = 1;                    // light curves the next launch searches (tls_search_batch)
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
     size_t list_stride = 0;
@@ -316,6 +317,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     a.chunk_lists = ctx->d_lists.ptr; a.list_stride = 2 * (long long)ctx->list_stride; a.list_cap = (long long)ctx->list_stride;
     a.prune_min_live = ctx->prune_min_live; a.p2_shift = ctx->p2_shift; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
+    a.sort2 = ctx->sort2 ? 1 : 0;
     a.n_curves = ctx->batch_curves; a.curve_S0 = ctx->d_curve_S0.ptr; a.curve_w0 = ctx->d_curve_w0.ptr;
     a.perm_scratch = ctx->d_perm.ptr;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
@@ -476,7 +478,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->resident = resident_bytes <= kLdsPerCU && n <= 65535;
     if (ctx->resident) {
         ctx->nb = (int)n;
-        ctx->tile_len = 0; ctx->tile_halo = 0;
+        ctx->tile_len = 0; ctx->tile_halo = 0; ctx->sort2 = false;
         ctx->lds_bytes = resident_bytes;
         const size_t per_cu = kLdsPerCU / resident_bytes;
         ctx->threads = per_cu >= 2 ? 512 : 1024;
@@ -516,6 +518,11 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
                                                 buffers * 8 * (tile + halo));
         ctx->threads = 1024;
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)ctx->n_cu);
+        // two-level sort with sequential HBM accesses (fold_and_sort_tiled) when its LDS windows fit
+        const size_t sort2_bytes = hdr + (size_t)tlsdev::sort2_lds_bytes((int)n);
+        const char* env_sort2 = std::getenv("TLS_SORT2");
+        ctx->sort2 = sort2_bytes <= kLdsPerCU && !(env_sort2 && std::atoi(env_sort2) == 0);
+        if (ctx->sort2) ctx->lds_bytes = std::max(ctx->lds_bytes, sort2_bytes);
         TLS_HIP(ctx, ctx->d_scratch.reserve((size_t)ctx->blocks * regions * region_doubles));
     }
     // per-width work units of phase 3 (M is fixed for the plan, so these are period independent)

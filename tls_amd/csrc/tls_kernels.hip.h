@@ -187,6 +187,7 @@ struct SearchArgs {
     long long scratch_stride;   // doubles per slab
     long long list_stride;      // entries per workgroup
     // survey mode: n_curves light curves on the same time stamps share the fold + sort of a period
+    int sort2;                  // tiled variant: use fold_and_sort_tiled (its LDS fits)
     int n_curves;               // >= 1; curve c reads y + c*n (w + c*n), writes out_* + c*n_periods
     const double* curve_S0;     // [n_curves] S0 per curve (n_curves > 1; else S0 / w0 below)
     const double* curve_w0;     // [n_curves]
@@ -968,6 +969,227 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
     pc.mark(3);
 }
 
+// ---------------------------------------------------------------------------------------
+// The same order for a series that lives in HBM (tiled variant): a two-level sort whose HBM accesses
+// are all sequential.  fold_and_sort scatters and ranks through global memory with one random
+// 4-8 B access per point and step, i.e. a whole 64 B sector each -- most of the HBM traffic of the
+// Kepler-size configuration.  Here the points are first partitioned into coarse phase bins (a chunk
+// of points is bucketed in LDS and leaves as one contiguous segment per bin), then every wavefront
+// sorts one bin entirely inside its private LDS window and writes its piece of the permutation.
+//   g_ph[n], g_idx[n]: HBM scratch (phase / original index, grouped by coarse bin); perm[n]: result.
+//   lds: at least sort2_lds_bytes(n) bytes.  Returns false (all threads alike) when a coarse bin
+//   overflows its LDS window (phases piled up, e.g. a period commensurate with the cadence): the
+//   caller then falls back to fold_and_sort.
+constexpr int kSort2Chunk = 8192;     // points bucketed per pass-1 round
+constexpr int kSort2BinCap = 384;     // points one wavefront can sort in its LDS window
+constexpr int kSort2BinMean = 160;    // target points per coarse bin
+constexpr int kSort2MaxBins = 1024;
+__host__ __device__ constexpr int sort2_bins(int n) {
+    return (n + kSort2BinMean - 1) / kSort2BinMean < kSort2MaxBins ? (n + kSort2BinMean - 1) / kSort2BinMean : kSort2MaxBins;
+}
+__host__ __device__ constexpr long long sort2_lds_bytes(int n) {
+    // counters (4 arrays of bins+1 words) + the larger of the pass-1 staging and the pass-2 windows
+    const long long counters = 4LL * 4 * (sort2_bins(n) + 1);
+    const long long stage = 14LL * kSort2Chunk;                                      // f64 + u32 + u16 per point
+    const long long windows = (long long)kMaxWaves * (8 + 4 + 4 + 4 + 4) * kSort2BinCap;  // ph, idx, cnt, slot, out
+    return (counters + 15) / 16 * 16 + (stage > windows ? stage : windows);
+}
+
+__device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, double period, double epoch, double* g_ph,
+                                                    unsigned int* g_idx, unsigned int* perm, unsigned char* lds,
+                                                    PhaseClock& pc) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (kWave - 1), nw = nt / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int B = sort2_bins(n);
+    const double B_d = (double)B;
+    unsigned int* g_start = reinterpret_cast<unsigned int*>(lds);   // [B+1] first output slot of every bin
+    unsigned int* g_cur = g_start + (B + 1);                        // [B+1] pass 1: next free slot of the bin
+    unsigned int* l_cnt = g_cur + (B + 1);                          // [B+1] pass 1: points of the bin in this chunk
+    unsigned int* l_start = l_cnt + (B + 1);                        // [B+1]
+    unsigned char* area = lds + (4 * 4 * (B + 1) + 15) / 16 * 16;
+
+    // ---- counts per coarse bin ------------------------------------------------------------------
+    for (int b = tid; b <= B; b += nt) { g_start[b] = 0; l_cnt[b] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        const double ph = fold_phase(t[i], period, epoch);
+        atomicAdd(&g_start[bucket_of(ph, B_d, B)], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the bins by wave 0 (B <= 1024: 16 per lane), and the overflow test
+    if (wave == 0) {
+        const int per = (B + kWave - 1) / kWave;
+        const int lo = lane * per < B ? lane * per : B, hi = lo + per < B ? lo + per : B;
+        unsigned int local = 0, biggest = 0;
+        for (int b = lo; b < hi; ++b) { const unsigned int c = g_start[b]; local += c; biggest = c > biggest ? c : biggest; }
+        unsigned int incl = local;
+#pragma unroll
+        for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+            const unsigned int o = __shfl_up(incl, dlt, kWave);
+            if (lane >= dlt) incl += o;
+        }
+#pragma unroll
+        for (int delta = kWave / 2; delta > 0; delta >>= 1) {
+            const unsigned int o = __shfl_down(biggest, delta, kWave);
+            biggest = o > biggest ? o : biggest;
+        }
+        unsigned int run = incl - local;
+        for (int b = lo; b < hi; ++b) { const unsigned int c = g_start[b]; g_start[b] = run; g_cur[b] = run; run += c; }
+        if (lane == kWave - 1) g_start[B] = run;
+        if (lane == 0) g_cur[B] = biggest;   // parked here for everybody to read
+    }
+    __syncthreads();
+    if (g_cur[B] > (unsigned int)kSort2BinCap) { __syncthreads(); return false; }
+    pc.mark(0);
+
+    // ---- pass 1: partition, one chunk of points per round ---------------------------------------
+    {
+        double* st_ph = reinterpret_cast<double*>(area);
+        unsigned int* st_idx = reinterpret_cast<unsigned int*>(st_ph + kSort2Chunk);
+        unsigned short* st_bin = reinterpret_cast<unsigned short*>(st_idx + kSort2Chunk);
+        constexpr int kPer = kSort2Chunk / 1024;   // points per thread and round (1024-thread workgroups)
+        const int chunk = kPer * nt < kSort2Chunk ? kPer * nt : kSort2Chunk;
+        for (int c0 = 0; c0 < n; c0 += chunk) {
+            const int cn = n - c0 < chunk ? n - c0 : chunk;
+            double ph[kPer];
+            unsigned int rank[kPer];
+            int bin[kPer];
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) {
+                const int k = tid + e * nt;
+                bin[e] = -1;
+                if (k < cn) {
+                    ph[e] = fold_phase(t[c0 + k], period, epoch);
+                    bin[e] = bucket_of(ph[e], B_d, B);
+                    rank[e] = atomicAdd(&l_cnt[bin[e]], 1u);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {   // chunk-local exclusive scan; reserve the bins' output segments
+                const int per = (B + kWave - 1) / kWave;
+                const int lo = lane * per < B ? lane * per : B, hi = lo + per < B ? lo + per : B;
+                unsigned int local = 0;
+                for (int b = lo; b < hi; ++b) local += l_cnt[b];
+                unsigned int incl = local;
+#pragma unroll
+                for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+                    const unsigned int o = __shfl_up(incl, dlt, kWave);
+                    if (lane >= dlt) incl += o;
+                }
+                unsigned int run = incl - local;
+                for (int b = lo; b < hi; ++b) { l_start[b] = run; run += l_cnt[b]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) {
+                if (bin[e] >= 0) {
+                    const unsigned int s = l_start[bin[e]] + rank[e];
+                    st_ph[s] = ph[e];
+                    st_idx[s] = (unsigned int)(c0 + tid + e * nt);
+                    st_bin[s] = (unsigned short)bin[e];
+                }
+            }
+            __syncthreads();
+            // every bin's points of this chunk leave as one contiguous segment
+            for (int sidx = tid; sidx < cn; sidx += nt) {
+                const int b = st_bin[sidx];
+                const unsigned int dst = g_cur[b] + ((unsigned int)sidx - l_start[b]);
+                g_ph[dst] = st_ph[sidx];
+                g_idx[dst] = st_idx[sidx];
+            }
+            __syncthreads();
+            for (int b = tid; b < B; b += nt) { g_cur[b] += l_cnt[b]; l_cnt[b] = 0; }
+            __syncthreads();
+        }
+    }
+    pc.mark(2);
+
+    // ---- pass 2: one coarse bin per wavefront, sorted inside its LDS window -----------------------
+    {
+        unsigned char* win = area + (size_t)wave * ((8 + 4 + 4 + 4 + 4) * kSort2BinCap);
+        double* w_ph = reinterpret_cast<double*>(win);
+        unsigned int* w_idx = reinterpret_cast<unsigned int*>(w_ph + kSort2BinCap);
+        unsigned int* w_cnt = w_idx + kSort2BinCap;
+        unsigned int* w_slot = w_cnt + kSort2BinCap;
+        unsigned int* w_out = w_slot + kSort2BinCap;
+        constexpr int kE = kSort2BinCap / kWave;   // entries per lane
+        for (int b0 = 0; b0 < B; b0 += nw) {
+            const int b = b0 + wave;
+            const unsigned int first = b < B ? g_start[b] : 0u;
+            const int m = b < B ? (int)(g_start[b + 1] - first) : 0;
+            // fine bucket of a point inside its coarse bin: monotone in the phase
+            int fb[kE];
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const int j = lane + e * kWave;
+                w_cnt[j] = 0;
+                fb[e] = 0;
+                if (j < m) {
+                    const double ph = g_ph[first + j];
+                    w_ph[j] = ph;
+                    w_idx[j] = g_idx[first + j];
+                    const int f = (int)((ph * B_d - (double)b) * (double)kSort2BinCap);
+                    fb[e] = f < 0 ? 0 : (f < kSort2BinCap - 1 ? f : kSort2BinCap - 1);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < kE; ++e) if (lane + e * kWave < m) atomicAdd(&w_cnt[fb[e]], 1u);
+            __syncthreads();
+            {   // exclusive scan of the kSort2BinCap counters of this window: kE consecutive per lane
+                unsigned int c[kE], local = 0;
+#pragma unroll
+                for (int e = 0; e < kE; ++e) { c[e] = w_cnt[lane * kE + e]; local += c[e]; }
+                unsigned int incl = local;
+#pragma unroll
+                for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+                    const unsigned int o = __shfl_up(incl, dlt, kWave);
+                    if (lane >= dlt) incl += o;
+                }
+                unsigned int run = incl - local;
+#pragma unroll
+                for (int e = 0; e < kE; ++e) { w_cnt[lane * kE + e] = run; run += c[e]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const int j = lane + e * kWave;
+                if (j < m) w_slot[atomicAdd(&w_cnt[fb[e]], 1u)] = (unsigned int)j;   // w_cnt[f] becomes the END of bucket f
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const int sidx = lane + e * kWave;
+                if (sidx < m) {
+                    const int j = (int)w_slot[sidx];
+                    const double ph = w_ph[j];
+                    const unsigned int id = w_idx[j];
+                    const int f = (int)((ph * B_d - (double)b) * (double)kSort2BinCap);
+                    const int fbj = f < 0 ? 0 : (f < kSort2BinCap - 1 ? f : kSort2BinCap - 1);
+                    const int lo = fbj ? (int)w_cnt[fbj - 1] : 0, hi = (int)w_cnt[fbj];
+                    int rank = 0;
+                    for (int s2 = lo; s2 < hi; ++s2) {
+                        const int j2 = (int)w_slot[s2];
+                        const double ph2 = w_ph[j2];
+                        rank += (ph2 < ph || (ph2 == ph && w_idx[j2] < id)) ? 1 : 0;
+                    }
+                    w_out[lo + rank] = id;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const int sidx = lane + e * kWave;
+                if (sidx < m) perm[first + sidx] = w_out[sidx];
+            }
+            __syncthreads();
+        }
+    }
+    pc.mark(3);
+    return true;
+}
+
 template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false>
 __global__ void __launch_bounds__(1024, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs a) {
@@ -1051,7 +1273,14 @@ tls_search_kernel(const SearchArgs a) {
         pc.start(a.phase_cycles);
 
         // ---- phase 1: fold + stable sort by phase ----------------------------------
-        fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc);
+        bool sorted = false;
+        if constexpr (!RESIDENT) {
+            // series in HBM: the two-level sort with sequential HBM accesses, unless a phase bin overflows
+            if (a.sort2)
+                sorted = fold_and_sort_tiled(a.t, n, period, 0.0, ph_orig, reinterpret_cast<unsigned int*>(idx_tmp),
+                                             reinterpret_cast<unsigned int*>(perm), smem + a.hdr_bytes, pc);
+        }
+        if (!sorted) fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc);
         // survey mode: the permutation depends on (t, period) only, so every light curve of the
         // batch reuses it; it must outlive the prefix sum that overwrites its LDS home
         const IdxT* perm_use = perm;
