@@ -1395,17 +1395,28 @@ tls_search_kernel(const SearchArgs a) {
             double* tile_c = UNIFORM_W ? tile_w : tile_w + staged;
             __syncthreads();  // the previous tile (or the sort histogram) is no longer read
             pc.mark(20);
-            for (int k = tid; k < staged; k += nt) {
-                const int src = p_lo + k;
-                const bool in = src < M + 1 + region_pad;
-                tile_e[k] = in ? regA[src] : 0.0;
-                if constexpr (!UNIFORM_W) tile_w[k] = in ? regW[src] : 0.0;
-                if constexpr (STAGE_C) tile_c[k] = in ? regB[src] : (double)(src - M) * 1.0e300;
+            if constexpr (STAGE_C) {
+                for (int k = tid; k < staged; k += nt) {
+                    const int src = p_lo + k;
+                    const bool in = src < M + 1 + region_pad;
+                    tile_e[k] = in ? regA[src] : 0.0;
+                    if constexpr (!UNIFORM_W) tile_w[k] = in ? regW[src] : 0.0;
+                    tile_c[k] = in ? regB[src] : (double)(src - M) * 1.0e300;
+                }
+                e_base = tile_e - p_lo;
+                w_base = tile_w - p_lo;
+                c_base = tile_c - p_lo;
+            } else {
+                // no room for C beside the samples: the predicate pass gets C in the samples' place
+                // (sequential HBM reads instead of the predicate's scattered ones), the samples follow
+                // once the live units are listed
+                for (int k = tid; k < staged; k += nt) {
+                    const int src = p_lo + k;
+                    tile_e[k] = src < M + 1 + region_pad ? regB[src] : (double)(src - M) * 1.0e300;
+                }
+                c_base = tile_e - p_lo;
             }
             for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;
-            e_base = tile_e - p_lo;
-            w_base = tile_w - p_lo;
-            if constexpr (STAGE_C) c_base = tile_c - p_lo;
             __syncthreads();
             pc.mark(12);
         }
@@ -1507,6 +1518,23 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
         pc.mark(9);
+        if constexpr (!RESIDENT && !STAGE_C) {
+            // the folded samples replace C in the tile; the few C values phase 3b needs come from the slab
+            double* tile_e = reinterpret_cast<double*>(smem + a.hdr_bytes);
+            const int staged = a.tile_len + a.tile_halo;
+            double* tile_w = tile_e + staged;
+            for (int k = tid; k < staged; k += nt) {
+                const int src = p_lo + k;
+                const bool in = src < M + 1 + region_pad;
+                tile_e[k] = in ? regA[src] : 0.0;
+                if constexpr (!UNIFORM_W) tile_w[k] = in ? regW[src] : 0.0;
+            }
+            e_base = tile_e - p_lo;
+            w_base = tile_w - p_lo;
+            c_base = regB;
+            __syncthreads();
+            pc.mark(12);
+        }
         // ---- pruning (exact): drop the units that cannot win before they reach phase 3b ------------
         // Worth its passes only when many cells passed the depth predicate (noisy light curves):
         // decided per period (and tile) from the number of live units.
