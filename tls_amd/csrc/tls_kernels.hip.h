@@ -124,6 +124,23 @@ __device__ __forceinline__ void load_taps(const double* p, double (&x)[kU]) {
     }
 }
 
+// dst[k] = src[k] for k in [0, count), all threads of the workgroup, four global reads in flight per
+// thread (the compiler does not overlap them itself: the store of one may alias the read of the next)
+__device__ __forceinline__ void copy_in_flight4(double* dst, const double* src, int count) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int k = tid; k < count; k += 4 * nt) {
+        const int k1 = k + nt, k2 = k + 2 * nt, k3 = k + 3 * nt;
+        const double v0 = src[k];
+        const double v1 = k1 < count ? src[k1] : 0.0;
+        const double v2 = k2 < count ? src[k2] : 0.0;
+        const double v3 = k3 < count ? src[k3] : 0.0;
+        dst[k] = v0;
+        if (k1 < count) dst[k1] = v1;
+        if (k2 < count) dst[k2] = v2;
+        if (k3 < count) dst[k3] = v3;
+    }
+}
+
 // developer instrumentation: thread 0 stamps the shader clock at phase boundaries
 struct PhaseClock {
     unsigned long long* out;
@@ -1012,9 +1029,13 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
     // ---- counts per coarse bin ------------------------------------------------------------------
     for (int b = tid; b <= B; b += nt) { g_start[b] = 0; l_cnt[b] = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += nt) {
-        const double ph = fold_phase(t[i], period, epoch);
-        atomicAdd(&g_start[bucket_of(ph, B_d, B)], 1u);
+    for (int i = tid; i < n; i += 4 * nt) {   // four time stamps in flight per thread
+        const int i1 = i + nt, i2 = i + 2 * nt, i3 = i + 3 * nt;
+        const double t0 = t[i], t1 = i1 < n ? t[i1] : 0.0, t2 = i2 < n ? t[i2] : 0.0, t3 = i3 < n ? t[i3] : 0.0;
+        atomicAdd(&g_start[bucket_of(fold_phase(t0, period, epoch), B_d, B)], 1u);
+        if (i1 < n) atomicAdd(&g_start[bucket_of(fold_phase(t1, period, epoch), B_d, B)], 1u);
+        if (i2 < n) atomicAdd(&g_start[bucket_of(fold_phase(t2, period, epoch), B_d, B)], 1u);
+        if (i3 < n) atomicAdd(&g_start[bucket_of(fold_phase(t3, period, epoch), B_d, B)], 1u);
     }
     __syncthreads();
     // exclusive scan over the bins by wave 0 (B <= 1024: 16 per lane), and the overflow test
@@ -1340,7 +1361,7 @@ tls_search_kernel(const SearchArgs a) {
             double carry = 0.0;
             for (int c0 = 0; c0 < M; c0 += kCumsumChunk) {
                 const int len = M - c0 < kCumsumChunk ? M - c0 : kCumsumChunk;
-                for (int k = tid; k < len; k += nt) f_l[k] = regA[c0 + k];
+                copy_in_flight4(f_l, regA + c0, len);
                 __syncthreads();
                 exact_sequential_cumsum(f_l, c_l, len, cumsum_scratch, a.phase_cycles, carry);
                 __syncthreads();
@@ -1396,12 +1417,17 @@ tls_search_kernel(const SearchArgs a) {
             __syncthreads();  // the previous tile (or the sort histogram) is no longer read
             pc.mark(20);
             if constexpr (STAGE_C) {
-                for (int k = tid; k < staged; k += nt) {
-                    const int src = p_lo + k;
-                    const bool in = src < M + 1 + region_pad;
-                    tile_e[k] = in ? regA[src] : 0.0;
-                    if constexpr (!UNIFORM_W) tile_w[k] = in ? regW[src] : 0.0;
-                    tile_c[k] = in ? regB[src] : (double)(src - M) * 1.0e300;
+                {
+                    const int avail = M + 1 + region_pad - p_lo;            // entries the slab still holds
+                    const int valid = avail < staged ? (avail > 0 ? avail : 0) : staged;
+                    copy_in_flight4(tile_e, regA + p_lo, valid);
+                    copy_in_flight4(tile_c, regB + p_lo, valid);
+                    if constexpr (!UNIFORM_W) copy_in_flight4(tile_w, regW + p_lo, valid);
+                    for (int k = valid + tid; k < staged; k += nt) {
+                        tile_e[k] = 0.0;
+                        if constexpr (!UNIFORM_W) tile_w[k] = 0.0;
+                        tile_c[k] = (double)(p_lo + k - M) * 1.0e300;
+                    }
                 }
                 e_base = tile_e - p_lo;
                 w_base = tile_w - p_lo;
@@ -1410,9 +1436,11 @@ tls_search_kernel(const SearchArgs a) {
                 // no room for C beside the samples: the predicate pass gets C in the samples' place
                 // (sequential HBM reads instead of the predicate's scattered ones), the samples follow
                 // once the live units are listed
-                for (int k = tid; k < staged; k += nt) {
-                    const int src = p_lo + k;
-                    tile_e[k] = src < M + 1 + region_pad ? regB[src] : (double)(src - M) * 1.0e300;
+                {
+                    const int avail = M + 1 + region_pad - p_lo;            // entries the slab still holds
+                    const int valid = avail < staged ? (avail > 0 ? avail : 0) : staged;
+                    copy_in_flight4(tile_e, regB + p_lo, valid);
+                    for (int k = valid + tid; k < staged; k += nt) tile_e[k] = (double)(p_lo + k - M) * 1.0e300;
                 }
                 c_base = tile_e - p_lo;
             }
@@ -1523,11 +1551,15 @@ tls_search_kernel(const SearchArgs a) {
             double* tile_e = reinterpret_cast<double*>(smem + a.hdr_bytes);
             const int staged = a.tile_len + a.tile_halo;
             double* tile_w = tile_e + staged;
-            for (int k = tid; k < staged; k += nt) {
-                const int src = p_lo + k;
-                const bool in = src < M + 1 + region_pad;
-                tile_e[k] = in ? regA[src] : 0.0;
-                if constexpr (!UNIFORM_W) tile_w[k] = in ? regW[src] : 0.0;
+            {
+                const int avail = M + 1 + region_pad - p_lo;
+                const int valid = avail < staged ? (avail > 0 ? avail : 0) : staged;
+                copy_in_flight4(tile_e, regA + p_lo, valid);
+                for (int k = valid + tid; k < staged; k += nt) tile_e[k] = 0.0;
+                if constexpr (!UNIFORM_W) {
+                    copy_in_flight4(tile_w, regW + p_lo, valid);
+                    for (int k = valid + tid; k < staged; k += nt) tile_w[k] = 0.0;
+                }
             }
             e_base = tile_e - p_lo;
             w_base = tile_w - p_lo;
