@@ -1012,9 +1012,12 @@ __host__ __device__ constexpr long long sort2_lds_bytes(int n) {
     return (counters + 15) / 16 * 16 + (stage > windows ? stage : windows);
 }
 
+//   y_gather (may be null): the folded flux y[perm[k]] is written over g_ph[k] on the way (and
+//   w_gather -> w_out likewise), which saves the separate gather pass of a single light curve.
 __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, double period, double epoch, double* g_ph,
                                                     unsigned int* g_idx, unsigned int* perm, unsigned char* lds,
-                                                    PhaseClock& pc) {
+                                                    PhaseClock& pc, const double* y_gather = nullptr,
+                                                    const double* w_gather = nullptr, double* w_out_g = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -1199,10 +1202,27 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 }
             }
             __syncthreads();
+            {
+                unsigned int id[kE];
 #pragma unroll
-            for (int e = 0; e < kE; ++e) {
-                const int sidx = lane + e * kWave;
-                if (sidx < m) perm[first + sidx] = w_out[sidx];
+                for (int e = 0; e < kE; ++e) {
+                    const int sidx = lane + e * kWave;
+                    id[e] = sidx < m ? w_out[sidx] : 0u;
+                    if (sidx < m) perm[first + sidx] = id[e];
+                }
+                if (y_gather) {   // this bin's phases are in the window: their slab entries may go
+                    double v[kE];
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) v[e] = y_gather[id[e]];
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) if (lane + e * kWave < m) g_ph[first + lane + e * kWave] = v[e];
+                    if (w_gather) {
+#pragma unroll
+                        for (int e = 0; e < kE; ++e) v[e] = w_gather[id[e]];
+#pragma unroll
+                        for (int e = 0; e < kE; ++e) if (lane + e * kWave < m) w_out_g[first + lane + e * kWave] = v[e];
+                    }
+                }
             }
             __syncthreads();
         }
@@ -1299,7 +1319,8 @@ tls_search_kernel(const SearchArgs a) {
             // series in HBM: the two-level sort with sequential HBM accesses, unless a phase bin overflows
             if (a.sort2)
                 sorted = fold_and_sort_tiled(a.t, n, period, 0.0, ph_orig, reinterpret_cast<unsigned int*>(idx_tmp),
-                                             reinterpret_cast<unsigned int*>(perm), smem + a.hdr_bytes, pc);
+                                             reinterpret_cast<unsigned int*>(perm), smem + a.hdr_bytes, pc,
+                                             a.n_curves == 1 ? a.y : nullptr, UNIFORM_W ? nullptr : a.w, regW);
         }
         if (!sorted) fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc);
         // survey mode: the permutation depends on (t, period) only, so every light curve of the
@@ -1316,7 +1337,8 @@ tls_search_kernel(const SearchArgs a) {
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  Three
         // elements per step: their global reads (L2 latency) are in flight together -- the compiler
         // cannot overlap them itself, the LDS store of one may alias the index read of the next
-        for (int k = tid; k < n; k += 3 * nt) {
+        const bool gathered = !RESIDENT && sorted && a.n_curves == 1;   // the two-level sort did it on the way
+        for (int k = tid; k < (gathered ? 0 : n); k += 3 * nt) {
             const int k1 = k + nt, k2 = k + 2 * nt;
             const int i0 = (int)perm_use[k];
             const int i1 = k1 < n ? (int)perm_use[k1] : i0;
