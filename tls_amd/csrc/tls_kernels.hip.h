@@ -124,6 +124,15 @@ __device__ __forceinline__ void load_taps(const double* p, double (&x)[kU]) {
     }
 }
 
+// Ordering point for code in which every wavefront works on LDS (and HBM) of its own: the memory
+// operations of the wave issued so far are complete before any later one starts.  No other wave
+// is waited for.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
 // dst[k] = src[k] for k in [0, count), all threads of the workgroup, four global reads in flight per
 // thread (the compiler does not overlap them itself: the store of one may alias the read of the next)
 __device__ __forceinline__ void copy_in_flight4(double* dst, const double* src, int count) {
@@ -1157,10 +1166,10 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                     fb[e] = f < 0 ? 0 : (f < kSort2BinCap - 1 ? f : kSort2BinCap - 1);
                 }
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int e = 0; e < kE; ++e) if (lane + e * kWave < m) atomicAdd(&w_cnt[fb[e]], 1u);
-            __syncthreads();
+            wave_sync();
             {   // exclusive scan of the kSort2BinCap counters of this window: kE consecutive per lane
                 unsigned int c[kE], local = 0;
 #pragma unroll
@@ -1175,13 +1184,13 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 #pragma unroll
                 for (int e = 0; e < kE; ++e) { w_cnt[lane * kE + e] = run; run += c[e]; }
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int e = 0; e < kE; ++e) {
                 const int j = lane + e * kWave;
                 if (j < m) w_slot[atomicAdd(&w_cnt[fb[e]], 1u)] = (unsigned int)j;   // w_cnt[f] becomes the END of bucket f
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int e = 0; e < kE; ++e) {
                 const int sidx = lane + e * kWave;
@@ -1201,7 +1210,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                     w_out[lo + rank] = id;
                 }
             }
-            __syncthreads();
+            wave_sync();
             {
                 unsigned int id[kE];
 #pragma unroll
@@ -1224,9 +1233,10 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
     }
+    __syncthreads();   // the permutation (and the gathered flux) is complete
     pc.mark(3);
     return true;
 }
