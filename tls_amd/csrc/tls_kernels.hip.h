@@ -648,8 +648,34 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
         int* const wave_end_m = reinterpret_cast<int*>(cs->dtot);   // dtot is idle since the end of phase A
         if (lane == kWave - 1) { cs->seg_tot[wave] = inc; wave_end_m[wave] = m_hi; }
         __syncthreads();
+        // prefix over the wave totals: every wave scans them itself (lane v holds wave v's total), a
+        // log-step scan instead of a chain of up to 15 dependent LDS reads and combines
         SegAcc pre; pre.map.i0 = 0.0; pre.map.i1 = 0.0; pre.cnt = 0; pre.reset = 0;
-        for (int v = 0; v < wave; ++v) pre = seg_combine(pre, cs->seg_tot[v], binade_constants(wave_end_m[v]));
+        if (nw <= 8) {   // few waves: the plain chain is shorter than the scan's fixed rounds
+            for (int v = 0; v < wave; ++v) pre = seg_combine(pre, cs->seg_tot[v], binade_constants(wave_end_m[v]));
+        } else {
+            SegAcc w_inc = pre;
+            int w_m = 0;
+            if (lane < nw) { w_inc = cs->seg_tot[lane]; w_m = wave_end_m[lane]; }
+            const BinadeD w_b = binade_constants(w_m);   // the binade wave `lane` ends in
+#pragma unroll
+            for (int dlt = 1; dlt < kMaxWaves; dlt <<= 1) {
+                SegAcc o;
+                o.map.i0 = __shfl_up(w_inc.map.i0, dlt, kWave);
+                o.map.i1 = __shfl_up(w_inc.map.i1, dlt, kWave);
+                o.cnt = __shfl_up(w_inc.cnt, dlt, kWave);
+                o.reset = __shfl_up(w_inc.reset, dlt, kWave);
+                if (lane >= dlt && lane < nw) w_inc = seg_combine(o, w_inc, w_b);
+            }
+            // the inclusive prefix of wave - 1 is this wave's exclusive one
+            const int src = wave > 0 ? wave - 1 : 0;
+            SegAcc got;
+            got.map.i0 = lane_value(w_inc.map.i0, src);
+            got.map.i1 = lane_value(w_inc.map.i1, src);
+            got.cnt = lane_value(w_inc.cnt, src);
+            got.reset = lane_value(w_inc.reset, src);
+            if (wave > 0) pre = got;
+        }
         {
             SegAcc ex;
             ex.map.i0 = __shfl_up(inc.map.i0, 1, kWave);
