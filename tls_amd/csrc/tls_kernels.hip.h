@@ -1173,6 +1173,21 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
         unsigned int* w_slot = w_cnt + kSort2BinCap;
         unsigned int* w_out = w_slot + kSort2BinCap;
         constexpr int kE = kSort2BinCap / kWave;   // entries per lane
+        // the points of a wave's NEXT bin are requested before the current one is sorted: their HBM
+        // latency hides behind the sort
+        double nx_ph[kE];
+        unsigned int nx_idx[kE];
+        {
+            const int b = wave;
+            const unsigned int first = b < B ? g_start[b] : 0u;
+            const int m = b < B ? (int)(g_start[b + 1] - first) : 0;
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const int j = lane + e * kWave;
+                nx_ph[e] = j < m ? g_ph[first + j] : 0.0;
+                nx_idx[e] = j < m ? g_idx[first + j] : 0u;
+            }
+        }
         for (int b0 = 0; b0 < B; b0 += nw) {
             const int b = b0 + wave;
             const unsigned int first = b < B ? g_start[b] : 0u;
@@ -1185,11 +1200,22 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 w_cnt[j] = 0;
                 fb[e] = 0;
                 if (j < m) {
-                    const double ph = g_ph[first + j];
+                    const double ph = nx_ph[e];
                     w_ph[j] = ph;
-                    w_idx[j] = g_idx[first + j];
+                    w_idx[j] = nx_idx[e];
                     const int f = (int)((ph * B_d - (double)b) * (double)kSort2BinCap);
                     fb[e] = f < 0 ? 0 : (f < kSort2BinCap - 1 ? f : kSort2BinCap - 1);
+                }
+            }
+            {
+                const int bn = b + nw;
+                const unsigned int first_n = bn < B ? g_start[bn] : 0u;
+                const int m_n = bn < B ? (int)(g_start[bn + 1] - first_n) : 0;
+#pragma unroll
+                for (int e = 0; e < kE; ++e) {
+                    const int j = lane + e * kWave;
+                    nx_ph[e] = j < m_n ? g_ph[first_n + j] : 0.0;
+                    nx_idx[e] = j < m_n ? g_idx[first_n + j] : 0u;
                 }
             }
             wave_sync();
