@@ -81,8 +81,8 @@ class transitleastsquares(object):
         periods, durations, lc_cache_overview, lc_arr = self._build_grids()
         if self.verbose:
             print("Searching " + str(len(self.y)) + " data points, " + str(len(periods))
-                  + " periods from " + str(round(min(periods), 3)) + " to "
-                  + str(round(max(periods), 3)) + " days")
+                  + " periods from " + str(round(numpy.min(periods), 3)) + " to "
+                  + str(round(numpy.max(periods), 3)) + " days")
 
         # The reference shuffles the search order with the GLOBAL numpy RNG
         # (main.py:129-130); the GPU does not need an order, but callers that
@@ -109,7 +109,7 @@ class transitleastsquares(object):
         # not rounded up to even here, unlike the search (main.py:201)
         maxwidth_in_samples = int(numpy.max(durations) * numpy.size(self.t))
 
-        no_transits_were_fit = max(chi2) == min(chi2)
+        no_transits_were_fit = numpy.max(chi2) == numpy.min(chi2)
         if no_transits_were_fit:
             warnings.warn('No transit were fit. Try smaller "transit_depth_min"')
 

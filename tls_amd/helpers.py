@@ -17,7 +17,7 @@ def resample(time, flux, factor):
     """Linear re-binning of a light curve onto len(flux)/factor equidistant
     points (reference helpers.py:8-15)."""
     n_out = int(len(flux) / factor)
-    time_resampled = numpy.linspace(min(time), max(time), n_out)
+    time_resampled = numpy.linspace(numpy.min(time), numpy.max(time), n_out)
     flux_resampled = interp1d(time_resampled, time)(flux)
     return time_resampled, flux_resampled
 

@@ -174,7 +174,7 @@ def final_T0_fit(signal, depth, t, y, dy, period, T0_fit_margin, show_progress_b
 def all_transit_times(T0, t, period):
     """Mid-transit times T0 + k*period inside the time series
     (reference stats.py:244-261)."""
-    first = T0 + period if T0 < min(t) else T0
+    first = T0 + period if T0 < numpy.min(t) else T0
     end = numpy.min(t) + (numpy.max(t) - numpy.min(t))
     times = [first]
     while times[-1] + period < end:
@@ -191,7 +191,7 @@ def calculate_fill_factor(t):
     """Fraction of cadences present, assuming a constant cadence
     (reference stats.py:294-301)."""
     cadence = numpy.median(numpy.diff(t))
-    return (len(t) - 1) / ((max(t) - min(t)) / cadence)
+    return (len(t) - 1) / ((numpy.max(t) - numpy.min(t)) / cadence)
 
 
 def calculate_transit_duration_in_days(t, period, transit_times, duration):
@@ -212,8 +212,8 @@ def model_lightcurve(transit_times, period, t, model_transit_single):
     ys = numpy.tile(model_transit_single, len(epochs))
     if numpy.all(numpy.isnan(xs)):
         return None, None
-    start = numpy.nanargmax(xs > min(t))
-    stop = numpy.nanargmax(xs > max(t))
+    start = numpy.nanargmax(xs > numpy.min(t))
+    stop = numpy.nanargmax(xs > numpy.max(t))
     return ys[start:stop], xs[start:stop]
 
 
@@ -226,9 +226,10 @@ def count_stats(t, y, transit_times, transit_duration_in_days):
     after, over epochs fully inside the data (reference stats.py:304-342)."""
     n_in = n_after = n_before = 0
     d = transit_duration_in_days
+    t_first, t_last = numpy.min(t), numpy.max(t)   # (the builtins walk the array element by element)
     for mid in transit_times:
         edges = (mid - 1.5 * d, mid - 0.5 * d, mid + 0.5 * d, mid + 1.5 * d)
-        if edges[0] > min(t) and edges[3] < max(t):
+        if edges[0] > t_first and edges[3] < t_last:
             n_before += len(y[_points_between(t, edges[0], edges[1])])
             n_in += len(y[_points_between(t, edges[1], edges[2])])
             n_after += len(y[_points_between(t, edges[2], edges[3])])
