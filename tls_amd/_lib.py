@@ -156,6 +156,7 @@ class Context(object):
                                + self._lib.tls_last_error(None).decode())
         self.device = int(device)
         self._n_periods = 0
+        self._plan_key = None     # what the device currently holds a prepared plan for (see search)
 
     # -- plumbing
     def close(self):
@@ -191,8 +192,26 @@ class Context(object):
 
     # -- one-shot
     def search(self, t, y, dy, periods, table, params, count_work=False):
-        """chi2, row, depth (and counters dict) for every period, in `periods` order."""
-        self.prepare(t, y, dy, periods, table, params)
+        """chi2, row, depth (and counters dict) for every period, in `periods` order.
+
+        Consecutive searches on the same time stamps, period list, template table and parameters
+        (a survey, or repeated power() calls) reuse the prepared plan: only the flux and the
+        weights are replaced (tls_update_flux), the host planning and the uploads are skipped."""
+        t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)
+        key = (len(t), hash(t.tobytes()), len(periods), hash(periods.tobytes()),
+               hash(_f8(table.values).tobytes()), hash(_i8(table.width).tobytes()),
+               hash(_f8(table.overshoot).tobytes()), tuple(sorted((k, float(v)) for k, v in params.items())),
+               os.environ.get("TLS_PRUNE"), os.environ.get("TLS_PRUNE_MIN_LIVE"), os.environ.get("TLS_SORT2"))
+        reused = False
+        if key == self._plan_key and len(y) == len(t) == len(dy):
+            try:
+                self.update_flux(y, dy)
+                reused = True
+            except RuntimeError:     # e.g. uniform dy after per-point dy: the plan differs after all
+                reused = False
+        if not reused:
+            self.prepare(t, y, dy, periods, table, params)
+            self._plan_key = key
         self.execute(count_work=count_work)
         return self.fetch(with_counters=True)
 
@@ -205,6 +224,7 @@ class Context(object):
         dy_batch = numpy.ascontiguousarray(dy_batch, dtype=numpy.float64)
         if y_batch.ndim != 2 or y_batch.shape != dy_batch.shape or y_batch.shape[1] != len(t):
             raise ValueError("y_batch and dy_batch must both have shape [n_curves, len(t)]")
+        self._plan_key = None
         arrays, tm, pr = self._pack(table, params)
         n_c, n_p = y_batch.shape[0], len(periods)
         chi2 = numpy.empty((n_c, n_p), dtype=numpy.float64)
@@ -217,6 +237,7 @@ class Context(object):
         return chi2, row, depth
 
     def prepare(self, t, y, dy, periods, table, params):
+        self._plan_key = None
         t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)
         if not (t.ndim == y.ndim == dy.ndim == 1 and len(t) == len(y) == len(dy)):
             raise ValueError("t, y, dy must be 1-dimensional and of equal length")
