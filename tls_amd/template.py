@@ -18,15 +18,31 @@ from . import transit_model
 from .interp import interp1d
 
 
+_CURVES = {}  # shape parameters -> (t, flux, first in-transit sample): the model is the costly part
+
+
+def _supersampled_curve(per, rp, a, inc, ecc, w, u, limb_dark):
+    """The template planet's light curve over +-0.5 d around mid-transit (transit.py:11-25).  It
+    depends on the shape parameters only, and power() asks for it several times per call."""
+    key = (float(per), float(rp), float(a), float(inc), float(ecc), float(w),
+           tuple(float(x) for x in u), str(limb_dark))
+    hit = _CURVES.get(key)
+    if hit is None:
+        half = 0.5
+        t = numpy.linspace(-half, half, C.SUPERSAMPLE_SIZE)
+        flux = transit_model.light_curve(t, 0, per, rp, a, inc, ecc, w, u, limb_dark)
+        first = int(numpy.argmax(flux < 1))  # first in-transit sample
+        if len(_CURVES) >= 8:
+            _CURVES.pop(next(iter(_CURVES)))
+        hit = _CURVES[key] = (t, flux, first)
+    return hit
+
+
 def reference_transit(samples, per, rp, a, inc, ecc, w, u, limb_dark):
     """In-transit part of the template planet's light curve, resampled to
     `samples` points and rescaled to depth 1 (0 = bottom, 1 = out of transit).
     Reference transit.py:8-42."""
-    half = 0.5  # the curve is evaluated over +-0.5 d around mid-transit
-    t = numpy.linspace(-half, half, C.SUPERSAMPLE_SIZE)
-    flux = transit_model.light_curve(t, 0, per, rp, a, inc, ecc, w, u, limb_dark)
-
-    first = int(numpy.argmax(flux < 1))  # first in-transit sample
+    t, flux, first = _supersampled_curve(per, rp, a, inc, ecc, w, u, limb_dark)
     # the slice is one sample longer on the egress side (transit.py:29-30)
     in_flux = flux[first: -first + 1]
     in_time = t[first: -first + 1]
