@@ -1032,7 +1032,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
 //   lds: at least sort2_lds_bytes(n) bytes.  Returns false (all threads alike) when a coarse bin
 //   overflows its LDS window (phases piled up, e.g. a period commensurate with the cadence): the
 //   caller then falls back to fold_and_sort.
-constexpr int kSort2Chunk = 8192;     // points bucketed per pass-1 round
+constexpr int kSort2Chunk = 10240;    // points bucketed per pass-1 round
 constexpr int kSort2BinCap = 384;     // points one wavefront can sort in its LDS window
 constexpr int kSort2BinMean = 160;    // target points per coarse bin
 constexpr int kSort2MaxBins = 1024;
