@@ -492,10 +492,10 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         ctx->nb = (int)std::min<int64_t>(n, (int64_t)((kLdsPerCU - hdr) / 4));
         const size_t halo = (size_t)W + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
         const size_t unit = (size_t)tlsdev::kR * tlsdev::kWave;  // tile bounds: multiples of 320
-        // staged per tile: e (or e*w), w for per-point weights, and the prefix sum C if that does
-        // not shrink the tiles too much (C is then read from the HBM slab through L2): with a
-        // window as wide as the LDS (Kepler-size series) most of a tile is halo, and halving the
-        // staged arrays cuts the number of tiles many times over
+        // staged per tile: e (or e*w), w for per-point weights, and the prefix sum C beside them only
+        // if that costs no extra tiles.  Otherwise C takes the samples' place for the predicate pass
+        // and the samples follow for the dot products: two stagings per tile, but fewer and larger
+        // tiles (TESS: 2 instead of 3, -8 %; Kepler-size: 7 instead of 82, most of a tile is halo)
         const size_t buffers_c = (uniform ? 1 : 2) + 1, buffers_noc = buffers_c - 1;
         auto tiles_for = [&](size_t buffers) -> size_t {
             const size_t cap = (kLdsPerCU - hdr) / 8 / buffers;
@@ -505,7 +505,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         };
         const size_t tiles_c = tiles_for(buffers_c), tiles_noc = tiles_for(buffers_noc);
         if (tiles_noc == 0) return fail(ctx, TLS_E_ARG, "widest transit window does not fit the LDS tile");
-        ctx->stage_c = tiles_c != 0 && tiles_c <= 4 * tiles_noc;
+        ctx->stage_c = tiles_c != 0 && tiles_c <= tiles_noc;
+        if (const char* env = std::getenv("TLS_STAGE_C")) ctx->stage_c = tiles_c != 0 && std::atoi(env) != 0;   // A/B switch
         const size_t buffers = ctx->stage_c ? buffers_c : buffers_noc;
         const size_t cap_doubles = (kLdsPerCU - hdr) / 8 / buffers;
         const size_t cap_tile = (cap_doubles - halo) / unit * unit;
