@@ -47,7 +47,7 @@
 // handful of live chunks are re-listed and evaluated one window per lane.
 //
 // Variants (template parameters): RESIDENT / tiled series, UNIFORM_W / per-point weights, STAGE_C
-// (tiled: prefix sum staged into LDS or read from the slab), WITH_PRUNING (noisy light curves: an
+// (tiled: prefix sum staged beside the samples, or in their place for the predicate pass), WITH_PRUNING (noisy light curves: an
 // exact branch-and-bound step drops the cells that cannot win before phase 3b, see cell_bound).
 // Survey batches (SearchArgs::n_curves > 1): the fold + sort of a period is shared by all light
 // curves of the launch; phases 2-4 run per curve.
@@ -1492,7 +1492,7 @@ tls_search_kernel(const SearchArgs a) {
         const int p_hi = p_lo + tile_len;
         const double* e_base = regA;   // e_base[b] = sample b of e (or e*w)
         const double* w_base = regW;
-        const double* c_base = regB;   // c_base[i] = C[i] (STAGE_C: the tile's LDS copy)
+        const double* c_base = regB;   // c_base[i] = C[i] (tiled: the tile's LDS copy while phase 3a runs)
         if constexpr (!RESIDENT) {
             double* tile_e = reinterpret_cast<double*>(smem + a.hdr_bytes);
             const int staged = a.tile_len + a.tile_halo;
