@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the TLS grid-search hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config k2_90d] [--mode survey|shard]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config k2_90d]
 
 N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
 (one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Rank 0
@@ -10,23 +10,30 @@ prints ONE JSON line.
 A "step" is one pass of the hot path over one batch of synthetic input that is already
 resident in HBM: the full period x duration x T0 grid search of BASELINE.json's config 2 (90 d,
 30-min cadence, default grids: 9679 periods, 8.77e8 trial cells).
-  * survey mode (default; BASELINE config 5): every GPU searches one light curve per step
-    (its own seed); the per-period (chi2, row, depth) triples of all K steps are exchanged with
-    ONE RCCL all-gather at the end of the timed region, so that every rank holds the whole
-    batch -> per-GPU work is fixed, "scaling": "weak".
-  * shard mode (BASELINE config 4 layout): ONE light curve per step, its period grid block-
-    partitioned over the GPUs by cumulative cell cost, one RCCL all-gather at the end
-    -> "scaling": "strong".
+  * `value` (survey layout, BASELINE config 5): every GPU searches one light curve per step (its
+    own seed); the per-period (chi2, row, depth) triples of all K steps are exchanged with ONE
+    RCCL all-gather at the end of the timed region, so that every rank holds the whole batch ->
+    per-GPU work is fixed, "scaling": "weak".
+  * N > 1 additionally times the PERIOD-SHARD layout north_star describes (BASELINE config 4): ONE
+    light curve per step, its period grid block-partitioned over the GPUs by cumulative cell cost,
+    one RCCL all-gather per light curve -> strong scaling; reported under "shard" for config 2 and
+    for the TESS 2-min configuration, with max/mean trial cells per rank.
 value = trial cells of the whole job / wall time of the K timed steps (barrier + device sync on
 both sides, max over ranks).  `roofline` prices the search kernel against HBM with the
 algorithmic bytes of SURVEY.md 8(d) (24*N + 24 B per period) and its HIP-event duration, and
-also reports the fp64 vector rate -- this path is compute/LDS bound, not HBM bound.
+also reports the fp64 vector rate three ways (reference flops, issued FMAs, useful FMAs) -- the
+LDS-resident path is compute/LDS bound, not HBM bound.  At N = 1 the line also carries,
+measured outside the timed region: the one-shot call with host buffers (planning + H2D + kernel +
+D2H), the Kepler 4-yr and TESS 27-d configurations (kernel time + their own HBM
+roofline: these two ARE HBM-staged), the 1024-curve survey throughput including transfers, the
+500 ppm variant and the wall clock of the whole power() call.
 `cpu_baseline` is the C oracle (a port of core.py, OpenMP over periods) timed on this box's
 host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -126,6 +133,214 @@ def _comm_init_with_deadline(ctx, world, rank, uid, deadline_s):
 _STUCK = []
 
 
+def recorded_traffic(config, n_periods):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json:
+    one record per configuration, each labelled with the commit it was measured at).  bench.py
+    cannot run the counter passes itself (they need their own rocprofv3 runs)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None, "no profiles/hbm_traffic.json"
+    rec = json.load(open(path))
+    recs = rec.get("records", [rec] if "config" in rec else [])
+    for r in recs:
+        if r.get("config") == config and r.get("n_periods"):
+            scale = n_periods / float(r["n_periods"])   # a period sample scales to the launch measured here
+            return r.get("bytes_per_launch") * scale, "rocprofv3 PMC passes (%s) of commit %s, %d periods%s" % (
+                r.get("source", "FETCH_SIZE x2 + WRITE_SIZE"), r.get("commit", "unknown"), r["n_periods"],
+                "" if scale == 1.0 else ", scaled by periods to this launch")
+    return None, "no record for %s" % config
+
+
+class Harness(object):
+    """One rank's view of the job: context, collective, barrier-bracketed timing."""
+
+    def __init__(self, args):
+        self.rank, self.world, local_rank, addr, port = rendezvous.env_layout()
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                         "(--nproc-per-node %d)" % (args.gpus, args.gpus))
+            args.gpus = self.world
+        n_dev = _lib.device_count()
+        self.ctx = _lib.Context(local_rank % max(n_dev, 1))
+        self.channel = None
+        self.collective = "none"
+        if self.world > 1:
+            # rank 0's RCCL unique id travels over the host channel; every rank then tries to join the
+            # communicator.  If RCCL cannot be brought up on this box on ANY rank, all ranks fall back to
+            # the host channel for the (tiny) result exchange and the output says so.
+            self.channel = rendezvous.HostChannel(self.rank, self.world, addr, port)
+            uid = self.channel.allgather_bytes(self.ctx.comm_unique_id() if self.rank == 0 else b"")[0]
+            ok, why = _comm_init_with_deadline(self.ctx, self.world, self.rank, uid, RCCL_INIT_DEADLINE_S)
+            if self.channel.all_true(ok):
+                self.collective = "rccl"
+            else:
+                self.collective = "host-tcp fallback (RCCL init failed: %s)" % (why or "on another rank")
+                if ok:
+                    self.ctx.comm_destroy()
+        elif args.force_collective:
+            self.ctx.comm_init(1, 0, self.ctx.comm_unique_id())
+            self.collective = "rccl"
+
+    def barrier(self):
+        if self.collective == "rccl":
+            self.ctx.comm_barrier()
+        elif self.channel is not None:
+            self.channel.barrier()
+
+    def reduce_max(self, v):
+        if self.collective == "rccl":
+            return self.ctx.comm_max(v)
+        return self.channel.max(v) if self.channel is not None else v
+
+    def timed(self, step, finish, steps, warmup, prefill=0):
+        """W untimed + exactly K timed steps, barrier + device sync on both sides, max over ranks.
+        Returns (seconds, mean search-kernel ms per launch from HIP events on the search stream)."""
+        ctx = self.ctx
+        for i in range(prefill):
+            step(i)
+        for i in range(warmup):
+            step(i)
+        finish()
+        ctx.synchronize()
+        ctx.kernel_timing(reset=True)
+        self.barrier()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        finish()
+        ctx.synchronize()
+        self.barrier()
+        ctx.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms, launches = ctx.kernel_timing(reset=True)
+        kernel_ms = kernel_ms / max(launches, 1)
+        if self.world > 1:
+            elapsed = self.reduce_max(elapsed)
+            kernel_ms = self.reduce_max(kernel_ms)
+        return elapsed, kernel_ms
+
+
+def run_survey(h, args, inp):
+    """Survey layout: one full-grid search of this rank's light curve per step."""
+    ctx = h.ctx
+    periods = inp["periods"]
+    ctx.prepare(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
+    count_per_rank = len(periods)
+    # the results of all K steps are exchanged with ONE all-gather at the end of the timed region
+    # (north_star: "a single RCCL all-gather ... at the end"): per step the triples are only parked in
+    # a slot of a device buffer, so no rank waits for another between two light curves
+    staged = h.collective == "rccl"
+    n_slots = max(args.steps, 1)
+
+    def step(i):
+        ctx.execute()
+        if staged:
+            ctx.comm_stage_results(count_per_rank, i % n_slots, n_slots)
+        elif h.channel is not None:
+            c, r, d = ctx.fetch()
+            h.channel.allgather_bytes(c.tobytes() + r.tobytes() + d.tobytes())
+
+    def finish():
+        if staged:
+            ctx.comm_allgather_staged(count_per_rank, n_slots)
+
+    elapsed, kernel_ms = h.timed(step, finish, args.steps, args.warmup, prefill=n_slots if staged else 0)
+    if staged:  # outside the timed region: one gathered slot on the host
+        g_chi2, g_row, g_depth = ctx.comm_fetch_staged(count_per_rank, n_slots, n_slots - 1, h.world)
+        assert len(g_chi2) == count_per_rank * h.world
+    return elapsed, kernel_ms
+
+
+def run_shard(h, args, config):
+    """Period-shard layout: ONE light curve per step, its period grid block-partitioned by cumulative
+    trial-cell cost (tls_amd/shard.py), one all-gather per light curve."""
+    ctx = h.ctx
+    t, flux, kw = synthetic.config(config, seed=0)
+    inp = synthetic.search_inputs(t, flux, **kw)
+    job = shard.ShardedSearch(h.rank, h.world)
+    lo, hi = job.plan(inp["t"], inp["periods"], inp["table"], inp["params"])
+    ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"][lo:hi], inp["table"], inp["params"])
+    c = job.count_per_rank
+
+    def step(i):
+        ctx.execute()
+        if h.collective == "rccl":
+            # pack + ncclAllGather are enqueued behind the kernel: every rank holds the whole result
+            # in HBM, and the next search starts without a host round trip
+            ctx.comm_allgather_device(c)
+        elif h.channel is not None:
+            cc, rr, dd = ctx.fetch()
+            h.channel.allgather_bytes(cc.tobytes() + rr.tobytes() + dd.tobytes())
+
+    elapsed, kernel_ms = h.timed(step, lambda: None, args.steps, args.warmup)
+    argmin = None
+    if h.collective == "rccl":
+        g = ctx.comm_fetch_gathered(c, h.world)
+        chi2 = shard.assemble(g[0], job.bounds, c)
+        assert len(chi2) == len(inp["periods"])
+        argmin = int(numpy.argmin(chi2))
+    cells = numpy.array([numpy.sum(job.costs[job.bounds[r]:job.bounds[r + 1]]) for r in range(h.world)], dtype=float)
+    total = float(numpy.sum(job.costs))
+    return {"config": config, "points": len(inp["t"]), "periods": len(inp["periods"]), "trial_cells": total,
+            "value": total * args.steps / elapsed, "unit": "trial cells/s", "scaling": "strong",
+            "ms_per_step": 1e3 * elapsed / args.steps, "kernel_ms_max_rank": kernel_ms,
+            "cells_per_rank_max": float(cells.max()), "cells_per_rank_mean": float(cells.mean()),
+            "imbalance_max_over_mean": float(cells.max() / cells.mean()),
+            "periods_per_rank": [int(job.bounds[r + 1] - job.bounds[r]) for r in range(h.world)],
+            "argmin_period_index": argmin}
+
+
+def large_config(ctx, name, reps):
+    """Kernel time of one of the HBM-staged configurations (Kepler 4 yr, TESS 27 d) at its full
+    grid, with its own HBM roofline: algorithmic bytes = periods x (24 N + 24) B."""
+    t, flux, kw = synthetic.config(name, seed=0)
+    inp = synthetic.search_inputs(t, flux, **kw)
+    t0 = time.perf_counter()
+    ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+    prep_s = time.perf_counter() - t0
+    info = ctx.plan_info()
+    ctx.execute()
+    chi2 = ctx.fetch()[0]
+    ms = ctx.execute_timed(reps)
+    n, n_per = len(inp["t"]), len(inp["periods"])
+    algo = n_per * (24 * n + 24)
+    achieved = algo / (ms * 1e-3) / 1e9
+    traffic, source = recorded_traffic(name, n_per)
+    return {"points": n, "periods": n_per, "trial_cells": info["grid_cells"], "kernel_ms": ms,
+            "trial_cells_per_s": info["grid_cells"] / (ms * 1e-3), "host_prepare_ms": 1e3 * prep_s,
+            "lds_resident": info["resident"], "argmin_period_index": int(numpy.argmin(chi2)),
+            "best_period": float(inp["periods"][int(numpy.argmin(chi2))]),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo,
+                         "traffic": traffic, "traffic_source": source}}
+
+
+def survey_1024(ctx, n_curves):
+    """BASELINE config 5 on one GPU: n_curves light curves (seeds 0..) of config 2 through ONE
+    tls_search_batch call, host buffers in, host buffers out (transfers and host passes included)."""
+    from tls_amd import survey
+    t, f0, kw = synthetic.config("k2_90d", seed=0)
+    fluxes = numpy.stack([synthetic.config("k2_90d", seed=s)[1] for s in range(n_curves)])
+    survey.search_batch(t, fluxes[:64], context=ctx, **kw)   # warm: plan buffers, pinned staging
+    t0 = time.perf_counter()
+    periods, chi2, row, depth = survey.search_batch(t, fluxes, context=ctx, **kw)
+    wall = time.perf_counter() - t0
+    best = numpy.argmin(chi2, axis=1)
+    return {"curves": n_curves, "wall_s": wall, "curves_per_s": n_curves / wall,
+            "ms_per_curve": 1e3 * wall / n_curves, "periods": len(periods),
+            "argmin_seed0": int(best[0]), "note": "tls_search_batch, host buffers in and out"}
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"],
+                                       stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,207 +348,158 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="k2_90d", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--sigma", type=float, default=None, help="noise override (e.g. 500e-6)")
-    ap.add_argument("--mode", default="survey", choices=["survey", "shard"])
+    ap.add_argument("--mode", default="both", choices=["both", "survey", "shard"],
+                    help="N > 1: which layouts to time (value is always the survey layout when it runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the untimed extras (500 ppm variant, power() wall clock, counted pass) so "
-                         "that a profiler sees only the timed workload's launches")
+                    help="skip the untimed extras (other configurations, 500 ppm variant, power() wall clock, "
+                         "counted pass) so that a profiler sees only the timed workload's launches")
+    ap.add_argument("--survey-curves", type=int, default=1024)
     ap.add_argument("--force-collective", action="store_true",
                     help="1-GPU runs: go through the RCCL code path with a one-rank communicator")
     args = ap.parse_args()
 
-    rank, world, local_rank, addr, port = rendezvous.env_layout()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "(--nproc-per-node %d)" % (args.gpus, args.gpus))
-        args.gpus = world
-    n_dev = _lib.device_count()
-    ctx = _lib.Context(local_rank % max(n_dev, 1))
-    channel = None
-    collective = "none"
-    if world > 1:
-        # rank 0's RCCL unique id travels over the host channel; every rank then tries to join the
-        # communicator.  If RCCL cannot be brought up on this box on ANY rank, all ranks fall back to
-        # the host channel for the (tiny) result exchange and the output says so.
-        channel = rendezvous.HostChannel(rank, world, addr, port)
-        uid = channel.allgather_bytes(ctx.comm_unique_id() if rank == 0 else b"")[0]
-        ok, why = _comm_init_with_deadline(ctx, world, rank, uid, RCCL_INIT_DEADLINE_S)
-        if channel.all_true(ok):
-            collective = "rccl"
-        else:
-            collective = "host-tcp fallback (RCCL init failed: %s)" % (why or "on another rank")
-            if ok:
-                ctx.comm_destroy()
+    h = Harness(args)
+    ctx, rank, world = h.ctx, h.rank, h.world
 
-    # ---- synthetic input, resident in HBM before the timed region --------------------
-    seed = rank if args.mode == "survey" else 0
-    t, flux, kw = synthetic.config(args.config, seed=seed, sigma=args.sigma)
+    # ---- timed region: synthetic input resident in HBM before it starts ---------------
+    t, flux, kw = synthetic.config(args.config, seed=rank, sigma=args.sigma)
     inp = synthetic.search_inputs(t, flux, **kw)
     periods = inp["periods"]
-    if args.mode == "shard" and world > 1:
-        job = shard.ShardedSearch(rank, world)
-        lo, hi = job.plan(inp["t"], periods, inp["table"], inp["params"])
-        my_periods = periods[lo:hi]
-        count_per_rank = job.count_per_rank
-        job_cells = int(numpy.sum(job.costs))
-    else:
-        my_periods = periods
-        count_per_rank = len(periods)
-        job_cells = None
-    ctx.prepare(inp["t"], inp["y"], inp["dy"], my_periods, inp["table"], inp["params"])
+    elapsed = kernel_ms = None
+    if args.mode in ("both", "survey") or world == 1:
+        elapsed, kernel_ms = run_survey(h, args, inp)
     info = ctx.plan_info()
-    if job_cells is None:
-        job_cells = info["grid_cells"] * world  # survey: one full grid per GPU per step
-
-    if world == 1 and args.force_collective:
-        ctx.comm_init(1, 0, ctx.comm_unique_id())
-        collective = "rccl"
-
-    def barrier():
-        if collective == "rccl":
-            ctx.comm_barrier()
-        elif channel is not None:
-            channel.barrier()
-
-    def reduce_max(v):
-        if collective == "rccl":
-            return ctx.comm_max(v)
-        return channel.max(v) if channel is not None else v
-
-    # Survey mode exchanges the results of all K steps with ONE all-gather at the end of the timed
-    # region (north_star: "a single RCCL all-gather ... at the end"): per step the triples are only
-    # parked in a slot of a device buffer, so no rank waits for another between two light curves.
-    # Shard mode searches one light curve per step across all ranks, so its gather is per step.
-    staged = collective == "rccl" and args.mode == "survey"
-    n_slots = max(args.steps, 1)
-
-    def step(i):
-        ctx.execute()
-        if staged:
-            ctx.comm_stage_results(count_per_rank, i % n_slots, n_slots)
-        elif collective == "rccl":
-            # pack + ncclAllGather are enqueued behind the kernel: every rank holds the whole result
-            # in HBM, and the next search starts without a host round trip
-            ctx.comm_allgather_device(count_per_rank)
-        elif channel is not None:
-            c, r, d = ctx.fetch()
-            channel.allgather_bytes(c.tobytes() + r.tobytes() + d.tobytes())
-
-    def finish():
-        if staged:
-            ctx.comm_allgather_staged(count_per_rank, n_slots)
-
-    if staged:   # every slot holds a result before the first gather ships the whole buffer
-        for i in range(n_slots):
-            step(i)
-    for i in range(args.warmup):
-        step(i)
-    finish()
-    ctx.synchronize()
-    ctx.kernel_timing(reset=True)
-    barrier()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    finish()
-    ctx.synchronize()
-    barrier()
-    ctx.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = ctx.kernel_timing(reset=True)
-    if staged:  # outside the timed region: one gathered slot on the host
-        g_chi2, g_row, g_depth = ctx.comm_fetch_staged(count_per_rank, n_slots, n_slots - 1, world)
-        assert len(g_chi2) == count_per_rank * world
-    elif collective == "rccl":
-        g_chi2, g_row, g_depth = ctx.comm_fetch_gathered(count_per_rank, world)
-        assert len(g_chi2) == count_per_rank * world
-    if world > 1:
-        elapsed = reduce_max(elapsed)
-        kernel_ms = reduce_max(kernel_ms)
-
-    # one counted pass (outside the timed region) for the work statistics
-    ctx.execute(count_work=True)
-    chi2, row, depth, counters = ctx.fetch(with_counters=True)
-
-    # secondary figure asked for by SURVEY.md 8(d): the same grid at 500 ppm noise, where 55 % of
-    # the cells pass the depth predicate instead of 11 % (outside the timed region, rank 0 only)
-    noisy = None
-    if rank == 0 and args.sigma is None and args.config == "k2_90d" and not args.no_extras:
-        t5, f5, kw5 = synthetic.config(args.config, seed=0, sigma=500e-6)
-        i5 = synthetic.search_inputs(t5, f5, **kw5)
-        ctx.prepare(i5["t"], i5["y"], i5["dy"], i5["periods"], i5["table"], i5["params"])
-        ctx.execute(count_work=True)
-        c5 = ctx.fetch(with_counters=True)[3]
-        ms5 = ctx.execute_timed(5)
-        noisy = {"sigma_ppm": 500.0, "kernel_ms": ms5, "trial_cells_per_s": c5["grid_cells"] / (ms5 * 1e-3),
-                 "evaluated_fraction": c5["evaluated_cells"] / c5["grid_cells"],
-                 "inner_steps": c5["inner_steps"]}
-
-    # wall clock of the whole drop-in call for one light curve (host buffers in, results object
-    # out: grids, template table, H2D, search, D2H, SDE spectra, device T0 fit, statistics)
-    power_wall_ms = None
-    if rank == 0 and not args.no_extras:
-        import tls_amd
-        model = tls_amd.transitleastsquares(t, flux, verbose=False)
-        best = float("inf")
-        for _ in range(4):
-            t1 = time.perf_counter()
-            model.power(verbose=False, show_progress_bar=False, context=ctx, **kw)
-            best = min(best, time.perf_counter() - t1)
-        power_wall_ms = 1e3 * best
+    shard_out = None
+    if world > 1 and args.mode in ("both", "shard"):
+        shard_out = [run_shard(h, args, args.config)]
+        if args.config != "tess_27d":
+            shard_out.append(run_shard(h, args, "tess_27d"))
+        if elapsed is None:   # --mode shard: the first shard run is the headline
+            elapsed = shard_out[0]["ms_per_step"] * 1e-3 * args.steps
+            kernel_ms = shard_out[0]["kernel_ms_max_rank"]
 
     out = None
     if rank == 0:
+        extras = world == 1 and not args.no_extras
+        # one counted pass (outside the timed region) for the work statistics
+        ctx.prepare(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
+        ctx.execute(count_work=True)
+        chi2, row, depth, counters = ctx.fetch(with_counters=True)
+
+        # the one-shot call a user of the C ABI sees -- host buffers in, host
+        # buffers out: planning + H2D + kernel + D2H (tls_search), best of 5
+        one_shot = None
+        if extras:
+            best = float("inf")
+            for _ in range(5):
+                t1 = time.perf_counter()
+                ctx.prepare(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
+                ctx.execute()
+                ctx.fetch()
+                best = min(best, time.perf_counter() - t1)
+            one_shot = {"ms": 1e3 * best, "trial_cells_per_s": info["grid_cells"] / best,
+                        "what": "tls_prepare + tls_execute + tls_fetch from host buffers (= tls_search): host "
+                                "planning, H2D, kernel, D2H"}
+
+        # the same grid at 500 ppm noise, where 55 % of the cells pass the depth predicate instead of 11 %
+        noisy = None
+        if extras and args.sigma is None and args.config == "k2_90d":
+            t5, f5, kw5 = synthetic.config(args.config, seed=0, sigma=500e-6)
+            i5 = synthetic.search_inputs(t5, f5, **kw5)
+            ctx.prepare(i5["t"], i5["y"], i5["dy"], i5["periods"], i5["table"], i5["params"])
+            ctx.execute(count_work=True)
+            c5 = ctx.fetch(with_counters=True)[3]
+            ms5 = ctx.execute_timed(5)
+            noisy = {"sigma_ppm": 500.0, "kernel_ms": ms5, "trial_cells_per_s": c5["grid_cells"] / (ms5 * 1e-3),
+                     "evaluated_fraction": c5["evaluated_cells"] / c5["grid_cells"],
+                     "inner_steps": c5["inner_steps"]}
+
+        # wall clock of the whole drop-in call for one light curve (host buffers in, results object
+        # out: grids, template table, H2D, search, D2H, SDE spectra, device T0 fit, statistics)
+        power_wall_ms = None
+        if extras:
+            import tls_amd
+            model = tls_amd.transitleastsquares(t, flux, verbose=False)
+            best = float("inf")
+            for _ in range(4):
+                t1 = time.perf_counter()
+                model.power(verbose=False, show_progress_bar=False, context=ctx, **kw)
+                best = min(best, time.perf_counter() - t1)
+            power_wall_ms = 1e3 * best
+
+        other = {}
+        if extras and args.config == "k2_90d":
+            for name, reps in (("tess_27d", 5), ("kepler_4yr", 2)):
+                try:
+                    other[name] = large_config(ctx, name, reps)
+                except Exception as exc:
+                    other[name] = {"error": str(exc)[:300]}
+            try:
+                other["survey_1024"] = survey_1024(ctx, args.survey_curves)
+            except Exception as exc:
+                other["survey_1024"] = {"error": str(exc)[:300]}
+
         n = len(inp["t"])
         ms_per_step = 1e3 * elapsed / args.steps
+        survey_ran = args.mode in ("both", "survey") or world == 1
+        job_cells = info["grid_cells"] * world if survey_ran else shard_out[0]["trial_cells"]
         value = job_cells * args.steps / elapsed
-        kernel_s = 1e-3 * kernel_ms / max(launches, 1)
-        algo_bytes = len(my_periods) * (24 * n + 24)       # B_period per period
+        kernel_s = 1e-3 * kernel_ms
+        algo_bytes = len(periods) * (24 * n + 24)          # B_period per period
         achieved = algo_bytes / kernel_s / 1e9
-        flops = 6.0 * counters["inner_steps"]               # reference flop count, core.py:68-69
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            rec = json.load(open(tpath))
-            if rec.get("config") == args.config and rec.get("n_periods") == len(my_periods):
-                traffic = rec.get("bytes_per_launch")
+        ref_flops = 6.0 * counters["inner_steps"]           # reference flop count, core.py:68-69
+        useful_flops = 2.0 * counters["inner_steps"]        # what the reformulated kernel needs: one FMA per tap
+        issued_flops = 2.0 * counters["issued_fma"]         # what it issues (chunk padding, idle lanes, unroll slack)
+        traffic, traffic_source = recorded_traffic(args.config, len(periods))
         out = {
             "metric": "trial cells/sec (period x duration x T0)",
             "value": value, "unit": "trial cells/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak" if args.mode == "survey" else "strong",
+            "scaling": "weak" if survey_ran else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d points, %d periods x %d durations, %.3e trial cells per "
                                    "light curve; %s" % (
-                                       args.config, n, len(periods), inp["table"].n_rows,
-                                       info["grid_cells"] if args.mode == "survey" else job_cells,
-                                       "survey mode, one light curve per GPU per step, one RCCL "
-                                       "all-gather of all steps' results at the end" if args.mode == "survey" else
+                                       args.config, n, len(periods), inp["table"].n_rows, info["grid_cells"],
+                                       "one light curve per GPU per step (inputs resident in HBM), one RCCL "
+                                       "all-gather of all steps' results at the end" if survey_ran else
                                        "period grid sharded over the GPUs + RCCL all-gather"),
-                       "mode": args.mode, "collective": collective, "sigma_ppm": 1e6 * (args.sigma or synthetic.CONFIGS[args.config][2]),
-                       "light_curves_per_step": world if args.mode == "survey" else 1,
-                       "search_ms_per_light_curve": ms_per_step / (world if args.mode == "survey" else 1),
+                       "mode": "survey" if survey_ran else "shard", "collective": h.collective,
+                       "sigma_ppm": 1e6 * (args.sigma or synthetic.CONFIGS[args.config][2]),
+                       "light_curves_per_step": world if survey_ran else 1,
+                       "search_ms_per_light_curve": ms_per_step / (world if survey_ran else 1),
+                       "one_shot": one_shot,
                        "power_call_wall_ms_per_light_curve": power_wall_ms,
                        "evaluated_cells": counters["evaluated_cells"],
-                       "inner_steps": counters["inner_steps"], "device": ctx.name,
+                       "inner_steps": counters["inner_steps"], "issued_fma": counters["issued_fma"],
+                       "device": ctx.name, "commit": git_head(),
                        "lds_bytes_per_workgroup": info["lds_bytes"], "workgroups": info["n_blocks"],
                        "lds_resident": info["resident"], "noisy_variant": noisy},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "tls_search_kernel", "kernel_ms": 1e3 * kernel_s,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "compute/LDS-bound path: HBM floor is 24*N+24 B per period; see fp64",
-                         "fp64": {"achieved": flops / kernel_s / 1e12, "peak": FP64_VECTOR_PEAK_TF,
-                                  "unit": "TFLOP/s", "frac": flops / kernel_s / 1e12 / FP64_VECTOR_PEAK_TF,
-                                  "flops_per_launch": flops}},
+                         "note": "compute/LDS-bound path: the light curve is L2-resident, the HBM floor is "
+                                 "24*N+24 B per period; fp64 is the binding unit (useful_frac: one FMA per "
+                                 "template tap; issued_frac: FMAs actually issued; reference_frac: the 6 flops "
+                                 "per tap core.py:68-69 spends)",
+                         "fp64": {"peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                                  "useful": useful_flops / kernel_s / 1e12,
+                                  "useful_frac": useful_flops / kernel_s / 1e12 / FP64_VECTOR_PEAK_TF,
+                                  "issued": issued_flops / kernel_s / 1e12,
+                                  "issued_frac": issued_flops / kernel_s / 1e12 / FP64_VECTOR_PEAK_TF,
+                                  "reference": ref_flops / kernel_s / 1e12,
+                                  "reference_frac": ref_flops / kernel_s / 1e12 / FP64_VECTOR_PEAK_TF,
+                                  "lane_efficiency": counters["inner_steps"] / max(counters["issued_fma"], 1)}},
             "argmin_period_index": int(numpy.argmin(chi2)), "chi2_min": float(numpy.min(chi2)),
         }
+        out.update(other)
+        if shard_out is not None:
+            out["shard"] = shard_out
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(inp, info["grid_cells"])
-    barrier()
-    if collective == "rccl":
+    h.barrier()
+    if h.collective == "rccl":
         ctx.comm_destroy()
     if not _STUCK:
         ctx.close()
@@ -346,13 +512,13 @@ def main():
     except OSError:
         pass
     sys.stdout.flush()
-    if channel is not None:
-        channel.barrier()
+    if h.channel is not None:
+        h.channel.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if channel is not None:
-        channel.barrier()
-        channel.close()
+    if h.channel is not None:
+        h.channel.barrier()
+        h.channel.close()
     if _STUCK:  # a helper thread is still inside RCCL: do not wait for it at interpreter exit
         sys.stderr.flush()
         os._exit(0)

@@ -45,6 +45,8 @@ typedef struct tls_counters {
     int64_t evaluated_cells; /* cells that passed mean > transit_depth_min (core.py:58) */
     int64_t inner_steps;     /* template samples multiplied (core.py:67-69) */
     int64_t pd_pairs;        /* (period, duration) pairs searched */
+    int64_t issued_fma;      /* lane-FMAs the chi^2 phase issued for them (chunk padding, idle lanes
+                                and unroll slack included): inner_steps / issued_fma = lane efficiency */
 } tls_counters;
 
 /* Template table = the reference's (lc_cache_overview, lc_arr) of transit.py:98-160,
@@ -126,8 +128,9 @@ int tls_fetch(tls_ctx *ctx, double *out_chi2, int64_t *out_row, double *out_dept
  * milliseconds, measured with HIP events on the context's stream. */
 int tls_execute_timed(tls_ctx *ctx, int reps, double *ms_per_execute);
 /* Sum of the search-kernel durations of all executes since the last reset, from HIP
- * events recorded around each launch on the context's stream; synchronises.  The event
- * pool grows by one pair per execute until reset: reset regularly. */
+ * events recorded around each launch on the context's stream; synchronises.  The events live in
+ * a ring of 64 pairs: with more launches since the last reset, the most recent 64 are summed and
+ * *launches says how many that was. */
 int tls_kernel_timing(tls_ctx *ctx, int reset, double *total_ms, int64_t *launches);
 /* data-independent work of the prepared search (no device work needed). */
 int tls_plan_info(const tls_ctx *ctx, tls_counters *counters, int64_t *lds_bytes,

@@ -64,6 +64,14 @@ class OracleLibrary(object):
                                             ctypes.c_int]
         self.lib.tls_oracle_fold_sort.restype = None
         self.lib.tls_oracle_fold_sort.argtypes = [_F8, ctypes.c_int64, ctypes.c_double, _F8, _I8]
+        self.lib.tls_oracle_final_t0_fit.restype = ctypes.c_int64
+        self.lib.tls_oracle_final_t0_fit.argtypes = [_F8, ctypes.c_int64, ctypes.c_double, _F8, _F8, ctypes.c_int64,
+                                                     ctypes.c_double, ctypes.c_double, _F8, _F8, _F8, ctypes.c_int]
+        self.lib.tls_oracle_t0_residuals.restype = ctypes.c_int
+        self.lib.tls_oracle_t0_residuals.argtypes = [_F8, _F8, ctypes.c_int64, ctypes.c_double, _F8, ctypes.c_int64,
+                                                     _F8, ctypes.c_int64, ctypes.c_int64, _F8, ctypes.c_int]
+        self.lib.tls_oracle_spectra.restype = ctypes.c_int
+        self.lib.tls_oracle_spectra.argtypes = [_F8, ctypes.c_int64, ctypes.c_int64, _F8, _F8, _F8, _F8]
 
     def search(self, t, y, dy, periods, table, transit_depth_min, R_star_min, R_star_max,
                M_star_min, M_star_max, T0_fit_margin, n_threads=0):
@@ -87,6 +95,41 @@ class OracleLibrary(object):
         if rc != 0:
             raise RuntimeError("tls_oracle_search failed with code %d" % rc)
         return chi2, row, depth, counters
+
+    def final_t0_fit(self, signal, depth, t, y, period, T0_fit_margin, n_threads=0):
+        """stats.py:135-204: returns (T0, epochs, residuals) -- the trial grid and the residual of
+        every trial epoch besides the reference's return value."""
+        c = lambda a: numpy.ascontiguousarray(a, dtype=numpy.float64)
+        signal, t, y = c(signal), c(t), c(y)
+        n = len(t)
+        T0 = numpy.zeros(1)
+        epochs, res = numpy.zeros(max(n, 1)), numpy.zeros(max(n, 1))
+        points = self.lib.tls_oracle_final_t0_fit(signal, len(signal), float(depth), t, y, n, float(period),
+                                                  float(T0_fit_margin), T0, epochs, res,
+                                                  int(n_threads) if int(n_threads) > 0 else usable_cores())
+        if points < 0:
+            raise RuntimeError("tls_oracle_final_t0_fit: bad arguments")
+        return float(T0[0]), epochs[:points].copy(), res[:points].copy()
+
+    def t0_residuals(self, t, y, period, signal, epochs, roll, n_threads=0):
+        """Loop body of stats.py:178-195 for every trial epoch (signal already depth-scaled)."""
+        c = lambda a: numpy.ascontiguousarray(a, dtype=numpy.float64)
+        t, y, signal, epochs = c(t), c(y), c(signal), c(epochs)
+        out = numpy.empty(len(epochs))
+        rc = self.lib.tls_oracle_t0_residuals(t, y, len(t), float(period), signal, len(signal), epochs, len(epochs),
+                                              int(roll), out, int(n_threads) if int(n_threads) > 0 else usable_cores())
+        if rc != 0:
+            raise RuntimeError("tls_oracle_t0_residuals: bad arguments")
+        return out
+
+    def spectra(self, chi2, kernel):
+        """stats.py:105-132: SR, power_raw, power, SDE_raw, SDE for an integer median kernel."""
+        chi2 = numpy.ascontiguousarray(chi2, dtype=numpy.float64)
+        n = len(chi2)
+        SR, praw, power, sde = numpy.empty(n), numpy.empty(n), numpy.empty(n), numpy.empty(2)
+        if self.lib.tls_oracle_spectra(chi2, n, int(kernel), SR, praw, power, sde) != 0:
+            raise RuntimeError("tls_oracle_spectra: bad arguments")
+        return SR, praw, power, float(sde[0]), float(sde[1])
 
     def t14(self, R_s, M_s, P, small):
         return self.lib.tls_oracle_t14(R_s, M_s, P, 1 if small else 0)

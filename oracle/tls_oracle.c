@@ -15,6 +15,8 @@
  *   core.py:28-76   lowest_residuals_in_this_duration  -> lowest_residuals()
  *   grid.py:9-32    T14                                -> t14()
  *   main.py:140-196 dispatch over periods + ordered gather -> tls_oracle_search()
+ *   stats.py:135-204 final_T0_fit (+ core.py:9-12 fold)  -> tls_oracle_final_t0_fit()
+ *   stats.py:105-132 spectra, helpers.py:93-108 running_median -> tls_oracle_spectra()
  * It follows the reference statement by statement: sequential summation order,
  * strict '<' comparisons (first trial wins ties), the same predicate, the same
  * 'datapoints' baseline.  Known deviations, all at the 1e-13 level: the reference
@@ -25,7 +27,9 @@
  * run in the build container (tests/golden/search_*.npz, made by
  * tools/gen_golden.py) and (b) the reference's own known-answer tests
  * (tests/test_synthetic.py:50 chi2_min = 8831.654060613922 etc.), see
- * tests/test_oracle_golden.py and tests/test_reference_pins.py.
+ * tests/test_oracle_golden.py and tests/test_power_host.py (constants in tests/pins.py).
+ * The T0 fit is pinned by tests/golden/t0fit_*.npz: the per-epoch residuals the unmodified
+ * reference's final_T0_fit computes, captured by tools/gen_golden_t0fit.py.
  *
  * Build: see oracle/Makefile  (gcc -O2 -fopenmp -shared -fPIC).
  */
@@ -382,8 +386,8 @@ double tls_oracle_t14(double R_s, double M_s, double P, int small) { return t14(
 void tls_oracle_fold_sort(const double *t, int64_t n, double period, double *phase_sorted,
                           int64_t *sort_index)
 {
-    int64_t i, *tmp = (int64_t *)malloc((size_t)n * sizeof(int64_t));
-    double *ph = (double *)malloc((size_t)n * sizeof(double));
+    int64_t i, *tmp = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+    double *ph = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
     for (i = 0; i < n; i++) {
         double x = t[i] / period;
         ph[i] = x - floor(x);
@@ -394,4 +398,193 @@ void tls_oracle_fold_sort(const double *t, int64_t n, double period, double *pha
         phase_sorted[i] = ph[sort_index[i]];
     free(tmp);
     free(ph);
+}
+
+
+/* ---- final T0 fit, stats.py:135-204 ------------------------------------------------------- */
+/* numpy.linspace(start, stop, num): arange(num) * step + start with step = (stop-start)/(num-1),
+ * last element set to stop. */
+static void linspace(double start, double stop, int64_t num, double *out)
+{
+    int64_t k;
+    double delta = stop - start, step;
+    if (num <= 0) return;
+    if (num == 1) { out[0] = start; return; }
+    step = delta / (double)(num - 1);
+    for (k = 0; k < num; k++)
+        out[k] = (step == 0.0 ? ((double)k / (double)(num - 1)) * delta : (double)k * step) + start;
+    out[num - 1] = stop;
+}
+
+/* Loop body of stats.py:178-195 for every trial epoch: fold, stable sort, roll twice, residuals.
+ * `signal` is already scaled to the fitted depth (stats.py:143). */
+static void t0_residuals(const double *t, const double *y, int64_t n, double period, const double *signal,
+                         int64_t dur, const double *epochs, int64_t points, int64_t roll_cadences, double *res,
+                         int n_threads)
+{
+    if (roll_cadences >= n) roll_cadences = 0;                 /* flux[-r:] is everything, flux[:-r] nothing */
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    (void)n_threads;
+#pragma omp parallel
+    {
+        double *ph = (double *)malloc((size_t)n * sizeof(double));
+        double *flux = (double *)malloc((size_t)n * sizeof(double));
+        double *rolled = (double *)malloc((size_t)n * sizeof(double));
+        double *dy = (double *)malloc((size_t)n * sizeof(double));
+        int64_t *idx = (int64_t *)malloc((size_t)n * sizeof(int64_t));
+        int64_t *tmp = (int64_t *)malloc((size_t)n * sizeof(int64_t));
+        int64_t e, j;
+#pragma omp for schedule(dynamic, 4)
+        for (e = 0; e < points; e++) {
+            double Tx = epochs[e], r_in = 0.0, r_out = 0.0;
+            for (j = 0; j < n; j++) {                          /* core.py:9-12 fold */
+                double x = (t[j] - Tx) / period;
+                ph[j] = x - floor(x);
+                idx[j] = j;
+            }
+            merge_sort_idx(ph, idx, tmp, 0, n);                /* stats.py:179 */
+            for (j = 0; j < n; j++) flux[j] = y[idx[j]];       /* stats.py:181 */
+            /* stats.py:190: flux = concatenate([flux[-r:], flux[:-r]]) */
+            for (j = 0; j < n; j++) rolled[j] = flux[(j - roll_cadences + n) % n];
+            /* stats.py:191: dy = concatenate([flux[-r:], flux[:-r]]) of the ROLLED flux (kept quirk) */
+            for (j = 0; j < n; j++) dy[j] = rolled[(j - roll_cadences + n) % n];
+            for (j = 0; j < dur; j++)                          /* stats.py:193 */
+                r_in += ((rolled[j] - signal[j]) * (rolled[j] - signal[j])) / (dy[j] * dy[j]);
+            for (j = dur; j < n; j++)                          /* stats.py:194 */
+                r_out += ((rolled[j] - 1.0) * (rolled[j] - 1.0)) / (dy[j] * dy[j]);
+            res[e] = r_in + r_out;
+        }
+        free(ph); free(flux); free(rolled); free(dy); free(idx); free(tmp);
+    }
+}
+
+/* The loop alone, for a caller-supplied trial grid and depth-scaled signal (what the device kernel
+ * tls_t0_fit computes). */
+int tls_oracle_t0_residuals(const double *t, const double *y, int64_t n, double period, const double *signal,
+                            int64_t dur, const double *epochs, int64_t n_epochs, int64_t roll, double *out,
+                            int n_threads)
+{
+    if (n < 1 || dur < 1 || dur > n || n_epochs < 0 || roll < 0) return -1;
+    t0_residuals(t, y, n, period, signal, dur, epochs, n_epochs, roll, out, n_threads);
+    return 0;
+}
+
+/* signal_in: the chosen template row (depth SIGNAL_DEPTH), `dur` samples; depth: the fitted depth.
+ * Returns the number of trial epochs; *T0_out the first epoch with the strictly smallest residual
+ * (0 when none is finite).  epochs_out / residuals_out (each `n` entries, may be NULL) receive the
+ * trial grid and the residual of every epoch. */
+int64_t tls_oracle_final_t0_fit(const double *signal_in, int64_t dur, double depth, const double *t,
+                                const double *y, int64_t n, double period, double T0_fit_margin,
+                                double *T0_out, double *epochs_out, double *residuals_out, int n_threads)
+{
+    int64_t points, k, i;
+    double *signal, *T0_array, *res, t_min;
+    double scale = TLS_SIGNAL_DEPTH / (1 - depth);             /* stats.py:142 */
+    double residuals_lowest = INFINITY, T0 = 0;
+    if (n < 1 || dur < 1 || dur > n) return -1;
+    signal = (double *)malloc((size_t)dur * sizeof(double));
+    for (k = 0; k < dur; k++) signal[k] = 1 - ((1 - signal_in[k]) / scale);   /* stats.py:143 */
+    if (T0_fit_margin == 0) points = n;                        /* stats.py:146-152 */
+    else points = (int64_t)((double)n / (T0_fit_margin * (double)dur));
+    if (points > n) points = n;
+    if (points < 0) points = 0;
+    T0_array = (double *)malloc((size_t)(points > 0 ? points : 1) * sizeof(double));
+    res = (double *)malloc((size_t)(points > 0 ? points : 1) * sizeof(double));
+    t_min = t[0];
+    for (i = 1; i < n; i++) if (t[i] < t_min) t_min = t[i];
+    linspace(t_min, t_min + period, points, T0_array);        /* stats.py:155-157 */
+    t0_residuals(t, y, n, period, signal, dur, T0_array, points, dur / 2 + 1 /* stats.py:189 */, res, n_threads);
+    for (k = 0; k < points; k++) {                             /* stats.py:199-201 */
+        if (res[k] < residuals_lowest) { residuals_lowest = res[k]; T0 = T0_array[k]; }
+        if (epochs_out) epochs_out[k] = T0_array[k];
+        if (residuals_out) residuals_out[k] = res[k];
+    }
+    *T0_out = T0;
+    free(signal); free(T0_array); free(res);
+    return points;
+}
+
+/* ---- SDE spectra, stats.py:105-132 with helpers.py:93-108 ----------------------------------- */
+static int cmp_double(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* helpers.py:93-108 for an integer kernel <= n: numpy.median of every window, edges padded */
+static void running_median(const double *data, int64_t n, int64_t kernel, double *out)
+{
+    int64_t n_med = n - kernel + 1, i, missing, front;
+    double *win = (double *)malloc((size_t)kernel * sizeof(double));
+    double *med = (double *)malloc((size_t)n_med * sizeof(double));
+    for (i = 0; i < n_med; i++) {
+        memcpy(win, data + i, (size_t)kernel * sizeof(double));
+        qsort(win, (size_t)kernel, sizeof(double), cmp_double);
+        med[i] = kernel % 2 ? win[kernel / 2] : 0.5 * (win[kernel / 2 - 1] + win[kernel / 2]);
+    }
+    missing = n - n_med;
+    front = (int64_t)((double)missing * 0.5);
+    for (i = 0; i < front; i++) out[i] = med[0];
+    for (i = 0; i < n_med; i++) out[front + i] = med[i];
+    for (i = front + n_med; i < n; i++) out[i] = med[n_med - 1];
+    free(win); free(med);
+}
+
+static double mean_of(const double *x, int64_t n)
+{
+    double s = 0.0; int64_t i;
+    for (i = 0; i < n; i++) s += x[i];
+    return s / (double)n;
+}
+
+static double std_of(const double *x, int64_t n)   /* numpy.std: population, two-pass */
+{
+    double m = mean_of(x, n), s = 0.0; int64_t i;
+    for (i = 0; i < n; i++) s += (x[i] - m) * (x[i] - m);
+    return sqrt(s / (double)n);
+}
+
+/* chi2[n] -> SR, power_raw, power (n each); sde[0] = SDE_raw, sde[1] = SDE.  `kernel` is
+ * oversampling_factor * SDE_MEDIAN_KERNEL_SIZE as an integer (stats.py:114). */
+int tls_oracle_spectra(const double *chi2, int64_t n, int64_t kernel, double *SR, double *power_raw,
+                       double *power, double *sde)
+{
+    int64_t i;
+    double cmin, m, SDE_raw, mx, scale, SDE;
+    if (n < 1) return -1;
+    cmin = chi2[0];
+    for (i = 1; i < n; i++) if (chi2[i] < cmin) cmin = chi2[i];
+    for (i = 0; i < n; i++) SR[i] = cmin / chi2[i];                        /* :106 */
+    m = mean_of(SR, n);
+    SDE_raw = (1 - m) / std_of(SR, n);                                     /* :107 */
+    mx = -INFINITY;
+    for (i = 0; i < n; i++) { power_raw[i] = SR[i] - m; if (power_raw[i] > mx) mx = power_raw[i]; }
+    scale = SDE_raw / mx;                                                  /* :111 */
+    for (i = 0; i < n; i++) power_raw[i] = power_raw[i] * scale;
+    if (kernel % 2 == 0) kernel = kernel + 1;                              /* :115-117 */
+    if (n > 2 * kernel) {
+        double *med = (double *)malloc((size_t)n * sizeof(double));
+        running_median(power_raw, n, kernel, med);
+        for (i = 0; i < n; i++) power[i] = power_raw[i] - med[i];          /* :120 */
+        m = mean_of(power, n);
+        for (i = 0; i < n; i++) power[i] = power[i] - m;                   /* :123 */
+        {
+            double sd = std_of(power, n);
+            SDE = -INFINITY; mx = -INFINITY;
+            for (i = 0; i < n; i++) {
+                if (power[i] / sd > SDE) SDE = power[i] / sd;              /* :124 */
+                if (power[i] > mx) mx = power[i];
+            }
+        }
+        scale = SDE / mx;                                                  /* :126 */
+        for (i = 0; i < n; i++) power[i] = power[i] * scale;
+        free(med);
+    } else {
+        for (i = 0; i < n; i++) power[i] = power_raw[i];
+        SDE = SDE_raw;
+    }
+    sde[0] = SDE_raw; sde[1] = SDE;
+    return 0;
 }

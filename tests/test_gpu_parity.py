@@ -17,7 +17,7 @@ RTOL_CONTRACT = 1e-6   # north_star
 RTOL_TIGHT = 1e-9
 
 
-def assert_parity(got, want, n_points, tight=RTOL_TIGHT):
+def assert_parity(got, want, n_points, tight=RTOL_TIGHT, allow_tie=False):
     chi2, row, depth = got[:3]
     ochi2, orow, odepth = want[:3]
     finite = numpy.isfinite(ochi2)
@@ -27,12 +27,14 @@ def assert_parity(got, want, n_points, tight=RTOL_TIGHT):
     numpy.testing.assert_array_equal(row, orow)
     numpy.testing.assert_allclose(depth, odepth, rtol=0, atol=1e-12)
     if finite.any():
-        # the argmin period index is exact -- unless two trial periods tie to within the 1e-13
-        # agreement of the two arithmetics (seen in the randomised sweep: two near-identical periods
-        # at the end of a short grid); then either index is the minimum
+        # the argmin period index is exact (north_star).  Only the randomised sweep (allow_tie) accepts
+        # the one case its 160-seed run met: two near-identical trial periods at the end of a very
+        # short grid whose chi2 tie to within the 1e-13 agreement of the two arithmetics
         ia, ib = int(numpy.nanargmin(numpy.where(finite, chi2, numpy.inf))), int(numpy.nanargmin(numpy.where(finite, ochi2, numpy.inf)))
-        if ia != ib:
+        if allow_tie and ia != ib:
             assert abs(ochi2[ia] - ochi2[ib]) <= 1e-11 * abs(ochi2[ib]), (ia, ib, ochi2[ia], ochi2[ib])
+        else:
+            assert ia == ib, (ia, ib, ochi2[ia], ochi2[ib])
     # exactly N where nothing beat the straight line (core.py:46)
     numpy.testing.assert_array_equal(chi2 == n_points, ochi2 == n_points)
 
@@ -101,25 +103,54 @@ def test_per_point_uncertainties_vs_oracle(gpu, oracle_lib):
     assert_parity(got, want, len(inp["t"]))
 
 
-def test_tess_2min_vs_oracle_sample(gpu, oracle_lib):
-    """BASELINE config 4 (N=19440): folded series does not fit LDS -> HBM-slab variant."""
+def test_tess_2min_full_grid_vs_oracle(gpu, oracle_lib):
+    """BASELINE config 4 (N=19440): folded series does not fit LDS -> HBM-slab variant.  The WHOLE
+    2459-period grid against the oracle, evaluated-cell counts included."""
     inp = _inputs("tess_27d")
-    got = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+    got = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"], count_work=True)
     assert not gpu.plan_info()["resident"]
-    sel = numpy.arange(0, len(inp["periods"]), int(os.environ.get("TLS_TESS_STRIDE", 25)))  # 1: the whole grid
-    want = oracle_search(oracle_lib, inp, periods=inp["periods"][sel])
-    assert_parity(tuple(a[sel] for a in got[:3]), want, len(inp["t"]))
     assert len(inp["periods"]) == 2459
-
-
-def test_kepler_4yr_sample_vs_oracle(gpu, oracle_lib):
-    """BASELINE config 3 (N=70128, W=8416), a spread sample of its 182k periods."""
-    inp = _inputs("kepler_4yr")
-    assert len(inp["periods"]) == 182388
-    sel = inp["periods"][::int(os.environ.get("TLS_KEPLER_STRIDE", 6000))]
-    got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
-    want = oracle_search(oracle_lib, inp, periods=sel)
+    want = oracle_search(oracle_lib, inp)
     assert_parity(got, want, len(inp["t"]))
+    assert got[3]["grid_cells"] == int(want[3][0])
+    assert got[3]["evaluated_cells"] == int(want[3][1])
+    assert got[3]["inner_steps"] == int(want[3][2])
+    plain = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+    for x, y in zip(got[:3], plain[:3]):
+        numpy.testing.assert_array_equal(x, y)
+
+
+def test_kepler_4yr_full_grid_vs_oracle(gpu, oracle_lib):
+    """BASELINE config 3 (N=70128, W=8416, 182 388 periods, 6e10 trial cells) at FULL size.
+    (i) the live oracle on >= 1000 periods spread over the grid; (ii) every period against the
+    oracle's whole-grid output kept in tests/golden/oracle_kepler_4yr_grid.npz
+    (tools/gen_oracle_grid.py; ~2 core-hours, so not recomputed here) after that fixture has been
+    re-checked on the same >= 1000 periods; (iii) the whole-grid argmin exact, with the live oracle
+    re-evaluated on +-64 periods around it."""
+    inp = _inputs("kepler_4yr")
+    periods = inp["periods"]
+    n_per = len(periods)
+    assert n_per == 182388
+    got = gpu.search(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
+    assert not gpu.plan_info()["resident"]
+    sel = numpy.arange(0, n_per, int(os.environ.get("TLS_KEPLER_STRIDE", 181)))
+    assert len(sel) >= 1000
+    want = oracle_search(oracle_lib, inp, periods=periods[sel])
+    # a spread sample has its own argmin; the exact-argmin assertion holds for it as well
+    assert_parity(tuple(a[sel] for a in got[:3]), want, len(inp["t"]))
+    fix = numpy.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_kepler_4yr_grid.npz"))
+    assert len(fix["chi2"]) == n_per
+    numpy.testing.assert_array_equal(fix["periods_first_last"], periods[[0, -1]])
+    numpy.testing.assert_allclose(fix["chi2"][sel], want[0], rtol=1e-13, atol=0)   # the fixture is this oracle's output
+    numpy.testing.assert_array_equal(fix["row"][sel], want[1])
+    assert_parity(got, (fix["chi2"], fix["row"].astype(numpy.int64), fix["depth"]), len(inp["t"]))
+    best = int(numpy.argmin(got[0]))
+    assert best == int(numpy.argmin(fix["chi2"]))
+    lo, hi = max(0, best - 64), min(n_per, best + 65)
+    near = oracle_search(oracle_lib, inp, periods=periods[lo:hi])
+    assert_parity(tuple(a[lo:hi] for a in got[:3]), near, len(inp["t"]))
+    assert lo + int(numpy.argmin(near[0])) == best
+    assert abs(periods[best] - 10.123) < 0.01      # the injected planet (tls_amd/synthetic.py)
 
 
 # ---- size-independent properties at full size ------------------------------------------
@@ -354,11 +385,20 @@ def test_exact_parallel_cumsum_is_numpy_cumsum(gpu):
             assert numpy.array_equal(got.view(numpy.uint64), want.view(numpy.uint64)), (name, threads)
 
 
-def test_t0_fit_residuals_match_host_restatement(gpu):
-    """tls_t0_fit (batched final T0 fit, stats.py:135-204) against the numpy restatement that
-    the reference pins hold (tests/test_power_host.py): same residual per trial epoch, same
-    first minimum."""
-    from tls_amd.stats import t0_fit_residuals_host
+def test_t0_fit_kernel_vs_oracle_and_reference_residuals(gpu, oracle_lib):
+    """tls_t0_fit (batched final T0 fit, stats.py:135-204) against (i) the per-epoch residuals the
+    UNMODIFIED reference computes (tests/golden/t0fit_*.npz, tools/gen_golden_t0fit.py) and (ii) the
+    oracle's C restatement of the loop at benchmark sizes: same residual per trial epoch, same first
+    minimum."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "t0fit_*.npz")))
+    assert len(files) >= 4
+    for f in files:
+        g = numpy.load(f)
+        roll = int(len(g["signal"]) / 2) + 1                      # stats.py:189
+        got = gpu.t0_fit_residuals(g["t"], g["y"], float(g["period"]), g["scaled_signal"], g["T0_array"], roll)
+        numpy.testing.assert_allclose(got, g["residuals"], rtol=1e-12, atol=0, err_msg=f)
+        assert g["T0_array"][int(numpy.argmin(got))] == float(g["T0"]), f
     for name, n_epochs in (("k2_90d", 1500), ("tess_27d", 64)):
         t, f, kw = synthetic.config(name)
         inp = synthetic.search_inputs(t, f, **kw)
@@ -367,7 +407,7 @@ def test_t0_fit_residuals_match_host_restatement(gpu):
         period = 10.12452
         epochs = numpy.linspace(t.min(), t.min() + period, n_epochs)
         roll = int(len(signal) / 2) + 1
-        want = t0_fit_residuals_host(inp["t"], inp["y"], period, signal, epochs, roll)
+        want = oracle_lib.t0_residuals(inp["t"], inp["y"], period, signal, epochs, roll)
         got = gpu.t0_fit_residuals(inp["t"], inp["y"], period, signal, epochs, roll)
         numpy.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
         assert int(numpy.argmin(got)) == int(numpy.argmin(want))
@@ -379,7 +419,7 @@ def test_t0_fit_residuals_match_host_restatement(gpu):
     t[50:60] = t[50]
     signal = numpy.linspace(0.999, 0.9995, 77)
     epochs = numpy.linspace(t.min(), t.min() + 3.3, 200)
-    want = t0_fit_residuals_host(t, f, 3.3, signal, epochs, 39)
+    want = oracle_lib.t0_residuals(t, f, 3.3, signal, epochs, 39)
     got = gpu.t0_fit_residuals(t, f, 3.3, signal, epochs, 39)
     numpy.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
 
@@ -410,6 +450,32 @@ def test_survey_batch_equals_individual_searches(gpu):
         numpy.testing.assert_array_equal(row[k], one[1])
         numpy.testing.assert_array_equal(depth[k], one[2])
     assert int(numpy.argmin(chi2[0])) == 7738
+
+
+def test_survey_1024_curves_vs_oracle(gpu, oracle_lib):
+    """BASELINE config 5 at FULL size: 1024 light curves (seeds 0..1023 of config 2) through ONE
+    tls_search_batch call on the full 9679-period grid; curves from different 32-curve launch groups
+    (first/last of a group, first and last group) are compared with the ORACLE, period by period."""
+    from tls_amd import survey
+    n_curves = int(os.environ.get("TLS_SURVEY_CURVES", 1024))
+    t, f0, kw = synthetic.config("k2_90d", seed=0)
+    fluxes = numpy.stack([synthetic.config("k2_90d", seed=s)[1] for s in range(n_curves)])
+    periods, chi2, row, depth = survey.search_batch(t, fluxes, context=gpu, **kw)
+    assert chi2.shape == (n_curves, 9679)
+    assert int(numpy.argmin(chi2[0])) == 7738                       # SURVEY.md Appendix D
+    numpy.testing.assert_allclose(chi2[0].min(), 4101.6439079674, rtol=1e-10)
+    checked = [s for s in (0, 1, 31, 32, 33, 511, 512, 777, 1000, 1023) if s < n_curves]
+    assert len([s for s in checked if s > 0]) >= 8 or n_curves < 1024
+    for s in checked:
+        inp = synthetic.search_inputs(t, fluxes[s], **kw)
+        want = oracle_search(oracle_lib, inp)
+        assert_parity((chi2[s], row[s], depth[s]), want, len(t))
+    # every curve carries the injected planet: the best period of each is near 10.123 d or an alias
+    best = periods[numpy.argmin(chi2, axis=1)]
+    ratio = best / 10.123
+    near = numpy.min(numpy.abs(ratio[:, None] - numpy.array([1 / 3, 0.5, 1.0, 2.0, 3.0, 4.0])[None, :]), axis=1) < 0.01
+    assert near.mean() > 0.95, near.mean()
+    assert numpy.all(chi2 <= len(t)) and numpy.all(chi2 > 0)
 
 
 @pytest.mark.parametrize("name,n_curves,stride,per_point", [("k2_90d", 35, 40, False), ("k2_90d", 5, 40, True),
@@ -490,12 +556,12 @@ def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
         sel = inp["periods"][:: max(1, len(inp["periods"]) // 150)]
         got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
         want = oracle_search(oracle_lib, inp, periods=sel)
-        assert_parity(got, want, len(inp["t"]))
+        assert_parity(got, want, len(inp["t"]), allow_tie=True)
         assert got[3]["evaluated_cells"] == int(want[3][1]), (case, kwargs)
         assert got[3]["inner_steps"] == int(want[3][2]), (case, kwargs)
         # the uncounted call may take the pruning kernel (noisy cases; TLS_PRUNE=1 forces it)
         plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
-        assert_parity(plain, want, len(inp["t"]))
+        assert_parity(plain, want, len(inp["t"]), allow_tie=True)
         n_cases += 1
     assert n_cases >= 12
 

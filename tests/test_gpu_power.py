@@ -76,10 +76,9 @@ def _extra_seeds():   # TLS_FUZZ_SEEDS="100-140" adds seeds for a one-off longer
 @pytest.mark.parametrize("seed", [1, 2, 3, 4] + _extra_seeds())
 def test_power_gpu_equals_power_with_oracle_search(monkeypatch, oracle_lib, seed):
     """End to end on random small light curves: the drop-in with the HIP search and the device T0
-    fit must return the same results object as the same host code fed by the CPU oracle and the
-    numpy T0 fit (the combination that the reference's own known answers pin)."""
+    fit must return the same results object as the same host code fed by the CPU oracle's search
+    and T0-fit loops (the combination that the reference's own known answers pin)."""
     from tls_amd import transit_model
-    from tls_amd.stats import t0_fit_residuals_host
     import warnings
     rng = numpy.random.RandomState(seed)
     span = float(rng.choice([15.0, 30.0, 60.0]))
@@ -102,7 +101,7 @@ def test_power_gpu_equals_power_with_oracle_search(monkeypatch, oracle_lib, seed
 
         monkeypatch.setattr(tls_amd.search, "search_periods", oracle_search_periods)
         monkeypatch.setattr(tls_amd.search, "t0_fit_residuals",
-                            lambda t_, y_, p_, s_, e_, r_, **kw: t0_fit_residuals_host(t_, y_, p_, s_, e_, r_))
+                            lambda t_, y_, p_, s_, e_, r_, **kw: oracle_lib.t0_residuals(t_, y_, p_, s_, e_, r_))
         want = make_model(t, y, dy).power(**kwargs)
     assert list(got.keys()) == list(want.keys())
     for key in pins.SCALARS:

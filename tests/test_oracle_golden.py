@@ -49,3 +49,45 @@ def test_oracle_fold_is_stable_argsort(oracle_lib):
         ref = numpy.argsort(phases, kind="mergesort")  # core.py:120
         numpy.testing.assert_array_equal(idx, ref)
         numpy.testing.assert_array_equal(ph, phases[ref])
+
+
+def test_oracle_final_t0_fit_matches_reference(oracle_lib):
+    """oracle tls_oracle_final_t0_fit against the unmodified reference's final_T0_fit
+    (stats.py:135-204): returned T0 and trial grid bit-exact, the residual of every trial epoch
+    (captured from the reference's own loop by tools/gen_golden_t0fit.py) to summation-order accuracy."""
+    import glob, os
+    from conftest import GOLDEN
+    files = sorted(glob.glob(os.path.join(GOLDEN, "t0fit_*.npz")))
+    assert len(files) >= 4
+    for f in files:
+        g = numpy.load(f)
+        T0, epochs, res = oracle_lib.final_t0_fit(g["signal"], float(g["depth"]), g["t"], g["y"],
+                                                  float(g["period"]), float(g["T0_fit_margin"]))
+        assert T0 == float(g["T0"]), f
+        numpy.testing.assert_array_equal(epochs, g["T0_array"])
+        numpy.testing.assert_allclose(res, g["residuals"], rtol=1e-12, atol=0)
+        loop = oracle_lib.t0_residuals(g["t"], g["y"], float(g["period"]), g["scaled_signal"], g["T0_array"],
+                                       int(len(g["signal"]) / 2) + 1)
+        numpy.testing.assert_array_equal(loop, res)
+
+
+def test_oracle_spectra_matches_reference(oracle_lib):
+    """oracle tls_oracle_spectra against the reference's stats.spectra (stats.py:105-132)."""
+    import glob, os
+    from conftest import GOLDEN
+    from tls_amd.stats import spectra
+    files = sorted(glob.glob(os.path.join(GOLDEN, "spectra_*.npz")))
+    assert len(files) >= 3
+    for f in files:
+        g = numpy.load(f)
+        osf = int(g["oversampling_factor"])
+        SR, praw, power, sde_raw, sde = oracle_lib.spectra(g["chi2"], osf * 30)
+        numpy.testing.assert_allclose(SR, g["SR"], rtol=1e-13)
+        numpy.testing.assert_allclose(praw, g["power_raw"], rtol=1e-10, atol=1e-11)
+        numpy.testing.assert_allclose(power, g["power"], rtol=1e-10, atol=1e-11)
+        numpy.testing.assert_allclose([sde_raw, sde], [float(g["SDE_raw"]), float(g["SDE"])], rtol=1e-11)
+        # the product's host restatement against the same reference outputs
+        h = spectra(g["chi2"], osf)
+        for got, key in zip(h[:3], ("SR", "power_raw", "power")):
+            numpy.testing.assert_allclose(got, g[key], rtol=1e-10, atol=1e-11)
+        numpy.testing.assert_allclose([h[3], h[4]], [float(g["SDE_raw"]), float(g["SDE"])], rtol=1e-11)

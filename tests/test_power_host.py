@@ -19,8 +19,7 @@ def make_model(monkeypatch, oracle_lib):
         return chi2, row, depth
 
     def host_t0_fit_residuals(t, y, period, signal, T0_array, roll, **_unused):
-        from tls_amd.stats import t0_fit_residuals_host   # numpy restatement of stats.py:178-195
-        return t0_fit_residuals_host(t, y, period, signal, T0_array, roll)
+        return oracle_lib.t0_residuals(t, y, period, signal, T0_array, roll)   # oracle: stats.py:178-195
 
     monkeypatch.setattr(tls_amd.search, "search_periods", oracle_search_periods)
     monkeypatch.setattr(tls_amd.search, "t0_fit_residuals", host_t0_fit_residuals)
@@ -63,3 +62,7 @@ def test_product_search_has_no_cpu_path():
     with pytest.raises(RuntimeError):
         tls_amd.transitleastsquares(t, y, verbose=False).power(verbose=False,
                                                               show_progress_bar=False)
+    # ... and the final T0 fit has no host evaluation either
+    from tls_amd.stats import final_T0_fit
+    with pytest.raises(RuntimeError):
+        final_T0_fit(numpy.full(5, 0.9), 0.999, t, y, None, 3.0, 0.01, False, False, None)

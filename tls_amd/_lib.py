@@ -39,7 +39,8 @@ class _Params(ctypes.Structure):
 
 class Counters(ctypes.Structure):
     _fields_ = [("grid_cells", ctypes.c_int64), ("evaluated_cells", ctypes.c_int64),
-                ("inner_steps", ctypes.c_int64), ("pd_pairs", ctypes.c_int64)]
+                ("inner_steps", ctypes.c_int64), ("pd_pairs", ctypes.c_int64),
+                ("issued_fma", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

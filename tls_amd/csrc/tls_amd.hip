@@ -34,6 +34,7 @@ constexpr double kFracDurationMax = 0.12;
 constexpr double kPi = 3.141592653589793;
 
 constexpr size_t kLdsPerCU = 160 * 1024;
+constexpr size_t kEventRing = 64;   // launch-timing event pairs kept per context
 
 std::string g_create_error;  // tls_last_error(NULL)
 
@@ -99,7 +100,7 @@ struct tls_ctx {
     int threads = 512, blocks = 0;
     size_t lds_bytes = 0;
     double S0 = 0, w0 = 1, depth_min = 0;
-    tls_counters plan_counters = {0, 0, 0, 0};
+    tls_counters plan_counters = {0, 0, 0, 0, 0};
     bool counted = false;
 
     // per-launch kernel timing (HIP events on the context's stream)
@@ -282,12 +283,12 @@ hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
-    if (ctx->ev_used == ctx->ev_pool.size()) {
+    if (ctx->ev_pool.size() < kEventRing) {   // a ring: a long-lived survey process never grows it
         hipEvent_t a, b;
         if ((e = hipEventCreate(&a)) != hipSuccess || (e = hipEventCreate(&b)) != hipSuccess) return e;
         ctx->ev_pool.emplace_back(a, b);
     }
-    auto& evp = ctx->ev_pool[ctx->ev_used++];
+    auto& evp = ctx->ev_pool[ctx->ev_used++ % kEventRing];
     if ((e = hipEventRecord(evp.first, ctx->stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->blocks), dim3((unsigned)ctx->threads), ctx->lds_bytes,
                        ctx->stream, args);
@@ -297,7 +298,7 @@ hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
 
 int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     if (count_work)
-        TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
     tlsdev::SearchArgs a;
     a.t = ctx->d_t.ptr; a.y = ctx->d_y.ptr; a.w = ctx->uniform_w ? nullptr : ctx->d_w.ptr;
     a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.rows = ctx->d_rows.ptr;
@@ -436,7 +437,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     std::vector<int> order((size_t)n_periods);
     std::vector<tlsdev::PeriodRows> prow((size_t)n_periods);
     std::vector<int64_t> cost((size_t)n_periods);
-    tls_counters pc = {0, 0, 0, 0};
+    tls_counters pc = {0, 0, 0, 0, 0};
     const double length = t_max - t_min;
     for (int64_t p = 0; p < n_periods; ++p) {
         const double P = periods[p];
@@ -570,7 +571,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     TLS_HIP(ctx, ctx->d_chi2.reserve((size_t)n_periods));
     TLS_HIP(ctx, ctx->d_row.reserve((size_t)n_periods));
     TLS_HIP(ctx, ctx->d_depth.reserve((size_t)n_periods));
-    TLS_HIP(ctx, ctx->d_counters.reserve(2));
+    TLS_HIP(ctx, ctx->d_counters.reserve(3));
     TLS_HIP(ctx, ctx->d_queue.reserve(1));
     TLS_HIP(ctx, ctx->d_squeue.reserve(2));
     TLS_HIP(ctx, hipMemsetAsync(ctx->d_squeue.ptr, 0, 2 * sizeof(unsigned int), ctx->stream));  // the kernel rewinds it itself
@@ -737,7 +738,7 @@ int tls_fetch(tls_ctx* ctx, double* out_chi2, int64_t* out_row, double* out_dept
         TLS_HIP(ctx, hipMemcpyAsync(out_row, ctx->d_row.ptr, np * 8, hipMemcpyDeviceToHost, ctx->stream));
         TLS_HIP(ctx, hipMemcpyAsync(out_depth, ctx->d_depth.ptr, np * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    unsigned long long dev_counts[2] = {0, 0};
+    unsigned long long dev_counts[3] = {0, 0, 0};
     if (counters && ctx->counted && np)
         TLS_HIP(ctx, hipMemcpyAsync(dev_counts, ctx->d_counters.ptr, sizeof dev_counts, hipMemcpyDeviceToHost, ctx->stream));
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -745,6 +746,7 @@ int tls_fetch(tls_ctx* ctx, double* out_chi2, int64_t* out_row, double* out_dept
         *counters = ctx->plan_counters;
         counters->evaluated_cells = ctx->counted ? (int64_t)dev_counts[0] : -1;
         counters->inner_steps = ctx->counted ? (int64_t)dev_counts[1] : -1;
+        counters->issued_fma = ctx->counted ? (int64_t)dev_counts[2] : -1;
     }
     return TLS_OK;
 }
@@ -754,20 +756,21 @@ int tls_kernel_timing(tls_ctx* ctx, int reset, double* total_ms, int64_t* launch
     TLS_HIP(ctx, hipSetDevice(ctx->device));
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double sum = 0;
-    for (size_t i = 0; i < ctx->ev_used; ++i) {
+    const size_t n_timed = std::min(ctx->ev_used, ctx->ev_pool.size());
+    for (size_t i = 0; i < n_timed; ++i) {
         float ms = 0;
         TLS_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
         sum += ms;
     }
     if (total_ms) *total_ms = sum;
-    if (launches) *launches = (int64_t)ctx->ev_used;
+    if (launches) *launches = (int64_t)n_timed;
     if (reset) ctx->ev_used = 0;
     return TLS_OK;
 }
 
 int tls_plan_info(const tls_ctx* ctx, tls_counters* counters, int64_t* lds_bytes, int64_t* n_blocks, int64_t* resident) {
     if (!ctx || !ctx->prepared) return TLS_E_STATE;
-    if (counters) { *counters = ctx->plan_counters; counters->evaluated_cells = -1; counters->inner_steps = -1; }
+    if (counters) { *counters = ctx->plan_counters; counters->evaluated_cells = -1; counters->inner_steps = -1; counters->issued_fma = -1; }
     if (lds_bytes) *lds_bytes = (int64_t)ctx->lds_bytes;
     if (n_blocks) *n_blocks = ctx->blocks;
     if (resident) *resident = ctx->resident ? 1 : 0;

@@ -205,7 +205,7 @@ struct SearchArgs {
     double* out_chi2;       // [n_periods]
     long long* out_row;     // [n_periods]
     double* out_depth;      // [n_periods]
-    unsigned long long* counters;      // [2] evaluated cells, inner steps (nullptr: off)
+    unsigned long long* counters;      // [3] evaluated cells, inner steps, issued lane-FMAs (nullptr: off)
     unsigned long long* phase_cycles;  // [kPhases] shader cycles per phase (nullptr: off)
     unsigned int* queue;        // [2] next work item, workgroups done (both 0 at launch, rewound by the kernel)
     double* scratch;        // non-resident: per-workgroup slabs of the folded series
@@ -1482,6 +1482,7 @@ tls_search_kernel(const SearchArgs a) {
         Best best;
         best.stat = INFINITY; best.td = 0.0; best.k = 0x7fffffff; best.i = 0x7fffffff;
         unsigned long long n_eval = 0, n_steps = 0;
+        unsigned long long n_issued = 0;   // FMAs per lane of this wave's dot products (wave-uniform)
         bool p2_ready = false;
         // ---- phase 3 runs over TILES of window-start positions [p_lo, p_hi).  Resident variant:
         // one tile, the folded series already sits in LDS.  Otherwise the series is in the HBM slab
@@ -1946,6 +1947,10 @@ tls_search_kernel(const SearchArgs a) {
                 const int unit = have ? (int)chunk_list[list_base + (n_singles ? n_live : 0) + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
                 const unsigned long long evals_before = n_eval;
+                if (a.counters) {   // what the loops below issue per lane, padding and idle lanes included
+                    const int reach = (tiled && n_singles == 0) ? (kR - 1) * xth : 0;
+                    n_issued += (unsigned long long)((L + reach + kU - 1) / kU * kU) * (reach ? kR : 1) * (UNIFORM_W ? 1 : 2);
+                }
                 if (tiled && n_singles == 0) {
                     // kR windows per lane, xth samples apart
                     const int u0 = unit * kR;
@@ -2071,6 +2076,7 @@ tls_search_kernel(const SearchArgs a) {
                 atomicAdd(&a.counters[0], n_eval);
                 atomicAdd(&a.counters[1], n_steps);
             }
+            if (lane == 0 && n_issued) atomicAdd(&a.counters[2], n_issued * kWave);
         }
         __syncthreads();
         }  // light curves of the batch

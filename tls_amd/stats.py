@@ -120,34 +120,17 @@ def spectra(chi2, oversampling_factor):
     return SR, power_raw, power, SDE_raw, SDE
 
 
-def t0_fit_residuals_host(t, y, period, signal, T0_array, roll, batch_bytes=64 << 20):
-    """Host (numpy) evaluation of the T0-fit residuals, trial epochs in batches: the restatement
-    of the loop body of stats.py:178-195 that pins the device kernel (tls_t0_fit)."""
-    n, dur = numpy.size(y), len(signal)
-    out = numpy.empty(len(T0_array))
-    rows = max(1, int(batch_bytes // (8 * n * 4)))
-    for lo in range(0, len(T0_array), rows):
-        Tx = T0_array[lo: lo + rows]
-        phases = fold(t[None, :], period, Tx[:, None])
-        order = numpy.argsort(phases, axis=1, kind="stable")
-        flux = numpy.roll(y[order], roll, axis=1)  # template starts at index 0
-        weight = numpy.roll(flux, roll, axis=1)
-        res_in = numpy.sum((flux[:, :dur] - signal) ** 2 / weight[:, :dur] ** 2, axis=1)
-        res_out = numpy.sum((flux[:, dur:] - 1.0) ** 2 / weight[:, dur:] ** 2, axis=1)
-        out[lo: lo + rows] = res_in + res_out
-    return out
-
-
 def final_T0_fit(signal, depth, t, y, dy, period, T0_fit_margin, show_progress_bar, verbose,
-                 residuals_fn=None):
+                 residuals_fn):
     """Mid-transit time of the best (period, duration, depth): chi^2 of the
     depth-scaled template over a grid of trial T0s, first minimum wins.
 
     Reference stats.py:135-204.  Kept quirk: the weights are 1/flux^2 of the
     flux rolled twice, not 1/dy^2 (the reference overwrites dy with the rolled
     flux, stats.py:191), so `dy` does not influence the result.
-    residuals_fn(t, y, period, signal, T0_array, roll) evaluates the trial epochs; the
-    drop-in passes the device kernel, the default is the numpy restatement.
+    residuals_fn(t, y, period, signal, T0_array, roll) evaluates the loop body (stats.py:178-195)
+    for every trial epoch: the device kernel tls_t0_fit (tls_amd.search.t0_fit_residuals).  There
+    is no host evaluation in the product; its CPU restatement lives in oracle/tls_oracle.c.
     """
     dur = len(signal)
     scale = C.SIGNAL_DEPTH / (1 - depth)
@@ -164,7 +147,7 @@ def final_T0_fit(signal, depth, t, y, dy, period, T0_fit_margin, show_progress_b
         print("Searching for best T0 for period", format(period, ".5f"), "days")
     roll = int(dur / 2) + 1
     if residuals_fn is None:
-        residuals_fn = t0_fit_residuals_host
+        raise RuntimeError("final_T0_fit needs the device evaluation of the trial epochs (no CPU path)")
     total = residuals_fn(t, y, period, signal, T0_array, roll)
     if len(total) == 0 or not (numpy.min(total) < float("inf")):
         return 0

@@ -12,7 +12,7 @@ Every array written here is an INPUT or an OUTPUT of reference code:
   grids.npz      period_grid / duration_grid / template-table outputs for a few argument sets.
   k2_*.npz       the two K2 light curves the reference's tests hold as data fixtures
                  (tests/EPIC201367065.csv, tests/EPIC206154641.csv: time, flux), stored
-                 as arrays for tests/test_reference_pins.py.
+                 as arrays for tests/pins.py (run by test_power_host.py and test_gpu_power.py).
 
 The reference's pure-Python inner loops are slow (~0.3 s per period at N=720), so
 the cases are small; full-size parity runs against the C oracle, which is itself
