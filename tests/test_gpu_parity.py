@@ -378,11 +378,20 @@ def test_exact_parallel_cumsum_is_numpy_cumsum(gpu):
         "one": numpy.array([0.75]),
         "empty": numpy.zeros(0),
     }
+    # The result is exact by construction (every block verifies its own start values and is redone by
+    # the per-binade routine otherwise), so a broken fast path would only show up as run time: count
+    # the fallbacks.  Ordinary flux series must never need one; series that cross more binades per
+    # block than the tables hold ("wide", "tiny", "growing") may.
+    must_be_fast = ("flux", "flux_long", "ties", "halves", "zeros", "unnormalised", "one")
     for name, v in cases.items():
         want = numpy.concatenate([[0.0], numpy.cumsum(v)])
         for threads in (64, 512, 1024):
             got = gpu.debug_cumsum(v, threads=threads)
             assert numpy.array_equal(got.view(numpy.uint64), want.view(numpy.uint64)), (name, threads)
+            stats = gpu.phase_cycles()
+            assert stats["cumsum_blocks"] == (len(v) + 16 * threads - 1) // (16 * threads) or len(v) <= 16 * threads, (name, threads)
+            if name in must_be_fast:
+                assert stats["cumsum_fallbacks"] == 0, (name, threads, stats["cumsum_blocks"], stats["cumsum_fallbacks"])
 
 
 def test_t0_fit_kernel_vs_oracle_and_reference_residuals(gpu, oracle_lib):

@@ -10,7 +10,8 @@ import os
 import numpy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtls_amd.so")
+# TLS_AMD_LIB: developer switch for A/B timing of two builds of the same source (tls_amd/csrc/Makefile `variant`)
+LIB_PATH = os.environ.get("TLS_AMD_LIB") or os.path.join(_HERE, "libtls_amd.so")
 
 # every symbol include/tls_amd.h declares (tests check the export list against the header)
 SYMBOLS = (

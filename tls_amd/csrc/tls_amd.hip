@@ -670,13 +670,18 @@ int tls_debug_cumsum(tls_ctx* ctx, const double* f, int64_t count, double* out, 
     TLS_HIP(ctx, d_f.reserve((size_t)count));
     TLS_HIP(ctx, d_out.reserve((size_t)count + 1));
     if (count) TLS_HIP(ctx, hipMemcpyAsync(d_f.ptr, f, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3((unsigned)threads), 0, ctx->stream, d_f.ptr, d_out.ptr, (int)count);
+    const int variant = getenv("TLS_DEBUG_CUMSUM_OLD") ? 1 : 0;
+    // block / fallback counts of this call land in the phase-clock buffer (tls_debug_phase_cycles slots 10, 11)
+    TLS_HIP(ctx, ctx->d_phase.reserve(tlsdev::kPhases));
+    TLS_HIP(ctx, hipMemsetAsync(ctx->d_phase.ptr, 0, tlsdev::kPhases * sizeof(unsigned long long), ctx->stream));
+    { const unsigned long long big = ~0ull; TLS_HIP(ctx, hipMemcpyAsync(ctx->d_phase.ptr + 22, &big, 8, hipMemcpyHostToDevice, ctx->stream)); TLS_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+    hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3((unsigned)threads), 0, ctx->stream, d_f.ptr, d_out.ptr, (int)count, variant, ctx->d_phase.ptr);
     TLS_HIP(ctx, hipGetLastError());
     if (const char* reps_env = getenv("TLS_DEBUG_CUMSUM_REPS")) {  // developer timing of one workgroup
         const int reps = atoi(reps_env);
         TLS_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         for (int r = 0; r < reps; ++r)
-            hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3((unsigned)threads), 0, ctx->stream, d_f.ptr, d_out.ptr, (int)count);
+            hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3((unsigned)threads), 0, ctx->stream, d_f.ptr, d_out.ptr, (int)count, variant, (unsigned long long*)nullptr);
         TLS_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         TLS_HIP(ctx, hipEventSynchronize(ctx->ev1));
         float ms = 0;

@@ -69,6 +69,9 @@ constexpr int kPhases = 26;    // phase-clock slots (tls_amd/_lib.py names them)
 #ifndef TLS_KR
 #define TLS_KR 5
 #endif
+#ifndef TLS_CUMSUM2
+#define TLS_CUMSUM2 1   // 1: three-barrier register-resident prefix sum (exact_cumsum); 0: the first version
+#endif
 #ifndef TLS_PRUNE
 #define TLS_PRUNE 1   // exact branch-and-bound pruning of trial cells (uniform weights), see cell_bound()
 #endif
@@ -787,6 +790,295 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Wave-level scans on the DPP crossbar (row_shr inside the rows of 16 lanes, row_bcast:15/31 across
+// them): a VALU move per 32-bit word and step instead of a ds_bpermute round trip through the LDS.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+    // lanes without a source (outside the row, or rows masked off) receive 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i32<CTRL, ROW_MASK>((int)(b & 0xffffffffLL));
+    const int hi = dpp_i32<CTRL, ROW_MASK>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;
+
+// inclusive prefix sum over the 64 lanes (0.0 is what the lanes without a source contribute)
+__device__ __forceinline__ double wave_inclusive_sum(double v) {
+    v += dpp_f64<kDppRowShr1, 0xF>(v);
+    v += dpp_f64<kDppRowShr2, 0xF>(v);
+    v += dpp_f64<kDppRowShr4, 0xF>(v);
+    v += dpp_f64<kDppRowShr8, 0xF>(v);
+    v += dpp_f64<kDppBcast15, 0xA>(v);
+    v += dpp_f64<kDppBcast31, 0xC>(v);
+    return v;
+}
+
+// Scan element of the one-pass cumsum: the composite parity map since the last (predicted) binade
+// change inside the scanned range, or since its start when `reset` is 0.  All-zero bits = identity.
+struct SegMap {
+    double i0, i1;
+    int reset;
+};
+// x (lower elements), then y; `b`: the binade y's elements live in (used when y holds no change)
+__device__ __forceinline__ SegMap seg_combine(const SegMap& x, const SegMap& y, const BinadeD& b) {
+    StepD xm, ym;
+    xm.i0 = x.i0; xm.i1 = x.i1; ym.i0 = y.i0; ym.i1 = y.i1;
+    const StepD c = compose(xm, ym, b);
+    SegMap z;
+    z.reset = x.reset | y.reset;
+    z.i0 = y.reset ? y.i0 : c.i0;
+    z.i1 = y.reset ? y.i1 : c.i1;
+    return z;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ SegMap dpp_seg(const SegMap& v) {
+    SegMap o;
+    o.i0 = dpp_f64<CTRL, ROW_MASK>(v.i0);
+    o.i1 = dpp_f64<CTRL, ROW_MASK>(v.i1);
+    o.reset = dpp_i32<CTRL, ROW_MASK>(v.reset);
+    return o;
+}
+__device__ __forceinline__ SegMap wave_inclusive_seg(SegMap v, const BinadeD& b) {
+    v = seg_combine(dpp_seg<kDppRowShr1, 0xF>(v), v, b);
+    v = seg_combine(dpp_seg<kDppRowShr2, 0xF>(v), v, b);
+    v = seg_combine(dpp_seg<kDppRowShr4, 0xF>(v), v, b);
+    v = seg_combine(dpp_seg<kDppRowShr8, 0xF>(v), v, b);
+    v = seg_combine(dpp_seg<kDppBcast15, 0xA>(v), v, b);
+    v = seg_combine(dpp_seg<kDppBcast31, 0xC>(v), v, b);
+    return v;
+}
+// the running sum after a range with composite map `m` that stays inside the binade of S
+__device__ __forceinline__ double apply_map(double S, double i0, double i1) { return S + (mantissa_bit0(S) ? i1 : i0); }
+
+// LDS scratch of exact_cumsum_block (shares its slot with CumsumScratch: the fallback runs after it)
+struct Cumsum2Scratch {
+    double wsum[kMaxWaves];          // A: plain sums of the waves
+    SegMap wseg[kMaxWaves];          // B: composite map of every wave (behind its last binade change, if any)
+    StepD tab_H[kMaxSeg];            // composite of the owner wave's elements in front of the element that
+                                     //    enters binade m_first + slot (since the wave's start or its previous change)
+    double tab_f[kMaxSeg];           // addend of that element
+    double wstart[kMaxWaves + 1];    // E: exact running sum at the first element of every wave (chain value)
+    double wendv[kMaxWaves];         //    ... and behind its last one (recurrence value)
+    unsigned int wmask[kMaxWaves];   // binades entered inside each wave's range (bit = slot)
+    double x_first;                  // first element of the block: slot 0 is the binade it leads into
+    int fail;                        // some check failed: the block is redone by the per-binade routine
+};
+static_assert(sizeof(Cumsum2Scratch) <= kCumsumScratchBytes, "cumsum scratch does not fit its slot");
+static_assert(kMaxSeg <= 32 && kMaxSeg <= kWave && kMaxWaves <= kWave, "slot tables are held one entry per lane");
+
+// One block of the exact sequential prefix sum, elements held in registers:
+//     C[k0] = s0,  C[k+1] = fl(C[k] + f[k])  for k in [k0, kb),   kb - k0 <= blockDim.x * PER.
+// Thread T owns `per` <= PER consecutive elements (slots past its range hold 0.0, the identity of every
+// step below).  Three workgroup barriers:
+//   A  plain (re-associated) prefix sums P predict in which binade every partial sum lies;
+//   B  every thread composes the parity maps of its elements between the predicted binade changes; a
+//      segmented wave scan, the wave totals and a table of the few elements that change the binade go
+//      to LDS.  Behind the barrier every wave chains the wave totals and those elements for itself
+//      (two additions per step) and obtains the exact sum at its own start and behind every change
+//      inside its range, hence the start value of every lane;
+//   E  every thread runs the ACTUAL recurrence over its elements from its start value (parity step
+//      inside the binade, plain fp64 addition when the sum leaves it), so its values are exact
+//      whenever its start value is.  The start values are verified, not trusted: thread T+1's start
+//      must equal thread T's end, bit for bit, and thread 0 starts from s0 -- by induction every
+//      value is the sequential sum.  Any mismatch (a mispredicted binade, more binades than table
+//      slots) sends the whole block through sequential_cumsum_by_binade.
+// ALIASED: C[k+1] is stored over f[k] (f == C + 1); the elements are then restored before a fallback.
+// Returns C[kb].
+template <int PER, bool ALIASED>
+__device__ __forceinline__ double exact_cumsum_block(const double* f, double* C, int k0, int kb, double s0,
+                                                     Cumsum2Scratch* cs, unsigned long long* dbg) {
+    PhaseClock cpc; cpc.start(dbg);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (kWave - 1), nw = nt / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    int per = (kb - k0 + nt - 1) / nt;
+    if ((per & 1) == 0 && per < PER) per += 1;      // odd stride: the 8-byte LDS accesses of a wave hit 32 bank pairs
+    const int lo = k0 + tid * per < kb ? k0 + tid * per : kb;
+    const int mine = lo + per < kb ? per : kb - lo;  // elements of this thread, 0..per
+    double x[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) x[e] = e < mine ? f[lo + e] : 0.0;
+    if (tid < kMaxWaves) cs->wmask[tid] = 0u;
+    if (tid == 0) { cs->fail = 0; cs->x_first = x[0]; }
+    // ---- A: plain prefix sums ------------------------------------------------------------------
+    double local = 0.0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) local += x[e];
+    const double incl = wave_inclusive_sum(local);
+    if (lane == kWave - 1) cs->wsum[wave] = incl;
+    __syncthreads();                                                                        // 1
+    double wave_base = s0;
+    for (int v = 0; v < wave; ++v) wave_base += cs->wsum[v];   // the same additions in every thread of the wave
+    // The end of my range IS the start of the next thread's: one definition for both sides, so the
+    // predicted binades form one sequence over the block.
+    const double p_start = wave_base + dpp_f64<kDppWaveShr1, 0xF>(incl);   // lane 0: + 0.0
+    double p_next = dpp_f64<kDppWaveShl1, 0xF>(p_start);                   // lane 63: replaced below
+    if (lane == kWave - 1) p_next = (wave_base + cs->wsum[wave]) + 0.0;    // = p_start of the next wave's lane 0
+    cpc.mark(14);
+    // ---- B: parity maps between the predicted binade changes --------------------------------------
+    // slots count binades from the one the block's first element leads into (the sum may start at 0.0,
+    // a thousand binades below its first partial sum)
+    const int m_first = unbiased_exponent(s0 + cs->x_first, nullptr);
+    const int m_lo = unbiased_exponent(p_start, nullptr);
+    const BinadeD b_lo = binade_constants(m_lo);
+    SegMap acc; acc.i0 = 0.0; acc.i1 = 0.0; acc.reset = 0;
+    StepD head; head.i0 = 0.0; head.i1 = 0.0;      // composite in front of the first change in my range
+    const int slot_in = m_lo - m_first;            // the segment my range starts in
+    int slot_first = -1;                           // slot entered by the first change in my range
+    bool overflow = false;
+    {
+        StepD seg; seg.i0 = 0.0; seg.i1 = 0.0;
+        BinadeD bk = b_lo;
+        int m_k = m_lo;
+        double p = p_start;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            if (e < mine) {
+                const double p_after = e == mine - 1 ? p_next : p + x[e];
+                const int m_after = unbiased_exponent(p_after, nullptr);
+                if (m_after != m_k || lo + e == k0) {           // leaves the binade (or opens the block)
+                    const int slot = m_after - m_first;
+                    const bool ok = slot >= 0 && slot < kMaxSeg;
+                    overflow |= !ok;
+                    if (slot_first < 0) { head = seg; slot_first = ok ? slot : kMaxSeg; }
+                    else if (ok) cs->tab_H[slot] = seg;          // in front of it: my elements since my previous change
+                    if (ok) { cs->tab_f[slot] = x[e]; atomicOr(&cs->wmask[wave], 1u << slot); }
+                    bk = binade_constants(m_after);
+                    seg.i0 = 0.0; seg.i1 = 0.0;
+                    acc.reset = 1;
+                } else {
+                    seg = compose(seg, step_of(x[e], bk), bk);
+                }
+                m_k = m_after;
+                p = p_after;
+            }
+        }
+        if (slot_first < 0) head = seg;
+        acc.i0 = seg.i0; acc.i1 = seg.i1;
+    }
+    const SegMap inc = wave_inclusive_seg(acc, b_lo);
+    const SegMap exc = dpp_seg<kDppWaveShr1, 0xF>(inc);        // lanes in front of me, inside my wave
+    if (slot_first >= 0 && slot_first < kMaxSeg) {
+        // in front of my first change: the wave's elements since its previous change (or its start), then mine
+        StepD em; em.i0 = exc.i0; em.i1 = exc.i1;
+        cs->tab_H[slot_first] = compose(em, head, b_lo);
+    }
+    if (lane == kWave - 1) cs->wseg[wave] = inc;
+    if (overflow) cs->fail = 1;
+    cpc.mark(15);
+    __syncthreads();                                                                        // 2
+    // ---- chain: every wave for itself, over the earlier waves and the binade changes ------------------
+    // lane v holds wave v's total and change mask, lane j the table entries of slot j
+    double w_i0 = 0.0, w_i1 = 0.0, h_i0 = 0.0, h_i1 = 0.0, h_f = 0.0;
+    unsigned int w_mask = 0u;
+    if (lane < nw) { w_i0 = cs->wseg[lane].i0; w_i1 = cs->wseg[lane].i1; w_mask = cs->wmask[lane]; }
+    if (lane < kMaxSeg) { h_i0 = cs->tab_H[lane].i0; h_i1 = cs->tab_H[lane].i1; h_f = cs->tab_f[lane]; }
+    double S = s0;
+    double seg_start = 0.0;                        // lane j: exact sum behind the element that enters slot j (my wave's)
+    for (int v = 0; v <= wave; ++v) {
+        if (v == wave && lane == 0) cs->wstart[wave] = S;
+        const double S_wave = S;
+        unsigned int left = (unsigned int)lane_value((int)w_mask, v);
+        while (left) {
+            const int j = __builtin_ctz(left);
+            left &= left - 1u;
+            S = apply_map(S, lane_value(h_i0, j), lane_value(h_i1, j));   // up to the element that leaves the binade
+            S = S + lane_value(h_f, j);                                    // its own step: plain fp64
+            if (v == wave && lane == j) seg_start = S;
+        }
+        if (v < wave) S = apply_map(S, lane_value(w_i0, v), lane_value(w_i1, v));
+        else S = S_wave;                            // my own wave: keep its start value
+    }
+    // my start value: the wave's start, or the sum behind the last change in front of me in my wave
+    // (the shuffle runs in ALL lanes, outside the select: ds_bpermute returns 0 for a source lane that is
+    // masked off, and the lane that holds a segment's start need not itself lie behind a change)
+    const double seg_base = __shfl(seg_start, slot_in < 0 ? 0 : (slot_in < kWave ? slot_in : kWave - 1), kWave);
+    const double base = exc.reset ? seg_base : S;
+    const double S_start = apply_map(base, exc.i0, exc.i1);
+    cpc.mark(16);
+    // ---- E: the recurrence itself ---------------------------------------------------------------------
+    double S_run = S_start;
+    {
+        BinadeD bk = binade_constants(unbiased_exponent(S_run, nullptr));
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            if (e < mine) {
+                const StepD t = step_of(x[e], bk);
+                double Sn = S_run + (mantissa_bit0(S_run) ? t.i1 : t.i0);
+                if (!(Sn < bk.sat)) {                           // leaves the binade: the plain sum IS the step
+                    Sn = S_run + x[e];
+                    bk = binade_constants(unbiased_exponent(Sn, nullptr));
+                }
+                S_run = Sn;
+                C[lo + e + 1] = Sn;
+            }
+        }
+    }
+    if (tid == 0) C[k0] = s0;
+    // ---- verification of the start values ---------------------------------------------------------------
+    const double next_start = dpp_f64<kDppWaveShl1, 0xF>(S_start);
+    bool bad = lane < kWave - 1 && !(S_run == next_start);
+    if (tid == 0) bad |= !(S_start == s0);
+    if (lane == kWave - 1) cs->wendv[wave] = S_run;
+    const unsigned long long bad_lanes = __ballot(bad);
+    if (bad_lanes != 0ull && lane == 0) cs->fail = 1;
+    cpc.mark(17);
+    __syncthreads();                                                                        // 3
+    bool failed = cs->fail != 0;
+    for (int v = 0; v + 1 < nw; ++v) failed |= !(cs->wendv[v] == cs->wstart[v + 1]);
+    const double s_end = cs->wendv[nw - 1];
+    if (dbg && tid == 0) { atomicAdd(&dbg[10], 1ull); if (failed) atomicAdd(&dbg[11], 1ull); }
+#ifdef TLS_CUMSUM_DIAG   // developer build: why a block failed (slots 18..22 of the debug-kernel's clock buffer)
+    if (dbg) {
+        if (overflow) atomicAdd(&dbg[18], 1ull);
+        if (lane == 0 && bad_lanes) atomicAdd(&dbg[19], (unsigned long long)__popcll(bad_lanes));
+        if (tid == 0) {
+            for (int v = 0; v + 1 < nw; ++v) if (!(cs->wendv[v] == cs->wstart[v + 1])) atomicAdd(&dbg[20], 1ull);
+            if (!(S_start == s0)) atomicAdd(&dbg[21], 1ull);
+        }
+        if (lane == 0 && bad_lanes) atomicMin(&dbg[22], (unsigned long long)(wave * 64 + __ffsll((long long)bad_lanes) - 1));
+    }
+#endif
+    if (failed) {
+        __syncthreads();                            // everybody has read the scratch: its slot is reused below
+        if constexpr (ALIASED) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) if (e < mine) const_cast<double*>(f)[lo + e] = x[e];
+            __syncthreads();
+        }
+        sequential_cumsum_by_binade(f, C, k0, kb, s0, reinterpret_cast<CumsumScratch*>(cs));
+        __syncthreads();
+        return C[kb];
+    }
+    return s_end;
+}
+
+// C[0] = s_start, C[k+1] = fl(C[k] + f[k]) for k < count: blocks of blockDim.x * 16 elements (one for an
+// LDS-resident light curve).  All threads of the workgroup call this; C is complete at return.
+template <bool ALIASED>
+__device__ __forceinline__ double exact_cumsum(const double* f, double* C, int count, Cumsum2Scratch* cs,
+                                               unsigned long long* dbg = nullptr, double s_start = 0.0) {
+    const int nt = blockDim.x;
+    if (count <= 0) { if (threadIdx.x == 0) C[0] = s_start; __syncthreads(); return s_start; }
+    double s0 = s_start;
+    for (int k0 = 0; k0 < count; ) {
+        const int left = count - k0;
+        int kb;
+        if (left <= 8 * nt) { kb = count; s0 = exact_cumsum_block<8, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
+        else if (left <= 12 * nt) { kb = count; s0 = exact_cumsum_block<12, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
+        else { kb = left <= 16 * nt ? count : k0 + 16 * nt; s0 = exact_cumsum_block<16, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
+        k0 = kb;
+        if (k0 < count) __syncthreads();             // the scratch is rewritten by the next block
+    }
+    return s0;
+}
+
 // Depth predicate of one trial cell (core.py:58): mean = 1 - (C[i+d]-C[i])/d > depth_min.
 // The quotient is replaced by a multiplication (the two differ by < 3e-16); only a result
 // within 1e-15 of the threshold is re-decided with the exact quotient, so the decision is
@@ -1437,7 +1729,11 @@ tls_search_kernel(const SearchArgs a) {
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup
         if constexpr (RESIDENT) {
+#if TLS_CUMSUM2
+            exact_cumsum<false>(regA, regB, M, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
+#else
             exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
+#endif
         } else {
             // the series is in the HBM slab: run the scan on LDS copies, kCumsumChunk elements a time
             double* f_l = reinterpret_cast<double*>(smem + a.hdr_bytes);
@@ -1447,7 +1743,11 @@ tls_search_kernel(const SearchArgs a) {
                 const int len = M - c0 < kCumsumChunk ? M - c0 : kCumsumChunk;
                 copy_in_flight4(f_l, regA + c0, len);
                 __syncthreads();
+#if TLS_CUMSUM2
+                exact_cumsum<false>(f_l, c_l, len, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles, carry);
+#else
                 exact_sequential_cumsum(f_l, c_l, len, cumsum_scratch, a.phase_cycles, carry);
+#endif
                 __syncthreads();
                 for (int k = tid; k <= len; k += nt) regB[c0 + k] = c_l[k];
                 // e = 1 - f (or e*w) goes back to the slab from the LDS copy: one pass less over HBM
@@ -2163,9 +2463,11 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a) {
 
 // Developer/test entry: the exact sequential cumsum on an arbitrary non-negative series
 // (one workgroup, global memory).  out has count + 1 entries.
-__global__ void __launch_bounds__(1024) tls_cumsum_kernel(const double* f, double* out, int count) {
-    __shared__ CumsumScratch cs;
-    exact_sequential_cumsum(f, out, count, &cs);
+__global__ void __launch_bounds__(1024) tls_cumsum_kernel(const double* f, double* out, int count, int variant,
+                                                          unsigned long long* dbg) {
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[kCumsumScratchBytes];
+    if (variant == 0) exact_cumsum<false>(f, out, count, reinterpret_cast<Cumsum2Scratch*>(scratch), dbg);
+    else exact_sequential_cumsum(f, out, count, reinterpret_cast<CumsumScratch*>(scratch));
 }
 
 }  // namespace tlsdev
