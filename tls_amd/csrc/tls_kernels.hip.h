@@ -819,80 +819,89 @@ __device__ __forceinline__ double wave_inclusive_sum(double v) {
     return v;
 }
 
-// Scan element of the one-pass cumsum: the composite parity map since the last (predicted) binade
-// change inside the scanned range, or since its start when `reset` is 0.  All-zero bits = identity.
-struct SegMap {
-    double i0, i1;
-    int reset;
+// ---------------------------------------------------------------------------------------
+// One block of the exact sequential prefix sum, elements held in registers (second formulation).
+//
+// Inside the binade [2^m, 2^(m+1)) every partial sum is a multiple of u = 2^(m-52).  Adding x rounds
+// to S + RN_u(x) where RN_u(x) = (2^m + x) - 2^m does NOT depend on S -- except when x lies exactly
+// half way between two multiples of u (a TIE: |x - RN_u(x)| == u/2, about one element per binade for
+// noisy flux), where round-to-even looks at the parity of S.  So the elements fall into two classes:
+//   ordinary   the step is the constant RN_u(x); sums of such steps inside one binade are exact under
+//              ANY association (multiples of u below 2^(m+1)): a plain parallel prefix sum;
+//   special    ties and the elements that carry the sum into the next binade (and the first element of
+//              the block): their step is whatever the hardware's fp64 addition S + x gives, which is
+//              the sequential step by definition.  A handful per block, chained one after the other.
+// Which binade a partial sum lies in is PREDICTED from a plain re-associated prefix sum P (phase A); the
+// ordinary steps are formed for the predicted binades (phase B), the specials go to a small table, and
+// every wave chains the wave totals and the table for itself to obtain the exact sum at its own start
+// and behind every special inside its range.  Phase E then runs the ACTUAL recurrence over the thread's
+// elements from its start value (constant step; plain addition for ties and binade changes), so a
+// thread's values are exact whenever its start value is.  The start values are verified, not trusted:
+// thread T+1's start must equal thread T's end bit for bit, and thread 0 starts from s0 -- by induction
+// every value is the sequential sum.  Any mismatch (a mispredicted binade, more specials than table
+// slots) sends the whole block through sequential_cumsum_by_binade.  Three workgroup barriers.
+constexpr int kMaxSpecial = 32;   // special elements handled per block by the fast path
+struct SegSum {                   // scan element: sum of the ordinary steps behind the last special of the
+    double sum;                   //   scanned range (or of the whole range), and that special's table
+    int tag;                      //   slot + 1 (0: no special inside)
 };
-// x (lower elements), then y; `b`: the binade y's elements live in (used when y holds no change)
-__device__ __forceinline__ SegMap seg_combine(const SegMap& x, const SegMap& y, const BinadeD& b) {
-    StepD xm, ym;
-    xm.i0 = x.i0; xm.i1 = x.i1; ym.i0 = y.i0; ym.i1 = y.i1;
-    const StepD c = compose(xm, ym, b);
-    SegMap z;
-    z.reset = x.reset | y.reset;
-    z.i0 = y.reset ? y.i0 : c.i0;
-    z.i1 = y.reset ? y.i1 : c.i1;
+__device__ __forceinline__ SegSum seg_combine(const SegSum& x, const SegSum& y) {   // x (lower elements), then y
+    SegSum z;
+    z.tag = y.tag ? y.tag : x.tag;
+    z.sum = y.tag ? y.sum : x.sum + y.sum;
     return z;
 }
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ SegMap dpp_seg(const SegMap& v) {
-    SegMap o;
-    o.i0 = dpp_f64<CTRL, ROW_MASK>(v.i0);
-    o.i1 = dpp_f64<CTRL, ROW_MASK>(v.i1);
-    o.reset = dpp_i32<CTRL, ROW_MASK>(v.reset);
+__device__ __forceinline__ SegSum dpp_seg(const SegSum& v) {
+    SegSum o;
+    o.sum = dpp_f64<CTRL, ROW_MASK>(v.sum);
+    o.tag = dpp_i32<CTRL, ROW_MASK>(v.tag);
     return o;
 }
-__device__ __forceinline__ SegMap wave_inclusive_seg(SegMap v, const BinadeD& b) {
-    v = seg_combine(dpp_seg<kDppRowShr1, 0xF>(v), v, b);
-    v = seg_combine(dpp_seg<kDppRowShr2, 0xF>(v), v, b);
-    v = seg_combine(dpp_seg<kDppRowShr4, 0xF>(v), v, b);
-    v = seg_combine(dpp_seg<kDppRowShr8, 0xF>(v), v, b);
-    v = seg_combine(dpp_seg<kDppBcast15, 0xA>(v), v, b);
-    v = seg_combine(dpp_seg<kDppBcast31, 0xC>(v), v, b);
+__device__ __forceinline__ SegSum wave_inclusive_seg(SegSum v) {
+    v = seg_combine(dpp_seg<kDppRowShr1, 0xF>(v), v);
+    v = seg_combine(dpp_seg<kDppRowShr2, 0xF>(v), v);
+    v = seg_combine(dpp_seg<kDppRowShr4, 0xF>(v), v);
+    v = seg_combine(dpp_seg<kDppRowShr8, 0xF>(v), v);
+    v = seg_combine(dpp_seg<kDppBcast15, 0xA>(v), v);
+    v = seg_combine(dpp_seg<kDppBcast31, 0xC>(v), v);
     return v;
 }
-// the running sum after a range with composite map `m` that stays inside the binade of S
-__device__ __forceinline__ double apply_map(double S, double i0, double i1) { return S + (mantissa_bit0(S) ? i1 : i0); }
+struct BinadeU {                  // constants of one binade for the constant-step form
+    double c0, half_u, sat;       // 2^m, u/2 = 2^(m-53) (0 in the lowest binades: everything is "special"), 2^(m+1)
+};
+__device__ __forceinline__ BinadeU binade_u(int m) {   // m in [-1022, 1023]
+    BinadeU b;
+    b.c0 = __longlong_as_double((long long)(m + 1023) << 52);
+    b.half_u = m - 53 >= -1022 ? __longlong_as_double((long long)(m - 53 + 1023) << 52) : 0.0;
+    b.sat = m < 1023 ? __longlong_as_double((long long)(m + 1024) << 52) : INFINITY;
+    return b;
+}
 
 // LDS scratch of exact_cumsum_block (shares its slot with CumsumScratch: the fallback runs after it)
 struct Cumsum2Scratch {
     double wsum[kMaxWaves];          // A: plain sums of the waves
-    SegMap wseg[kMaxWaves];          // B: composite map of every wave (behind its last binade change, if any)
-    StepD tab_H[kMaxSeg];            // composite of the owner wave's elements in front of the element that
-                                     //    enters binade m_first + slot (since the wave's start or its previous change)
-    double tab_f[kMaxSeg];           // addend of that element
+    SegSum wseg[kMaxWaves];          // B: ordinary-step total of every wave (behind its last special, if any)
+    double tab_H[kMaxSpecial];       // ordinary steps of the owner wave in front of the special (since the
+                                     //    wave's start or its previous special)
+    double tab_f[kMaxSpecial];       // the special element itself
+    unsigned int tab_key[kMaxSpecial];  // thread * 32 + element slot: orders the specials, names the owner wave
     double wstart[kMaxWaves + 1];    // E: exact running sum at the first element of every wave (chain value)
     double wendv[kMaxWaves];         //    ... and behind its last one (recurrence value)
-    unsigned int wmask[kMaxWaves];   // binades entered inside each wave's range (bit = slot)
-    double x_first;                  // first element of the block: slot 0 is the binade it leads into
+    unsigned int n_special;
     int fail;                        // some check failed: the block is redone by the per-binade routine
 };
 static_assert(sizeof(Cumsum2Scratch) <= kCumsumScratchBytes, "cumsum scratch does not fit its slot");
-static_assert(kMaxSeg <= 32 && kMaxSeg <= kWave && kMaxWaves <= kWave, "slot tables are held one entry per lane");
+static_assert(kMaxSpecial <= kWave && kMaxWaves <= kWave, "the tables are held one entry per lane");
 
-// One block of the exact sequential prefix sum, elements held in registers:
 //     C[k0] = s0,  C[k+1] = fl(C[k] + f[k])  for k in [k0, kb),   kb - k0 <= blockDim.x * PER.
-// Thread T owns `per` <= PER consecutive elements (slots past its range hold 0.0, the identity of every
-// step below).  Three workgroup barriers:
-//   A  plain (re-associated) prefix sums P predict in which binade every partial sum lies;
-//   B  every thread composes the parity maps of its elements between the predicted binade changes; a
-//      segmented wave scan, the wave totals and a table of the few elements that change the binade go
-//      to LDS.  Behind the barrier every wave chains the wave totals and those elements for itself
-//      (two additions per step) and obtains the exact sum at its own start and behind every change
-//      inside its range, hence the start value of every lane;
-//   E  every thread runs the ACTUAL recurrence over its elements from its start value (parity step
-//      inside the binade, plain fp64 addition when the sum leaves it), so its values are exact
-//      whenever its start value is.  The start values are verified, not trusted: thread T+1's start
-//      must equal thread T's end, bit for bit, and thread 0 starts from s0 -- by induction every
-//      value is the sequential sum.  Any mismatch (a mispredicted binade, more binades than table
-//      slots) sends the whole block through sequential_cumsum_by_binade.
+// Thread T owns `per` <= PER consecutive elements (slots past its range hold 0.0).
 // ALIASED: C[k+1] is stored over f[k] (f == C + 1); the elements are then restored before a fallback.
 // Returns C[kb].
 template <int PER, bool ALIASED>
 __device__ __forceinline__ double exact_cumsum_block(const double* f, double* C, int k0, int kb, double s0,
                                                      Cumsum2Scratch* cs, unsigned long long* dbg) {
+    static_assert(PER <= 32, "the special key packs the element slot into 5 bits");
     PhaseClock cpc; cpc.start(dbg);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
@@ -904,8 +913,7 @@ __device__ __forceinline__ double exact_cumsum_block(const double* f, double* C,
     double x[PER];
 #pragma unroll
     for (int e = 0; e < PER; ++e) x[e] = e < mine ? f[lo + e] : 0.0;
-    if (tid < kMaxWaves) cs->wmask[tid] = 0u;
-    if (tid == 0) { cs->fail = 0; cs->x_first = x[0]; }
+    if (tid == 0) { cs->fail = 0; cs->n_special = 0u; }
     // ---- A: plain prefix sums ------------------------------------------------------------------
     double local = 0.0;
 #pragma unroll
@@ -915,105 +923,103 @@ __device__ __forceinline__ double exact_cumsum_block(const double* f, double* C,
     __syncthreads();                                                                        // 1
     double wave_base = s0;
     for (int v = 0; v < wave; ++v) wave_base += cs->wsum[v];   // the same additions in every thread of the wave
-    // The end of my range IS the start of the next thread's: one definition for both sides, so the
-    // predicted binades form one sequence over the block.
+    // The end of my range IS the start of the next thread's: one definition for both sides.
     const double p_start = wave_base + dpp_f64<kDppWaveShr1, 0xF>(incl);   // lane 0: + 0.0
     double p_next = dpp_f64<kDppWaveShl1, 0xF>(p_start);                   // lane 63: replaced below
     if (lane == kWave - 1) p_next = (wave_base + cs->wsum[wave]) + 0.0;    // = p_start of the next wave's lane 0
     cpc.mark(14);
-    // ---- B: parity maps between the predicted binade changes --------------------------------------
-    // slots count binades from the one the block's first element leads into (the sum may start at 0.0,
-    // a thousand binades below its first partial sum)
-    const int m_first = unbiased_exponent(s0 + cs->x_first, nullptr);
-    const int m_lo = unbiased_exponent(p_start, nullptr);
-    const BinadeD b_lo = binade_constants(m_lo);
-    SegMap acc; acc.i0 = 0.0; acc.i1 = 0.0; acc.reset = 0;
-    StepD head; head.i0 = 0.0; head.i1 = 0.0;      // composite in front of the first change in my range
-    const int slot_in = m_lo - m_first;            // the segment my range starts in
-    int slot_first = -1;                           // slot entered by the first change in my range
+    // ---- B: ordinary steps for the predicted binades; specials go to the table --------------------------
+    SegSum acc; acc.sum = 0.0; acc.tag = 0;
+    double head = 0.0;                             // ordinary steps in front of the first special in my range
+    int slot_first = -1;                           // table slot of the first special in my range
     bool overflow = false;
     {
-        StepD seg; seg.i0 = 0.0; seg.i1 = 0.0;
-        BinadeD bk = b_lo;
-        int m_k = m_lo;
-        double p = p_start;
+        BinadeU bk = binade_u(unbiased_exponent(p_start, nullptr));
+        double seg = 0.0, p = p_start;
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             if (e < mine) {
                 const double p_after = e == mine - 1 ? p_next : p + x[e];
-                const int m_after = unbiased_exponent(p_after, nullptr);
-                if (m_after != m_k || lo + e == k0) {           // leaves the binade (or opens the block)
-                    const int slot = m_after - m_first;
-                    const bool ok = slot >= 0 && slot < kMaxSeg;
+                const double i0 = (bk.c0 + x[e]) - bk.c0;                   // RN_u(x)
+                const bool leaves = !(p_after < bk.sat);
+                const bool special = leaves || fabs(x[e] - i0) == bk.half_u || lo + e == k0;
+                if (special) {                                                // rare
+                    const unsigned int slot = atomicAdd(&cs->n_special, 1u);
+                    const bool ok = slot < (unsigned int)kMaxSpecial;
                     overflow |= !ok;
-                    if (slot_first < 0) { head = seg; slot_first = ok ? slot : kMaxSeg; }
-                    else if (ok) cs->tab_H[slot] = seg;          // in front of it: my elements since my previous change
-                    if (ok) { cs->tab_f[slot] = x[e]; atomicOr(&cs->wmask[wave], 1u << slot); }
-                    bk = binade_constants(m_after);
-                    seg.i0 = 0.0; seg.i1 = 0.0;
-                    acc.reset = 1;
+                    if (ok) {
+                        cs->tab_key[slot] = (unsigned int)tid * 32u + (unsigned int)e;
+                        cs->tab_f[slot] = x[e];
+                        if (slot_first >= 0) cs->tab_H[slot] = seg;            // since my previous special
+                    }
+                    if (slot_first < 0) { head = seg; slot_first = ok ? (int)slot : kMaxSpecial; }
+                    acc.tag = ok ? (int)slot + 1 : kMaxSpecial;
+                    if (leaves) bk = binade_u(unbiased_exponent(p_after, nullptr));
+                    seg = 0.0;
                 } else {
-                    seg = compose(seg, step_of(x[e], bk), bk);
+                    seg += i0;
                 }
-                m_k = m_after;
                 p = p_after;
             }
         }
         if (slot_first < 0) head = seg;
-        acc.i0 = seg.i0; acc.i1 = seg.i1;
+        acc.sum = seg;
     }
-    const SegMap inc = wave_inclusive_seg(acc, b_lo);
-    const SegMap exc = dpp_seg<kDppWaveShr1, 0xF>(inc);        // lanes in front of me, inside my wave
-    if (slot_first >= 0 && slot_first < kMaxSeg) {
-        // in front of my first change: the wave's elements since its previous change (or its start), then mine
-        StepD em; em.i0 = exc.i0; em.i1 = exc.i1;
-        cs->tab_H[slot_first] = compose(em, head, b_lo);
-    }
+    const SegSum inc = wave_inclusive_seg(acc);
+    const SegSum exc = dpp_seg<kDppWaveShr1, 0xF>(inc);        // the lanes in front of me, inside my wave
+    // in front of my first special: the wave's ordinary steps since its previous special (or its start), then mine
+    if (slot_first >= 0 && slot_first < kMaxSpecial) cs->tab_H[slot_first] = exc.sum + head;
     if (lane == kWave - 1) cs->wseg[wave] = inc;
     if (overflow) cs->fail = 1;
     cpc.mark(15);
     __syncthreads();                                                                        // 2
-    // ---- chain: every wave for itself, over the earlier waves and the binade changes ------------------
-    // lane v holds wave v's total and change mask, lane j the table entries of slot j
-    double w_i0 = 0.0, w_i1 = 0.0, h_i0 = 0.0, h_i1 = 0.0, h_f = 0.0;
-    unsigned int w_mask = 0u;
-    if (lane < nw) { w_i0 = cs->wseg[lane].i0; w_i1 = cs->wseg[lane].i1; w_mask = cs->wmask[lane]; }
-    if (lane < kMaxSeg) { h_i0 = cs->tab_H[lane].i0; h_i1 = cs->tab_H[lane].i1; h_f = cs->tab_f[lane]; }
-    double S = s0;
-    double seg_start = 0.0;                        // lane j: exact sum behind the element that enters slot j (my wave's)
-    for (int v = 0; v <= wave; ++v) {
-        if (v == wave && lane == 0) cs->wstart[wave] = S;
-        const double S_wave = S;
-        unsigned int left = (unsigned int)lane_value((int)w_mask, v);
-        while (left) {
-            const int j = __builtin_ctz(left);
-            left &= left - 1u;
-            S = apply_map(S, lane_value(h_i0, j), lane_value(h_i1, j));   // up to the element that leaves the binade
-            S = S + lane_value(h_f, j);                                    // its own step: plain fp64
-            if (v == wave && lane == j) seg_start = S;
+    // ---- chain: every wave for itself, over the earlier waves and the specials up to its own ----------------
+    // lane v holds wave v's total, lane j the table entry of slot j and its rank in element order
+    const int n_sp = (int)(cs->n_special < (unsigned int)kMaxSpecial ? cs->n_special : (unsigned int)kMaxSpecial);
+    double w_sum = 0.0, h_H = 0.0, h_f = 0.0;
+    unsigned int h_key = 0xffffffffu;
+    if (lane < nw) w_sum = cs->wseg[lane].sum;
+    if (lane < n_sp) { h_H = cs->tab_H[lane]; h_f = cs->tab_f[lane]; h_key = cs->tab_key[lane]; }
+    int rank = 0;
+    for (int i = 0; i < n_sp; ++i) rank += ((unsigned int)lane_value((int)h_key, i) < h_key) ? 1 : 0;
+    double S = s0, S_wave = s0;
+    double seg_start = 0.0;                        // lane j: exact sum behind special j (those of my wave)
+    {
+        int r = 0;
+        for (int v = 0; v <= wave; ++v) {
+            if (v == wave) S_wave = S;
+            while (r < n_sp) {
+                const unsigned long long sel = __ballot(rank == r && lane < n_sp);
+                const int j = __ffsll((long long)sel) - 1;
+                const unsigned int key = (unsigned int)lane_value((int)h_key, j);
+                if ((int)(key >> 11) != v) break;                              // key / (32 * 64): the owner wave
+                S = S + lane_value(h_H, j);                                    // ordinary steps up to the special: exact
+                S = S + lane_value(h_f, j);                                    // its own step: the hardware's fp64 addition
+                if (v == wave && lane == j) seg_start = S;
+                ++r;
+            }
+            if (v < wave) S = S + lane_value(w_sum, v);
         }
-        if (v < wave) S = apply_map(S, lane_value(w_i0, v), lane_value(w_i1, v));
-        else S = S_wave;                            // my own wave: keep its start value
     }
-    // my start value: the wave's start, or the sum behind the last change in front of me in my wave
+    if (lane == 0) cs->wstart[wave] = S_wave;
+    // my start value: the wave's start, or the sum behind the last special in front of me in my wave
     // (the shuffle runs in ALL lanes, outside the select: ds_bpermute returns 0 for a source lane that is
-    // masked off, and the lane that holds a segment's start need not itself lie behind a change)
-    const double seg_base = __shfl(seg_start, slot_in < 0 ? 0 : (slot_in < kWave ? slot_in : kWave - 1), kWave);
-    const double base = exc.reset ? seg_base : S;
-    const double S_start = apply_map(base, exc.i0, exc.i1);
+    // masked off, and the lane that holds a special's sum need not itself lie behind one)
+    const double seg_base = __shfl(seg_start, exc.tag > 0 && exc.tag <= kMaxSpecial ? exc.tag - 1 : 0, kWave);
+    const double S_start = (exc.tag ? seg_base : S_wave) + exc.sum;
     cpc.mark(16);
     // ---- E: the recurrence itself ---------------------------------------------------------------------
     double S_run = S_start;
     {
-        BinadeD bk = binade_constants(unbiased_exponent(S_run, nullptr));
+        BinadeU bk = binade_u(unbiased_exponent(S_run, nullptr));
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             if (e < mine) {
-                const StepD t = step_of(x[e], bk);
-                double Sn = S_run + (mantissa_bit0(S_run) ? t.i1 : t.i0);
-                if (!(Sn < bk.sat)) {                           // leaves the binade: the plain sum IS the step
-                    Sn = S_run + x[e];
-                    bk = binade_constants(unbiased_exponent(Sn, nullptr));
+                const double i0 = (bk.c0 + x[e]) - bk.c0;
+                double Sn = S_run + i0;
+                if (fabs(x[e] - i0) == bk.half_u || !(Sn < bk.sat)) {   // a tie, or the sum leaves the binade:
+                    Sn = S_run + x[e];                                     // the plain addition IS the step
+                    if (!(Sn < bk.sat)) bk = binade_u(unbiased_exponent(Sn, nullptr));
                 }
                 S_run = Sn;
                 C[lo + e + 1] = Sn;
@@ -1034,13 +1040,14 @@ __device__ __forceinline__ double exact_cumsum_block(const double* f, double* C,
     for (int v = 0; v + 1 < nw; ++v) failed |= !(cs->wendv[v] == cs->wstart[v + 1]);
     const double s_end = cs->wendv[nw - 1];
     if (dbg && tid == 0) { atomicAdd(&dbg[10], 1ull); if (failed) atomicAdd(&dbg[11], 1ull); }
-#ifdef TLS_CUMSUM_DIAG   // developer build: why a block failed (slots 18..22 of the debug-kernel's clock buffer)
+#ifdef TLS_CUMSUM_DIAG   // developer build: why a block failed (slots 18..22 of the debug kernel's clock buffer)
     if (dbg) {
         if (overflow) atomicAdd(&dbg[18], 1ull);
         if (lane == 0 && bad_lanes) atomicAdd(&dbg[19], (unsigned long long)__popcll(bad_lanes));
         if (tid == 0) {
             for (int v = 0; v + 1 < nw; ++v) if (!(cs->wendv[v] == cs->wstart[v + 1])) atomicAdd(&dbg[20], 1ull);
             if (!(S_start == s0)) atomicAdd(&dbg[21], 1ull);
+            atomicAdd(&dbg[23], (unsigned long long)cs->n_special);
         }
         if (lane == 0 && bad_lanes) atomicMin(&dbg[22], (unsigned long long)(wave * 64 + __ffsll((long long)bad_lanes) - 1));
     }
@@ -1842,6 +1849,7 @@ tls_search_kernel(const SearchArgs a) {
             const int units0 = widths_c[k_lo].n_chunks;  // the shortest width has the most positions
             const int unit_lo = p_lo / kR;               // tile bounds are multiples of kR * 64
             const int unit_hi = p_hi / kR < units0 ? p_hi / kR : units0;
+            const int n_dense = k_x - k_lo;
             for (int tile = wave; unit_lo + tile * kWave < unit_hi; tile += nw) {
                 const int unit = unit_lo + tile * kWave + lane;
                 const int u0 = unit * kR;
@@ -1849,6 +1857,10 @@ tls_search_kernel(const SearchArgs a) {
                 double c_lo[kR];
 #pragma unroll
                 for (int r = 0; r < kR; ++r) c_lo[r] = c_base[u0c + r];
+                // Lane j collects the live mask of row k_lo + j of this 64-unit tile; the list slots of
+                // ALL rows are then reserved with one LDS atomic instruction (one lane per row) instead
+                // of one dependent atomic round trip per row.
+                unsigned long long row_mask = 0ull;
                 // kRowBatch durations per step: all LDS reads of the step are in flight together
                 constexpr int kRowBatch = 4;
                 for (int k = k_lo; k < k_x; k += kRowBatch) {
@@ -1877,9 +1889,28 @@ tls_search_kernel(const SearchArgs a) {
                             const int cls = depth_class(dC[j], inv[j], dmin);
                             bool live = cls > 0;
                             if (cls < 0) live = depth_exact(dC[j], (double)dv[j], dmin);  // rare: on the threshold
-                            push_live(live && unit < unit_hi, (unsigned int)unit, &rt.live[k + j - k_lo],
-                                      chunk_list + widths_c[k + j].list_base, lane);
+                            if (n_dense <= kWave) {
+                                const unsigned long long mask = __ballot(live && unit < unit_hi);
+                                if (lane == k + j - k_lo) row_mask = mask;
+                            } else {   // more dense rows than lanes (never with the default duration grid)
+                                push_live(live && unit < unit_hi, (unsigned int)unit, &rt.live[k + j - k_lo],
+                                          chunk_list + widths_c[k + j].list_base, lane);
+                            }
                         }
+                    }
+                }
+                if (n_dense <= kWave) {
+                    unsigned int base = 0;
+                    const unsigned int mine = (unsigned int)__popcll(row_mask);
+                    if (mine) base = atomicAdd(&rt.live[lane], mine);      // lane j: row k_lo + j
+                    const unsigned long long rows_hit = __ballot(mine != 0u);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    for (unsigned long long left = rows_hit; left; left &= left - 1ull) {
+                        const int j = __ffsll((long long)left) - 1;
+                        const unsigned long long mask = (unsigned long long)lane_value((long long)row_mask, j);
+                        const unsigned int b0 = (unsigned int)lane_value((int)base, j);
+                        if ((mask >> lane) & 1ull)
+                            chunk_list[widths_c[k_lo + j].list_base + b0 + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
                     }
                 }
             }
@@ -1894,6 +1925,9 @@ tls_search_kernel(const SearchArgs a) {
             const int n_units = widths_c[k].n_chunks;
             const double inv_d = widths_c[k].inv_d;
             unsigned int* list = chunk_list + widths_c[k].list_base;
+            // the row belongs to this wave alone: its list tail is a register, not an LDS atomic
+            unsigned int n_listed = 0;
+            const unsigned long long below = (1ull << lane) - 1ull;
             if (widths_c[k].tiled) {
                 const int span = kR * xth;  // samples between the first windows of two units
                 const int unit_lo = (p_lo + span - 1) / span;
@@ -1911,7 +1945,10 @@ tls_search_kernel(const SearchArgs a) {
                     const int cls = depth_class(dC, inv_d, dmin);
                     bool live = cls > 0;
                     if (cls < 0) live = depth_exact(dC, (double)d, dmin);
-                    push_live(live && unit < unit_hi, (unsigned int)unit, &rt.live[k - k_lo], list, lane);
+                    live = live && unit < unit_hi;
+                    const unsigned long long mask = __ballot(live);
+                    if (live) list[n_listed + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
+                    n_listed += (unsigned int)__popcll(mask);
                 }
             } else {
                 const int unit_lo = (p_lo + xth - 1) / xth;
@@ -1925,9 +1962,12 @@ tls_search_kernel(const SearchArgs a) {
                         const int cls = depth_class(dC, inv_d, dmin);
                         live = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
                     }
-                    push_live(live, (unsigned int)unit, &rt.live[k - k_lo], list, lane);
+                    const unsigned long long mask = __ballot(live);
+                    if (live) list[n_listed + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
+                    n_listed += (unsigned int)__popcll(mask);
                 }
             }
+            if (lane == 0) rt.live[k - k_lo] = n_listed;
         }
         __syncthreads();
         pc.mark(9);

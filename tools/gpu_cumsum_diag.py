@@ -14,5 +14,5 @@ for name, v in cases.items():
         ph = ctx.phase_cycles()
         keys = list(ph.keys())
         raw = [ph[k] for k in keys]
-        print(name, threads, "exact", bool(numpy.array_equal(got, want)), "blocks", raw[10], "fails", raw[11], "overflow", raw[18],
+        print(name, threads, "exact", bool(numpy.array_equal(got, want)), "blocks", raw[10], "fails", raw[11], "specials", raw[23], "overflow", raw[18],
               "bad_lanes", raw[19], "wave_mismatch", raw[20], "t0", raw[21], "first_bad_thread", raw[22] if raw[22] < 2**63 else None, flush=True)
