@@ -203,7 +203,8 @@ class Context(object):
         key = (len(t), hash(t.tobytes()), len(periods), hash(periods.tobytes()),
                hash(_f8(table.values).tobytes()), hash(_i8(table.width).tobytes()),
                hash(_f8(table.overshoot).tobytes()), tuple(sorted((k, float(v)) for k, v in params.items())),
-               os.environ.get("TLS_PRUNE"), os.environ.get("TLS_PRUNE_MIN_LIVE"), os.environ.get("TLS_SORT2"))
+               os.environ.get("TLS_PRUNE"), os.environ.get("TLS_PRUNE_MIN_LIVE"), os.environ.get("TLS_SORT2"),
+               os.environ.get("TLS_SORT3"))
         reused = False
         if key == self._plan_key and len(y) == len(t) == len(dy):
             try:

@@ -84,6 +84,8 @@ struct tls_ctx {
     DevBuf<unsigned int> d_queue, d_squeue, d_lists, d_perm;   // d_squeue: the search kernel's self-rewinding queue
     DevBuf<double> d_curve_S0, d_curve_w0;   // survey batches
     bool sort2 = false;                      // tiled variant: two-level sort
+    bool sort3 = false;                      // tiled variant, one light curve: fused partition + per-bin sort + prefix sum
+    DevBuf<unsigned long long> d_sort3;      // its pass-1 output
     int batch_curves = 1;                    // light curves the next launch searches (tls_search_batch)
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
     size_t list_stride = 0;
@@ -319,6 +321,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     a.prune_min_live = ctx->prune_min_live; a.p2_shift = ctx->p2_shift; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
     a.sort2 = ctx->sort2 ? 1 : 0;
+    a.sort3 = ctx->sort3 ? 1 : 0; a.sort3_scratch = ctx->d_sort3.ptr;
     a.n_curves = ctx->batch_curves; a.curve_S0 = ctx->d_curve_S0.ptr; a.curve_w0 = ctx->d_curve_w0.ptr;
     a.perm_scratch = ctx->d_perm.ptr;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
@@ -402,7 +405,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_chi2.release(); ctx->d_depth.release(); ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release(); ctx->d_row.release(); ctx->d_order.release();
     ctx->d_rows.release(); ctx->d_widths.release(); ctx->d_counters.release();
-    ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
+    ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     for (auto& evp : ctx->ev_pool) { (void)hipEventDestroy(evp.first); (void)hipEventDestroy(evp.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -479,7 +482,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->resident = resident_bytes <= kLdsPerCU && n <= 65535;
     if (ctx->resident) {
         ctx->nb = (int)n;
-        ctx->tile_len = 0; ctx->tile_halo = 0; ctx->sort2 = false;
+        ctx->tile_len = 0; ctx->tile_halo = 0; ctx->sort2 = false; ctx->sort3 = false;
         ctx->lds_bytes = resident_bytes;
         const size_t per_cu = kLdsPerCU / resident_bytes;
         ctx->threads = per_cu >= 2 ? 512 : 1024;
@@ -520,11 +523,22 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
                                                 buffers * 8 * (tile + halo));
         ctx->threads = 1024;
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)ctx->n_cu);
+        if (const char* env = std::getenv("TLS_BLOCKS"))   // developer switch: workgroups in flight (memory-system experiments)
+            ctx->blocks = std::max(1, std::min(ctx->blocks, std::atoi(env)));
         // two-level sort with sequential HBM accesses (fold_and_sort_tiled) when its LDS windows fit
         const size_t sort2_bytes = hdr + (size_t)tlsdev::sort2_lds_bytes((int)n);
         const char* env_sort2 = std::getenv("TLS_SORT2");
         ctx->sort2 = sort2_bytes <= kLdsPerCU && !(env_sort2 && std::atoi(env_sort2) == 0);
         if (ctx->sort2) ctx->lds_bytes = std::max(ctx->lds_bytes, sort2_bytes);
+        // one light curve per launch: partition into large phase bins, per-bin LDS sort fused with the prefix sum
+        const size_t sort3_bytes = hdr + (size_t)tlsdev::sort3_lds_bytes();
+        const char* env_sort3 = std::getenv("TLS_SORT3");
+        ctx->sort3 = sort3_bytes <= kLdsPerCU && tlsdev::sort3_bins((int)n) <= tlsdev::kSort3MaxBins && (int64_t)W <= n &&
+                     !(env_sort3 && std::atoi(env_sort3) == 0);
+        if (ctx->sort3) {
+            ctx->lds_bytes = std::max(ctx->lds_bytes, sort3_bytes);
+            TLS_HIP(ctx, ctx->d_sort3.reserve((size_t)ctx->blocks * (size_t)tlsdev::sort3_scratch_doubles((int)n)));
+        }
         TLS_HIP(ctx, ctx->d_scratch.reserve((size_t)ctx->blocks * regions * region_doubles));
     }
     // per-width work units of phase 3 (M is fixed for the plan, so these are period independent)

@@ -127,6 +127,29 @@ __device__ __forceinline__ void load_taps(const double* p, double (&x)[kU]) {
     }
 }
 
+// Streaming accesses to the per-workgroup HBM slabs (written once, read once or twice by the same CU):
+// non-temporal, so that they do not push the light curve (t, y: read at random by every workgroup of
+// the XCD) out of the L2.  TLS_NT=0 builds plain accesses for A/B timing.
+#ifndef TLS_NT
+#define TLS_NT 1
+#endif
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if TLS_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void stream_store(T* p, T v) {
+#if TLS_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // Ordering point for code in which every wavefront works on LDS (and HBM) of its own: the memory
 // operations of the wave issued so far are complete before any later one starts.  No other wave
 // is waited for.
@@ -136,20 +159,68 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic only: the LDS operations of every wave are complete, global
+// loads and stores STAY IN FLIGHT across it.  __syncthreads() also drains the vector-memory counter,
+// i.e. every barrier between two LDS steps would expose a full HBM round trip of whatever was
+// prefetched or written just before -- on the slab path that was most of the time.  Use it only where
+// no thread consumes global data another thread of the workgroup has just written.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// All vector-memory operations of this wave issued so far are complete.  Placed BEFORE a batch of
+// stores where only old loads are pending: the compiler's wait-count pass treats a counter with loads
+// AND stores pending as out of order and turns the next wait on any load into a full drain, i.e. a
+// prefetched value first used behind a batch of stores would wait for those stores.
+__device__ __forceinline__ void vmem_wait_all() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt untouched (gfx9 encoding)
+}
+
 // dst[k] = src[k] for k in [0, count), all threads of the workgroup, four global reads in flight per
 // thread (the compiler does not overlap them itself: the store of one may alias the read of the next)
 __device__ __forceinline__ void copy_in_flight4(double* dst, const double* src, int count) {
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int k = tid; k < count; k += 4 * nt) {
         const int k1 = k + nt, k2 = k + 2 * nt, k3 = k + 3 * nt;
-        const double v0 = src[k];
-        const double v1 = k1 < count ? src[k1] : 0.0;
-        const double v2 = k2 < count ? src[k2] : 0.0;
-        const double v3 = k3 < count ? src[k3] : 0.0;
+        const double v0 = stream_load(src + k);     // the source is a slab in HBM
+        const double v1 = k1 < count ? stream_load(src + k1) : 0.0;
+        const double v2 = k2 < count ? stream_load(src + k2) : 0.0;
+        const double v3 = k3 < count ? stream_load(src + k3) : 0.0;
         dst[k] = v0;
         if (k1 < count) dst[k1] = v1;
         if (k2 < count) dst[k2] = v2;
         if (k3 < count) dst[k3] = v3;
+    }
+}
+
+// Tiled variant: `count` samples of the PATCHED folded series, from position p_lo on, go from the HBM
+// slab into an LDS tile as e = 1 - f (or e*w and w).  The slab holds the folded flux f[0..n) (and
+// weights) only once: position p in [n, M) is sample p - n again (core.py:126-132), positions from M
+// on are zero.  Eight global reads in flight per thread.
+template <bool UNIFORM_W>
+__device__ __forceinline__ void stage_samples(double* tile_e, double* tile_w, const double* f, const double* w,
+                                              int p_lo, int count, int n, int M) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    constexpr int kInFlight = 8;
+    for (int k0 = tid; k0 < count; k0 += kInFlight * nt) {
+        double fv[kInFlight], wv[kInFlight];
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) {
+            const int k = k0 + j * nt, p = p_lo + k;
+            const bool ok = k < count && p < M;
+            const int src = p < n ? p : p - n;
+            fv[j] = ok ? stream_load(f + src) : 1.0;
+            if constexpr (!UNIFORM_W) wv[j] = ok ? stream_load(w + src) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) {
+            const int k = k0 + j * nt;
+            if (k < count) {
+                double e = 1.0 - fv[j];
+                if constexpr (!UNIFORM_W) { e *= wv[j]; tile_w[k] = wv[j]; }
+                tile_e[k] = e;
+            }
+        }
     }
 }
 
@@ -217,6 +288,8 @@ struct SearchArgs {
     long long list_stride;      // entries per workgroup
     // survey mode: n_curves light curves on the same time stamps share the fold + sort of a period
     int sort2;                  // tiled variant: use fold_and_sort_tiled (its LDS fits)
+    int sort3;                  // tiled variant, one light curve: fold_sort_cumsum_tiled
+    unsigned long long* sort3_scratch;   // [blocks][sort3_scratch_doubles(n)] pass-1 output of that path
     int n_curves;               // >= 1; curve c reads y + c*n (w + c*n), writes out_* + c*n_periods
     const double* curve_S0;     // [n_curves] S0 per curve (n_curves > 1; else S0 / w0 below)
     const double* curve_w0;     // [n_curves]
@@ -899,7 +972,7 @@ static_assert(kMaxSpecial <= kWave && kMaxWaves <= kWave, "the tables are held o
 // ALIASED: C[k+1] is stored over f[k] (f == C + 1); the elements are then restored before a fallback.
 // Returns C[kb].
 template <int PER, bool ALIASED>
-__device__ __forceinline__ double exact_cumsum_block(const double* f, double* C, int k0, int kb, double s0,
+__device__ __noinline__ double exact_cumsum_block(const double* f, double* C, int k0, int kb, double s0,
                                                      Cumsum2Scratch* cs, unsigned long long* dbg) {
     static_assert(PER <= 32, "the special key packs the element slot into 5 bits");
     PhaseClock cpc; cpc.start(dbg);
@@ -920,7 +993,7 @@ __device__ __forceinline__ double exact_cumsum_block(const double* f, double* C,
     for (int e = 0; e < PER; ++e) local += x[e];
     const double incl = wave_inclusive_sum(local);
     if (lane == kWave - 1) cs->wsum[wave] = incl;
-    __syncthreads();                                                                        // 1
+    lds_barrier();                                                                          // 1
     double wave_base = s0;
     for (int v = 0; v < wave; ++v) wave_base += cs->wsum[v];   // the same additions in every thread of the wave
     // The end of my range IS the start of the next thread's: one definition for both sides.
@@ -972,7 +1045,7 @@ __device__ __forceinline__ double exact_cumsum_block(const double* f, double* C,
     if (lane == kWave - 1) cs->wseg[wave] = inc;
     if (overflow) cs->fail = 1;
     cpc.mark(15);
-    __syncthreads();                                                                        // 2
+    lds_barrier();                                                                          // 2
     // ---- chain: every wave for itself, over the earlier waves and the specials up to its own ----------------
     // lane v holds wave v's total, lane j the table entry of slot j and its rank in element order
     const int n_sp = (int)(cs->n_special < (unsigned int)kMaxSpecial ? cs->n_special : (unsigned int)kMaxSpecial);
@@ -1035,7 +1108,8 @@ __device__ __forceinline__ double exact_cumsum_block(const double* f, double* C,
     const unsigned long long bad_lanes = __ballot(bad);
     if (bad_lanes != 0ull && lane == 0) cs->fail = 1;
     cpc.mark(17);
-    __syncthreads();                                                                        // 3
+    lds_barrier();                                                                          // 3 (LDS only: C in
+    // global memory is the caller's to publish; every thread has written only its own elements)
     bool failed = cs->fail != 0;
     for (int v = 0; v + 1 < nw; ++v) failed |= !(cs->wendv[v] == cs->wstart[v + 1]);
     const double s_end = cs->wendv[nw - 1];
@@ -1072,7 +1146,7 @@ template <bool ALIASED>
 __device__ __forceinline__ double exact_cumsum(const double* f, double* C, int count, Cumsum2Scratch* cs,
                                                unsigned long long* dbg = nullptr, double s_start = 0.0) {
     const int nt = blockDim.x;
-    if (count <= 0) { if (threadIdx.x == 0) C[0] = s_start; __syncthreads(); return s_start; }
+    if (count <= 0) { if (threadIdx.x == 0) C[0] = s_start; lds_barrier(); return s_start; }
     double s0 = s_start;
     for (int k0 = 0; k0 < count; ) {
         const int left = count - k0;
@@ -1081,7 +1155,7 @@ __device__ __forceinline__ double exact_cumsum(const double* f, double* C, int c
         else if (left <= 12 * nt) { kb = count; s0 = exact_cumsum_block<12, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
         else { kb = left <= 16 * nt ? count : k0 + 16 * nt; s0 = exact_cumsum_block<16, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
         k0 = kb;
-        if (k0 < count) __syncthreads();             // the scratch is rewritten by the next block
+        if (k0 < count) lds_barrier();               // the scratch is rewritten by the next block
     }
     return s0;
 }
@@ -1592,6 +1666,302 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
     return true;
 }
 
+// ---------------------------------------------------------------------------------------
+// Series in HBM, one light curve per launch: fold, stable sort and exact prefix sum in ONE sweep whose
+// HBM accesses are all sequential and issued in large batches (the first version of this path was
+// bound by exposed HBM latency: per-wave bins of ~160 points, 10 chunks of prefix sum, each with its
+// own round trip).
+//   pass 1  the points are partitioned into B = n/6144 coarse phase bins through an LDS staging
+//           buffer (8 K points per round): a 32-bit fixed-point phase key, the index AND the flux (and
+//           weight) of the point, every bin's points of a round leaving as one contiguous segment;
+//   pass 2  bin by bin (<= 8192 points, the whole workgroup): the points into registers (requested one
+//           bin ahead), an LDS bucket sort on the key (ties on the 32-bit key are decided by
+//           the exact fp64 phase, then the index: the order of numpy's stable sort, core.py:120),
+//           the sorted flux of the bin assembled in LDS, written out, and -- while it is there -- run
+//           through the exact prefix sum (exact_cumsum, carry from the previous bin), whose values are
+//           written out as well.  The folded flux is never read back for the prefix sum.
+//   patch   the prefix sum continues over the first W samples again (core.py:126-132).
+// The slab afterwards holds f[0..n) (and w) and C[0..M]; e = 1 - f is formed when a tile is staged.
+// Returns false (all threads alike) when a coarse bin overflows (phases piled up): the caller falls
+// back to the general path.
+constexpr int kSort3BinCap = 8192;      // points one coarse phase bin may hold
+constexpr int kSort3BinMean = 6144;     // target points per coarse bin
+constexpr int kSort3Fine = 4096;        // fine buckets of the per-bin LDS sort
+constexpr int kSort3Chunk = 16384;      // points partitioned per pass-1 round
+constexpr int kSort3MaxBins = 64;
+__host__ __device__ constexpr int sort3_bins(int n) {
+    return (n + kSort3BinMean - 1) / kSort3BinMean < 1 ? 1 : (n + kSort3BinMean - 1) / kSort3BinMean;
+}
+__host__ __device__ constexpr long long sort3_lds_bytes() {
+    // bin counters + the larger of the pass-1 staging (8 B per point) and the pass-2 arrays
+    // (flux / prefix-sum buffer, sorted entries, fine-bucket counters); the patch round reuses the front
+    const long long counters = 4LL * 4 * kSort3MaxBins;
+    const long long pass1 = 8LL * kSort3Chunk;
+    const long long pass2 = 8LL * (kSort3BinCap + 1) + 8 + 8LL * kSort3BinCap + 4LL * kSort3Fine;
+    const long long patch = 8LL * (kSort3Chunk + 1) + 8;
+    long long m = pass1 > pass2 ? pass1 : pass2;
+    m = m > patch ? m : patch;
+    return counters + m;
+}
+__host__ __device__ constexpr long long sort3_scratch_doubles(int n) {   // pass-1 output: entry, flux, weight per slot
+    return 3LL * sort3_bins(n) * kSort3BinCap;
+}
+
+// 32-bit fixed-point phase: monotone in the phase, uniform resolution 2^-32
+__device__ __forceinline__ unsigned int phase_key(double ph) {
+    return ph < 1.0 ? (unsigned int)(ph * 4294967296.0) : 0xffffffffu;
+}
+
+// exclusive prefix sum of cnt[0..nb) (LDS) in place, nb <= 8 * blockDim.x; two LDS barriers
+__device__ __forceinline__ void block_exclusive_scan8(unsigned int* cnt, int nb, unsigned int* wsum) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (kWave - 1), nw = nt / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int chunk = (nb + nt - 1) / nt;   // <= 8
+    const int lo = tid * chunk;
+    unsigned int c[8], local = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { c[e] = (e < chunk && lo + e < nb) ? cnt[lo + e] : 0u; local += c[e]; }
+    unsigned int incl = local;
+    incl += (unsigned int)dpp_i32<kDppRowShr1, 0xF>((int)incl);
+    incl += (unsigned int)dpp_i32<kDppRowShr2, 0xF>((int)incl);
+    incl += (unsigned int)dpp_i32<kDppRowShr4, 0xF>((int)incl);
+    incl += (unsigned int)dpp_i32<kDppRowShr8, 0xF>((int)incl);
+    incl += (unsigned int)dpp_i32<kDppBcast15, 0xA>((int)incl);
+    incl += (unsigned int)dpp_i32<kDppBcast31, 0xC>((int)incl);
+    if (lane == kWave - 1) wsum[wave] = incl;
+    lds_barrier();
+    unsigned int run = incl - local;
+    for (int v = 0; v < wave; ++v) run += wsum[v];
+    (void)nw;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < chunk && lo + e < nb) { cnt[lo + e] = run; run += c[e]; }
+    lds_barrier();
+}
+
+template <bool UNIFORM_W>
+__device__ __noinline__ bool fold_sort_cumsum_tiled(const double* t, const double* y, const double* w, int n, int W,
+                                                       double period, double* f_out, double* c_out, double* w_out,
+                                                       unsigned long long* g_ent, unsigned char* lds, unsigned int* wsum,
+                                                       Cumsum2Scratch* cs, PhaseClock& pc, unsigned long long* dbg) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int B = sort3_bins(n);
+    unsigned int* l_cnt = reinterpret_cast<unsigned int*>(lds);      // [B] points of the bin in this round
+    unsigned int* l_start = l_cnt + kSort3MaxBins;                   // [B]
+    unsigned int* g_cnt = l_start + kSort3MaxBins;                   // [B] points of the bin so far
+    unsigned int* flags = g_cnt + kSort3MaxBins;                     // [0]: overflow
+    unsigned char* area = lds + 4 * 4 * kSort3MaxBins;
+    constexpr int kE = kSort3BinCap / 1024;   // entries per thread in pass 2 (1024-thread workgroups)
+    if (kE * nt < kSort3BinCap) return false; // needs 1024 threads (uniform)
+    // pass-1 output, bin-major: entries (key << 32 | index), the flux and the weight of every point travel
+    // together -- a gather y[index] in pass 2 would be 70 000 random 64-byte requests per period and CU
+    const long long slots = (long long)B * kSort3BinCap;
+    double* g_y = reinterpret_cast<double*>(g_ent + slots);
+    double* g_w = g_y + slots;
+
+    // Barriers inside the two passes are lds_barrier(): they order the LDS steps and leave the global
+    // loads (prefetched time stamps / bin entries) and the slab stores in flight.
+    // ---- pass 1: partition into coarse phase bins -----------------------------------------------------
+    {
+        constexpr int kChunk = UNIFORM_W ? kSort3Chunk / 2 : kSort3Chunk / 4;   // 16 / 24 bytes per staged point
+        constexpr int kPer = kChunk / 1024;        // points per thread and round
+        unsigned long long* st_ent = reinterpret_cast<unsigned long long*>(area);   // [chunk] key << 32 | index
+        double* st_y = reinterpret_cast<double*>(st_ent + kChunk);
+        double* st_w = st_y + kChunk;
+        if (tid < kSort3MaxBins) { l_cnt[tid] = 0u; g_cnt[tid] = 0u; }
+        if (tid == 0) flags[0] = 0u;
+        double tv[kPer], yv[kPer], wv[kPer];
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {   // all in flight
+            const bool ok = tid + e * nt < n;
+            tv[e] = ok ? t[tid + e * nt] : 0.0;
+            yv[e] = ok ? y[tid + e * nt] : 0.0;
+            if constexpr (!UNIFORM_W) wv[e] = ok ? w[tid + e * nt] : 0.0;
+        }
+        lds_barrier();
+        for (int c0 = 0; c0 < n; c0 += kChunk) {
+            const int cn = n - c0 < kChunk ? n - c0 : kChunk;
+            unsigned int key[kPer], rank[kPer];
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) {
+                key[e] = phase_key(fold_phase(tv[e], period, 0.0));
+                const int bin = (int)(((unsigned long long)key[e] * (unsigned long long)B) >> 32);
+                rank[e] = tid + e * nt < cn ? atomicAdd(&l_cnt[bin], 1u) : 0u;
+            }
+            lds_barrier();
+            if (tid < kWave) {   // exclusive scan over the bins (B <= 64: one lane each) and the capacity test
+                const unsigned int c = tid < B ? l_cnt[tid] : 0u;
+                unsigned int incl = c;
+                incl += (unsigned int)dpp_i32<kDppRowShr1, 0xF>((int)incl);
+                incl += (unsigned int)dpp_i32<kDppRowShr2, 0xF>((int)incl);
+                incl += (unsigned int)dpp_i32<kDppRowShr4, 0xF>((int)incl);
+                incl += (unsigned int)dpp_i32<kDppRowShr8, 0xF>((int)incl);
+                incl += (unsigned int)dpp_i32<kDppBcast15, 0xA>((int)incl);
+                incl += (unsigned int)dpp_i32<kDppBcast31, 0xC>((int)incl);
+                if (tid < B) {
+                    l_start[tid] = incl - c;
+                    if (g_cnt[tid] + c > (unsigned int)kSort3BinCap) flags[0] = 1u;
+                }
+            }
+            lds_barrier();
+            if (flags[0]) { __syncthreads(); return false; }
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) {
+                if (tid + e * nt < cn) {
+                    const int bin = (int)(((unsigned long long)key[e] * (unsigned long long)B) >> 32);
+                    const unsigned int slot = l_start[bin] + rank[e];
+                    st_ent[slot] = ((unsigned long long)key[e] << 32) | (unsigned int)(c0 + tid + e * nt);
+                    st_y[slot] = yv[e];
+                    if constexpr (!UNIFORM_W) st_w[slot] = wv[e];
+                }
+            }
+            // the next round's points are requested now (nothing else of this wave is pending), consumed
+            // behind this round's copy-out
+            {
+                const int c1 = c0 + kChunk;
+#pragma unroll
+                for (int e = 0; e < kPer; ++e) {
+                    const bool ok = c1 + tid + e * nt < n;
+                    tv[e] = ok ? t[c1 + tid + e * nt] : 0.0;
+                    yv[e] = ok ? y[c1 + tid + e * nt] : 0.0;
+                    if constexpr (!UNIFORM_W) wv[e] = ok ? w[c1 + tid + e * nt] : 0.0;
+                }
+            }
+            lds_barrier();
+            // every bin's points of this round leave as one contiguous segment
+            for (int sidx = tid; sidx < cn; sidx += nt) {
+                const unsigned long long ent = st_ent[sidx];
+                const int bin = (int)(((ent >> 32) * (unsigned long long)B) >> 32);
+                const long long dst = (long long)bin * kSort3BinCap + g_cnt[bin] + ((unsigned int)sidx - l_start[bin]);
+                stream_store(&g_ent[dst], ent);
+                stream_store(&g_y[dst], st_y[sidx]);
+                if constexpr (!UNIFORM_W) stream_store(&g_w[dst], st_w[sidx]);
+            }
+            lds_barrier();
+            if (tid < B) { g_cnt[tid] += l_cnt[tid]; l_cnt[tid] = 0u; }
+            lds_barrier();
+        }
+    }
+    __syncthreads();   // the partitioned points are in memory: other threads read them below
+    pc.mark(2);
+
+    // ---- pass 2: bin by bin -- LDS sort on the key, prefix sum of the sorted flux ---------------------------
+    double* buf = reinterpret_cast<double*>(area);                                   // C[0..m], f = buf + 1
+    unsigned long long* ent_s = reinterpret_cast<unsigned long long*>(buf + kSort3BinCap + 2);   // [cap] bucket order
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(ent_s + kSort3BinCap);       // [fine]
+    double carry = 0.0;
+    int off = 0;
+    unsigned long long ent_next[kE];
+    double y_next[kE], w_next[kE];
+    {
+        const int m0 = (int)g_cnt[0];
+#pragma unroll
+        for (int e = 0; e < kE; ++e) {
+            const bool ok = tid + e * nt < m0;
+            ent_next[e] = ok ? stream_load(g_ent + tid + e * nt) : ~0ull;
+            y_next[e] = ok ? stream_load(g_y + tid + e * nt) : 0.0;
+            if constexpr (!UNIFORM_W) w_next[e] = ok ? stream_load(g_w + tid + e * nt) : 0.0;
+        }
+    }
+    for (int b = 0; b < B; ++b) {
+        const int m = (int)g_cnt[b];
+        // smallest key of the bin and of the next one: (key * B) >> 32 == b  <=>  lo_key <= key < hi_key
+        const unsigned long long lo_key = (((unsigned long long)b << 32) + (unsigned long long)B - 1ull) / (unsigned long long)B;
+        const unsigned long long hi_key = ((((unsigned long long)b + 1ull) << 32) + (unsigned long long)B - 1ull) / (unsigned long long)B;
+        const double scale = (double)kSort3Fine / (double)(hi_key - lo_key) * (1.0 - 1e-9);
+        unsigned long long ent[kE];
+        double yv[kE], wv[kE];
+        int fb[kE];
+#pragma unroll
+        for (int e = 0; e < kE; ++e) {
+            ent[e] = ent_next[e]; yv[e] = y_next[e];
+            if constexpr (!UNIFORM_W) wv[e] = w_next[e];
+        }
+        for (int k = tid; k < kSort3Fine; k += nt) cnt[k] = 0u;
+        lds_barrier();
+        pc.mark(0);
+        unsigned int r[kE];
+#pragma unroll
+        for (int e = 0; e < kE; ++e) {
+            const double rel = (double)((ent[e] >> 32) - lo_key);
+            int fbe = (int)(rel * scale);
+            fb[e] = fbe < kSort3Fine - 1 ? fbe : kSort3Fine - 1;
+            r[e] = tid + e * nt < m ? atomicAdd(&cnt[fb[e]], 1u) : 0u;
+        }
+        lds_barrier();
+        block_exclusive_scan8(cnt, kSort3Fine, wsum);
+        pc.mark(1);
+#pragma unroll
+        for (int e = 0; e < kE; ++e) if (tid + e * nt < m) ent_s[cnt[fb[e]] + r[e]] = ent[e];
+        lds_barrier();
+        int dest[kE];
+#pragma unroll
+        for (int e = 0; e < kE; ++e) {
+            dest[e] = -1;
+            if (tid + e * nt < m) {
+                const int lo = (int)cnt[fb[e]], hi = fb[e] + 1 < kSort3Fine ? (int)cnt[fb[e] + 1] : m;
+                const unsigned int key = (unsigned int)(ent[e] >> 32), id = (unsigned int)(ent[e] & 0xffffffffull);
+                int rank = 0;
+                for (int s2 = lo; s2 < hi; ++s2) {
+                    const unsigned long long o = ent_s[s2];
+                    const unsigned int okey = (unsigned int)(o >> 32), oid = (unsigned int)(o & 0xffffffffull);
+                    bool less = okey < key;
+                    if (okey == key && oid != id) {   // same 32-bit key (about once per period): the exact phases decide
+                        const double pa = fold_phase(t[oid], period, 0.0), pm = fold_phase(t[id], period, 0.0);
+                        less = pa < pm || (pa == pm && oid < id);
+                    }
+                    rank += less ? 1 : 0;
+                }
+                dest[e] = lo + rank;
+            }
+        }
+        pc.mark(4);
+#pragma unroll
+        for (int e = 0; e < kE; ++e) if (dest[e] >= 0) buf[1 + dest[e]] = yv[e];
+        lds_barrier();
+        pc.mark(3);
+        // the sorted flux of the bin: out to the slab, then through the prefix sum where it lies
+        for (int k = tid; k < m; k += nt) stream_store(&f_out[off + k], buf[1 + k]);
+        if (b + 1 < B) {   // the next bin's points are requested here, where few registers are live, and
+                           // arrive while the prefix sum runs
+            const int m1 = (int)g_cnt[b + 1];
+            const long long base = (long long)(b + 1) * kSort3BinCap;
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const bool ok = tid + e * nt < m1;
+                ent_next[e] = ok ? stream_load(g_ent + base + tid + e * nt) : ~0ull;
+                y_next[e] = ok ? stream_load(g_y + base + tid + e * nt) : 0.0;
+                if constexpr (!UNIFORM_W) w_next[e] = ok ? stream_load(g_w + base + tid + e * nt) : 0.0;
+            }
+        }
+        carry = exact_cumsum<true>(buf + 1, buf, m, cs, dbg, carry);
+        vmem_wait_all();   // those loads (and the flux stores, a prefix sum old) BEFORE the stores below: see vmem_wait_all
+        for (int k = tid; k <= m; k += nt) stream_store(&c_out[off + k], buf[k]);
+        if constexpr (!UNIFORM_W) {
+            lds_barrier();
+#pragma unroll
+            for (int e = 0; e < kE; ++e) if (dest[e] >= 0) buf[1 + dest[e]] = wv[e];
+            lds_barrier();
+            for (int k = tid; k < m; k += nt) stream_store(&w_out[off + k], buf[1 + k]);
+        }
+        off += m;
+        lds_barrier();   // the LDS arrays are rewritten by the next bin
+        pc.mark(5);
+    }
+    __syncthreads();   // the folded flux is in memory: the patch below reads its head back
+    // ---- patch: the prefix sum runs on over the first W samples (core.py:126-132) -------------------------
+    for (int k0 = 0; k0 < W; k0 += kSort3Chunk) {
+        const int len = W - k0 < kSort3Chunk ? W - k0 : kSort3Chunk;
+        copy_in_flight4(buf + 1, f_out + k0, len);
+        lds_barrier();
+        carry = exact_cumsum<true>(buf + 1, buf, len, cs, dbg, carry);
+        for (int k = tid; k <= len; k += nt) stream_store(&c_out[n + k0 + k], buf[k]);
+        lds_barrier();
+    }
+    pc.mark(5);
+    return true;
+}
+
 template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false>
 __global__ void __launch_bounds__(1024, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs a) {
@@ -1676,14 +2046,20 @@ tls_search_kernel(const SearchArgs a) {
 
         // ---- phase 1: fold + stable sort by phase ----------------------------------
         bool sorted = false;
+        bool fused = false;   // fold, sort, gather AND prefix sum done by fold_sort_cumsum_tiled
         if constexpr (!RESIDENT) {
+            if (a.sort3 && a.n_curves == 1)
+                fused = fold_sort_cumsum_tiled<UNIFORM_W>(a.t, a.y, a.w, n, W, period, regA, regB, regW,
+                                                          a.sort3_scratch + (long long)blockIdx.x * sort3_scratch_doubles(n),
+                                                          smem + a.hdr_bytes, wsum,
+                                                          reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), pc, a.phase_cycles);
             // series in HBM: the two-level sort with sequential HBM accesses, unless a phase bin overflows
-            if (a.sort2)
+            if (!fused && a.sort2)
                 sorted = fold_and_sort_tiled(a.t, n, period, 0.0, ph_orig, reinterpret_cast<unsigned int*>(idx_tmp),
                                              reinterpret_cast<unsigned int*>(perm), smem + a.hdr_bytes, pc,
                                              a.n_curves == 1 ? a.y : nullptr, UNIFORM_W ? nullptr : a.w, regW);
         }
-        if (!sorted) fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc);
+        if (!sorted && !fused) fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc);
         // survey mode: the permutation depends on (t, period) only, so every light curve of the
         // batch reuses it; it must outlive the prefix sum that overwrites its LDS home
         const IdxT* perm_use = perm;
@@ -1698,7 +2074,7 @@ tls_search_kernel(const SearchArgs a) {
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  Three
         // elements per step: their global reads (L2 latency) are in flight together -- the compiler
         // cannot overlap them itself, the LDS store of one may alias the index read of the next
-        const bool gathered = !RESIDENT && sorted && a.n_curves == 1;   // the two-level sort did it on the way
+        const bool gathered = !RESIDENT && (fused || (sorted && a.n_curves == 1));   // the sort did it on the way
         for (int k = tid; k < (gathered ? 0 : n); k += 3 * nt) {
             const int k1 = k + nt, k2 = k + 2 * nt;
             const int i0 = (int)perm_use[k];
@@ -1718,11 +2094,13 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
         // ---- phase 2: patch (core.py:126-132) and sequential cumsum ----------------
-        for (int k = tid; k < W; k += nt) {
-            regA[n + k] = regA[k];
-            if constexpr (!UNIFORM_W) regW[n + k] = regW[k];
+        if (RESIDENT || !fused) {
+            for (int k = tid; k < W; k += nt) {
+                regA[n + k] = regA[k];
+                if constexpr (!UNIFORM_W) regW[n + k] = regW[k];
+            }
+            if (tid == 0) regA[M] = 0.0;
         }
-        if (tid == 0) regA[M] = 0.0;
         __syncthreads();
         pc.mark(4);
 
@@ -1741,7 +2119,7 @@ tls_search_kernel(const SearchArgs a) {
 #else
             exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
 #endif
-        } else {
+        } else if (!fused) {
             // the series is in the HBM slab: run the scan on LDS copies, kCumsumChunk elements a time
             double* f_l = reinterpret_cast<double*>(smem + a.hdr_bytes);
             double* c_l = f_l + kCumsumChunk;
@@ -1757,12 +2135,7 @@ tls_search_kernel(const SearchArgs a) {
 #endif
                 __syncthreads();
                 for (int k = tid; k <= len; k += nt) regB[c0 + k] = c_l[k];
-                // e = 1 - f (or e*w) goes back to the slab from the LDS copy: one pass less over HBM
-                for (int k = tid; k < len; k += nt) {
-                    double e = 1.0 - f_l[k];
-                    if constexpr (!UNIFORM_W) e *= regW[c0 + k];
-                    regA[c0 + k] = e;
-                }
+                // the slab keeps f: e = 1 - f (or e*w) is formed when a tile is staged (stage_samples)
                 carry = c_l[len];
                 __syncthreads();
             }
@@ -1812,14 +2185,9 @@ tls_search_kernel(const SearchArgs a) {
                 {
                     const int avail = M + 1 + region_pad - p_lo;            // entries the slab still holds
                     const int valid = avail < staged ? (avail > 0 ? avail : 0) : staged;
-                    copy_in_flight4(tile_e, regA + p_lo, valid);
+                    stage_samples<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M);
                     copy_in_flight4(tile_c, regB + p_lo, valid);
-                    if constexpr (!UNIFORM_W) copy_in_flight4(tile_w, regW + p_lo, valid);
-                    for (int k = valid + tid; k < staged; k += nt) {
-                        tile_e[k] = 0.0;
-                        if constexpr (!UNIFORM_W) tile_w[k] = 0.0;
-                        tile_c[k] = (double)(p_lo + k - M) * 1.0e300;
-                    }
+                    for (int k = valid + tid; k < staged; k += nt) tile_c[k] = (double)(p_lo + k - M) * 1.0e300;
                 }
                 e_base = tile_e - p_lo;
                 w_base = tile_w - p_lo;
@@ -1977,14 +2345,7 @@ tls_search_kernel(const SearchArgs a) {
             const int staged = a.tile_len + a.tile_halo;
             double* tile_w = tile_e + staged;
             {
-                const int avail = M + 1 + region_pad - p_lo;
-                const int valid = avail < staged ? (avail > 0 ? avail : 0) : staged;
-                copy_in_flight4(tile_e, regA + p_lo, valid);
-                for (int k = valid + tid; k < staged; k += nt) tile_e[k] = 0.0;
-                if constexpr (!UNIFORM_W) {
-                    copy_in_flight4(tile_w, regW + p_lo, valid);
-                    for (int k = valid + tid; k < staged; k += nt) tile_w[k] = 0.0;
-                }
+                stage_samples<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M);
             }
             e_base = tile_e - p_lo;
             w_base = tile_w - p_lo;
@@ -2018,7 +2379,10 @@ tls_search_kernel(const SearchArgs a) {
                         const int hi = (b + 1) * G < M ? (b + 1) * G : M;
                         double acc = 0.0;
 #pragma unroll 4
-                        for (int kk = b * G; kk < hi; ++kk) acc = fma(regA[kk], regA[kk], acc);
+                        for (int kk = b * G; kk < hi; ++kk) {
+                            const double ev = RESIDENT ? regA[kk] : 1.0 - regA[kk < n ? kk : kk - n];   // the slab keeps f
+                            acc = fma(ev, ev, acc);
+                        }
                         P2[b + 1] = acc;
                     }
                 } else {            // long blocks (series in the HBM slab): one wave each, coalesced
@@ -2027,7 +2391,10 @@ tls_search_kernel(const SearchArgs a) {
                         const int hi = (b + 1) * G < M ? (b + 1) * G : M;
                         double acc = 0.0;
 #pragma unroll 2
-                        for (int kk = b * G + lane; kk < hi; kk += kWave) acc = fma(regA[kk], regA[kk], acc);
+                        for (int kk = b * G + lane; kk < hi; kk += kWave) {
+                            const double ev = RESIDENT ? regA[kk] : 1.0 - regA[kk < n ? kk : kk - n];
+                            acc = fma(ev, ev, acc);
+                        }
 #pragma unroll
                         for (int delta = kWave / 2; delta > 0; delta >>= 1) acc += __shfl_down(acc, delta, kWave);
                         if (lane == 0) P2[b + 1] = acc;
