@@ -575,6 +575,23 @@ def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
     assert n_cases >= 12
 
 
+@pytest.mark.parametrize("name,stride,sort3", [("tess_27d", 5, "1"), ("tess_27d", 40, "0"), ("kepler_4yr", 700, "0"),
+                                               ("kepler_4yr", 700, "1")])
+def test_both_slab_sort_paths_vs_oracle(gpu, oracle_lib, monkeypatch, name, stride, sort3):
+    """The HBM-slab variant has two sort paths (two-level per-wave bins; partition + per-bin workgroup
+    sort fused with the prefix sum); the size picks the default, TLS_SORT3 forces either: both against
+    the oracle on both sizes, evaluated-cell counts included."""
+    monkeypatch.setenv("TLS_SORT3", sort3)
+    inp = _inputs(name)
+    sel = inp["periods"][::stride]
+    got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+    assert not gpu.plan_info()["resident"]
+    want = oracle_search(oracle_lib, inp, periods=sel)
+    assert_parity(got, want, len(inp["t"]))
+    assert got[3]["evaluated_cells"] == int(want[3][1])
+    assert got[3]["inner_steps"] == int(want[3][2])
+
+
 @pytest.mark.parametrize("name,stride", [("tess_27d", 60), ("kepler_4yr", 9000)])
 def test_large_series_with_per_point_weights(gpu, oracle_lib, name, stride):
     """Tiled (non-resident) variant with per-point dy: e*w and w staged per tile; for the

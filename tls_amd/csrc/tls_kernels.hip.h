@@ -159,6 +159,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
+// A pointer into LDS that reached a real (non-inlined) function as a generic pointer: handing it back
+// through its own address space lets the compiler use ds_* instructions again.  Without this every "LDS"
+// access of such a function is a FLAT instruction -- through the vector-memory pipe, counted on vmcnt AND
+// lgkmcnt, several times slower (found in the ISA of the first non-inlined version of the slab sort).
+template <typename T>
+__device__ __forceinline__ T* as_lds(T* p) {
+    return (T*)(__attribute__((address_space(3))) T*)p;
+}
+
 // Workgroup barrier that orders LDS traffic only: the LDS operations of every wave are complete, global
 // loads and stores STAY IN FLIGHT across it.  __syncthreads() also drains the vector-memory counter,
 // i.e. every barrier between two LDS steps would expose a full HBM round trip of whatever was
@@ -972,11 +981,13 @@ static_assert(kMaxSpecial <= kWave && kMaxWaves <= kWave, "the tables are held o
 // ALIASED: C[k+1] is stored over f[k] (f == C + 1); the elements are then restored before a fallback.
 // Returns C[kb].
 template <int PER, bool ALIASED>
-__device__ __noinline__ double exact_cumsum_block(const double* f, double* C, int k0, int kb, double s0,
-                                                     Cumsum2Scratch* cs, unsigned long long* dbg) {
+__device__ __forceinline__ double exact_cumsum_block_inline(const double* f, double* C, int k0, int kb, double s0,
+                                                            Cumsum2Scratch* cs, unsigned long long* dbg) {
     static_assert(PER <= 32, "the special key packs the element slot into 5 bits");
     PhaseClock cpc; cpc.start(dbg);
-    const int tid = threadIdx.x, nt = blockDim.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // opaque: nothing derived from it is hoisted out of a caller's loop (and spilled)
+    const int nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     int per = (kb - k0 + nt - 1) / nt;
@@ -1140,9 +1151,23 @@ __device__ __noinline__ double exact_cumsum_block(const double* f, double* C, in
     return s_end;
 }
 
+// The same as a real function: one copy per (PER, ALIASED) shared by all callers and kernels (the block is
+// ~4000 instructions; inlined into every phase that needs it, it evicted the rest from the instruction cache)
+template <int PER, bool ALIASED, bool IN_LDS>
+__device__ __noinline__ double exact_cumsum_block(const double* f, double* C, int k0, int kb, double s0,
+                                                  Cumsum2Scratch* cs, unsigned long long* dbg) {
+    if constexpr (IN_LDS)
+        return exact_cumsum_block_inline<PER, ALIASED>(as_lds(f), as_lds(C), k0, kb, s0, as_lds(cs), dbg);
+    else
+        return exact_cumsum_block_inline<PER, ALIASED>(f, C, k0, kb, s0, as_lds(cs), dbg);
+}
+
 // C[0] = s_start, C[k+1] = fl(C[k] + f[k]) for k < count: blocks of blockDim.x * 16 elements (one for an
 // LDS-resident light curve).  All threads of the workgroup call this; C is complete at return.
-template <bool ALIASED>
+// IN_LDS: f and C live in LDS (every kernel use; the developer test entry passes global memory).
+// INLINE: the block is inlined at the call site (pointers keep their address space and uniformity: the
+// LDS-resident kernel, which runs exactly one block per period); otherwise a call to the shared copy.
+template <bool ALIASED, bool IN_LDS = true, bool INLINE = false>
 __device__ __forceinline__ double exact_cumsum(const double* f, double* C, int count, Cumsum2Scratch* cs,
                                                unsigned long long* dbg = nullptr, double s_start = 0.0) {
     const int nt = blockDim.x;
@@ -1151,9 +1176,16 @@ __device__ __forceinline__ double exact_cumsum(const double* f, double* C, int c
     for (int k0 = 0; k0 < count; ) {
         const int left = count - k0;
         int kb;
-        if (left <= 8 * nt) { kb = count; s0 = exact_cumsum_block<8, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
-        else if (left <= 12 * nt) { kb = count; s0 = exact_cumsum_block<12, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
-        else { kb = left <= 16 * nt ? count : k0 + 16 * nt; s0 = exact_cumsum_block<16, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
+        if constexpr (INLINE) {
+            if (left <= 8 * nt) { kb = count; s0 = exact_cumsum_block_inline<8, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
+            else if (left <= 12 * nt) { kb = count; s0 = exact_cumsum_block_inline<12, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
+            else { kb = left <= 16 * nt ? count : k0 + 16 * nt; s0 = exact_cumsum_block_inline<16, ALIASED>(f, C, k0, kb, s0, cs, dbg); }
+        } else {
+            if (left <= 5 * nt) { kb = count; s0 = exact_cumsum_block<5, ALIASED, IN_LDS>(f, C, k0, kb, s0, cs, dbg); }
+            else if (left <= 8 * nt) { kb = count; s0 = exact_cumsum_block<8, ALIASED, IN_LDS>(f, C, k0, kb, s0, cs, dbg); }
+            else if (left <= 12 * nt) { kb = count; s0 = exact_cumsum_block<12, ALIASED, IN_LDS>(f, C, k0, kb, s0, cs, dbg); }
+            else { kb = left <= 16 * nt ? count : k0 + 16 * nt; s0 = exact_cumsum_block<16, ALIASED, IN_LDS>(f, C, k0, kb, s0, cs, dbg); }
+        }
         k0 = kb;
         if (k0 < count) lds_barrier();               // the scratch is rewritten by the next block
     }
@@ -1684,9 +1716,9 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 // The slab afterwards holds f[0..n) (and w) and C[0..M]; e = 1 - f is formed when a tile is staged.
 // Returns false (all threads alike) when a coarse bin overflows (phases piled up): the caller falls
 // back to the general path.
-constexpr int kSort3BinCap = 8192;      // points one coarse phase bin may hold
-constexpr int kSort3BinMean = 6144;     // target points per coarse bin
-constexpr int kSort3Fine = 4096;        // fine buckets of the per-bin LDS sort
+constexpr int kSort3BinCap = 4096;      // points one coarse phase bin may hold
+constexpr int kSort3BinMean = 3072;     // target points per coarse bin
+constexpr int kSort3Fine = 2048;        // fine buckets of the per-bin LDS sort
 constexpr int kSort3Chunk = 16384;      // points partitioned per pass-1 round
 constexpr int kSort3MaxBins = 64;
 __host__ __device__ constexpr int sort3_bins(int n) {
@@ -1697,7 +1729,8 @@ __host__ __device__ constexpr long long sort3_lds_bytes() {
     // (flux / prefix-sum buffer, sorted entries, fine-bucket counters); the patch round reuses the front
     const long long counters = 4LL * 4 * kSort3MaxBins;
     const long long pass1 = 8LL * kSort3Chunk;
-    const long long pass2 = 8LL * (kSort3BinCap + 1) + 8 + 8LL * kSort3BinCap + 4LL * kSort3Fine;
+    const long long pass2 = 16LL * kSort3BinCap /* landing zone of the next bin's records */ + 8LL * (kSort3BinCap + 2) +
+                            8LL * kSort3BinCap + 4LL * (kSort3Fine + 4);
     const long long patch = 8LL * (kSort3Chunk + 1) + 8;
     long long m = pass1 > pass2 ? pass1 : pass2;
     m = m > patch ? m : patch;
@@ -1713,8 +1746,8 @@ __device__ __forceinline__ unsigned int phase_key(double ph) {
 }
 
 // exclusive prefix sum of cnt[0..nb) (LDS) in place, nb <= 8 * blockDim.x; two LDS barriers
-__device__ __forceinline__ void block_exclusive_scan8(unsigned int* cnt, int nb, unsigned int* wsum) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+__device__ __forceinline__ void block_exclusive_scan8(unsigned int* cnt, int nb, unsigned int* wsum, int tid) {
+    const int nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int chunk = (nb + nt - 1) / nt;   // <= 8
@@ -1739,11 +1772,34 @@ __device__ __forceinline__ void block_exclusive_scan8(unsigned int* cnt, int nb,
     lds_barrier();
 }
 
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));   // one partitioned point: {key << 32 | index, flux bits}
+
+// dst[0..count) (slab, HBM) = src[0..count) (LDS): 16-byte stores wherever the destination allows
+__device__ __forceinline__ void copy_out_stream(double* dst, const double* src, int count, int tid) {
+    const int nt = blockDim.x;
+    const int head = (int)((reinterpret_cast<unsigned long long>(dst) >> 3) & 1ull);   // 1: dst starts on an odd element
+    if (tid == 0 && head && count > 0) stream_store(dst, src[0]);
+    const int pairs = (count - head) / 2;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2* d2 = reinterpret_cast<f64x2*>(dst + head);
+    const double* s1 = src + head;
+    for (int q = tid; q < pairs; q += nt) {
+        f64x2 v; v.x = s1[2 * q]; v.y = s1[2 * q + 1];
+        stream_store(d2 + q, v);
+    }
+    if (tid == 0 && head + 2 * pairs < count) stream_store(dst + count - 1, src[count - 1]);
+}
+
 template <bool UNIFORM_W>
-__device__ __noinline__ bool fold_sort_cumsum_tiled(const double* t, const double* y, const double* w, int n, int W,
-                                                       double period, double* f_out, double* c_out, double* w_out,
-                                                       unsigned long long* g_ent, unsigned char* lds, unsigned int* wsum,
-                                                       Cumsum2Scratch* cs, PhaseClock& pc, unsigned long long* dbg) {
+__device__ __forceinline__ bool fold_sort_cumsum_tiled(const double* t, const double* y, const double* w, int n, int W,
+                                                    double period, double* f_out, double* c_out, double* w_out,
+                                                    unsigned long long* g_scratch, unsigned char* lds_generic,
+                                                    unsigned int* wsum_generic, Cumsum2Scratch* cs_generic,
+                                                    unsigned long long* dbg) {
+    unsigned char* lds = as_lds(lds_generic);
+    unsigned int* wsum = as_lds(wsum_generic);
+    Cumsum2Scratch* cs = as_lds(cs_generic);
+    PhaseClock pc; pc.start(dbg);   // its own clock: the caller restarts its clock behind the call
     const int tid = threadIdx.x, nt = blockDim.x;
     const int B = sort3_bins(n);
     unsigned int* l_cnt = reinterpret_cast<unsigned int*>(lds);      // [B] points of the bin in this round
@@ -1751,23 +1807,23 @@ __device__ __noinline__ bool fold_sort_cumsum_tiled(const double* t, const doubl
     unsigned int* g_cnt = l_start + kSort3MaxBins;                   // [B] points of the bin so far
     unsigned int* flags = g_cnt + kSort3MaxBins;                     // [0]: overflow
     unsigned char* area = lds + 4 * 4 * kSort3MaxBins;
-    constexpr int kE = kSort3BinCap / 1024;   // entries per thread in pass 2 (1024-thread workgroups)
+    constexpr int kE = kSort3BinCap / 1024;   // points per thread in pass 2 (1024-thread workgroups)
     if (kE * nt < kSort3BinCap) return false; // needs 1024 threads (uniform)
-    // pass-1 output, bin-major: entries (key << 32 | index), the flux and the weight of every point travel
-    // together -- a gather y[index] in pass 2 would be 70 000 random 64-byte requests per period and CU
+    // pass-1 output, bin-major: a 16-byte record per point -- the sort key, the index and the FLUX travel
+    // together (a gather y[index] in pass 2 would be 70 000 random 64-byte requests per period and CU);
+    // weights, when there are any, in a parallel array
     const long long slots = (long long)B * kSort3BinCap;
-    double* g_y = reinterpret_cast<double*>(g_ent + slots);
-    double* g_w = g_y + slots;
+    u64x2* g_rec = reinterpret_cast<u64x2*>(g_scratch);
+    double* g_w = reinterpret_cast<double*>(g_scratch + 2 * slots);
 
     // Barriers inside the two passes are lds_barrier(): they order the LDS steps and leave the global
-    // loads (prefetched time stamps / bin entries) and the slab stores in flight.
+    // loads and the slab stores in flight.
     // ---- pass 1: partition into coarse phase bins -----------------------------------------------------
     {
         constexpr int kChunk = UNIFORM_W ? kSort3Chunk / 2 : kSort3Chunk / 4;   // 16 / 24 bytes per staged point
         constexpr int kPer = kChunk / 1024;        // points per thread and round
-        unsigned long long* st_ent = reinterpret_cast<unsigned long long*>(area);   // [chunk] key << 32 | index
-        double* st_y = reinterpret_cast<double*>(st_ent + kChunk);
-        double* st_w = st_y + kChunk;
+        u64x2* st_rec = reinterpret_cast<u64x2*>(area);                     // [chunk]
+        double* st_w = reinterpret_cast<double*>(st_rec + kChunk);
         if (tid < kSort3MaxBins) { l_cnt[tid] = 0u; g_cnt[tid] = 0u; }
         if (tid == 0) flags[0] = 0u;
         double tv[kPer], yv[kPer], wv[kPer];
@@ -1805,14 +1861,20 @@ __device__ __noinline__ bool fold_sort_cumsum_tiled(const double* t, const doubl
             }
             lds_barrier();
             if (flags[0]) { __syncthreads(); return false; }
+            unsigned int base[kPer];
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) {   // the reads of all points in flight together
+                const int bin = (int)(((unsigned long long)key[e] * (unsigned long long)B) >> 32);
+                base[e] = l_start[bin];
+            }
 #pragma unroll
             for (int e = 0; e < kPer; ++e) {
                 if (tid + e * nt < cn) {
-                    const int bin = (int)(((unsigned long long)key[e] * (unsigned long long)B) >> 32);
-                    const unsigned int slot = l_start[bin] + rank[e];
-                    st_ent[slot] = ((unsigned long long)key[e] << 32) | (unsigned int)(c0 + tid + e * nt);
-                    st_y[slot] = yv[e];
-                    if constexpr (!UNIFORM_W) st_w[slot] = wv[e];
+                    u64x2 rec;
+                    rec.x = ((unsigned long long)key[e] << 32) | (unsigned int)(c0 + tid + e * nt);
+                    rec.y = (unsigned long long)__double_as_longlong(yv[e]);
+                    st_rec[base[e] + rank[e]] = rec;
+                    if constexpr (!UNIFORM_W) st_w[base[e] + rank[e]] = wv[e];
                 }
             }
             // the next round's points are requested now (nothing else of this wave is pending), consumed
@@ -1828,14 +1890,17 @@ __device__ __noinline__ bool fold_sort_cumsum_tiled(const double* t, const doubl
                 }
             }
             lds_barrier();
-            // every bin's points of this round leave as one contiguous segment
-            for (int sidx = tid; sidx < cn; sidx += nt) {
-                const unsigned long long ent = st_ent[sidx];
-                const int bin = (int)(((ent >> 32) * (unsigned long long)B) >> 32);
-                const long long dst = (long long)bin * kSort3BinCap + g_cnt[bin] + ((unsigned int)sidx - l_start[bin]);
-                stream_store(&g_ent[dst], ent);
-                stream_store(&g_y[dst], st_y[sidx]);
-                if constexpr (!UNIFORM_W) stream_store(&g_w[dst], st_w[sidx]);
+            // every bin's points of this round leave as one contiguous segment, one 16-byte store per point
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) {
+                const int sidx = tid + e * nt;
+                if (sidx < cn) {
+                    const u64x2 rec = st_rec[sidx];
+                    const int bin = (int)(((rec.x >> 32) * (unsigned long long)B) >> 32);
+                    const long long dst = (long long)bin * kSort3BinCap + g_cnt[bin] + ((unsigned int)sidx - l_start[bin]);
+                    stream_store(&g_rec[dst], rec);
+                    if constexpr (!UNIFORM_W) stream_store(&g_w[dst], st_w[sidx]);
+                }
             }
             lds_barrier();
             if (tid < B) { g_cnt[tid] += l_cnt[tid]; l_cnt[tid] = 0u; }
@@ -1846,116 +1911,165 @@ __device__ __noinline__ bool fold_sort_cumsum_tiled(const double* t, const doubl
     pc.mark(2);
 
     // ---- pass 2: bin by bin -- LDS sort on the key, prefix sum of the sorted flux ---------------------------
-    double* buf = reinterpret_cast<double*>(area);                                   // C[0..m], f = buf + 1
+    // Software pipeline over the bins: the records of bin b+1 stream into an LDS landing zone
+    // (global_load_lds: no registers, 1 KiB per wave-instruction) while bin b is sorted; every lane later
+    // reads exactly the slots its own wave's loads filled, so no barrier guards the zone.  The prefix sum
+    // of bin b leaves for the slab at the top of round b+1, when its stores no longer sit between a load
+    // and its use.
+    u64x2* landing = reinterpret_cast<u64x2*>(area);                                 // [cap]
+    double* buf = reinterpret_cast<double*>(landing + kSort3BinCap);                 // C[0..m], f = buf + 1
     unsigned long long* ent_s = reinterpret_cast<unsigned long long*>(buf + kSort3BinCap + 2);   // [cap] bucket order
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(ent_s + kSort3BinCap);       // [fine]
-    double carry = 0.0;
-    int off = 0;
-    unsigned long long ent_next[kE];
-    double y_next[kE], w_next[kE];
-    {
-        const int m0 = (int)g_cnt[0];
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(ent_s + kSort3BinCap);       // [fine + 1]
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    // (inline assembly, not __builtin_amdgcn_global_load_lds: the compiler cannot tell the landing zone from
+    // the other LDS arrays and would wait for the transfer -- vmcnt(0) -- before EVERY later LDS access, i.e.
+    // right after it is issued.  The zone is read only behind the explicit vmem_wait_all() of the next round.)
+    const unsigned int landing_addr = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) u64x2*)landing;
+    auto request_bin = [&](int bin, int tid) {
+        const int mb = (int)g_cnt[bin];
+        const u64x2* src = g_rec + (long long)bin * kSort3BinCap;
 #pragma unroll
         for (int e = 0; e < kE; ++e) {
-            const bool ok = tid + e * nt < m0;
-            ent_next[e] = ok ? stream_load(g_ent + tid + e * nt) : ~0ull;
-            y_next[e] = ok ? stream_load(g_y + tid + e * nt) : 0.0;
-            if constexpr (!UNIFORM_W) w_next[e] = ok ? stream_load(g_w + tid + e * nt) : 0.0;
+            const int i = tid + e * nt;
+            const unsigned int dst = (unsigned int)__builtin_amdgcn_readfirstlane((int)(landing_addr + 16u * (unsigned int)(wave * kWave + e * nt)));
+            unsigned int m0_saved;
+            if (i < mb)   // M0 carries the LDS base of the transfer; it is put back (the compiler may own it)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+#if TLS_NT
+                             " nt"
+#endif
+                             "\n\ts_mov_b32 m0, %0"
+                             : "=&s"(m0_saved) : "v"(src + i), "s"(dst) : "memory");
         }
-    }
+    };
+    double carry = 0.0;
+    int off = 0, prev_off = 0, prev_m = -1;
+    request_bin(0, tid);
+    const int tid_outer = tid;
     for (int b = 0; b < B; ++b) {
+        // Every address of this round is recomputed from an opaque copy of the thread index: hoisted out of
+        // the loop they would all be live across it, and at 128 registers per thread the compiler spills
+        // them -- each reload then waits (vmcnt) for the transfer that was issued just before it.
+        int tid = tid_outer;
+        asm volatile("" : "+v"(tid));
         const int m = (int)g_cnt[b];
         // smallest key of the bin and of the next one: (key * B) >> 32 == b  <=>  lo_key <= key < hi_key
         const unsigned long long lo_key = (((unsigned long long)b << 32) + (unsigned long long)B - 1ull) / (unsigned long long)B;
         const unsigned long long hi_key = ((((unsigned long long)b + 1ull) << 32) + (unsigned long long)B - 1ull) / (unsigned long long)B;
         const double scale = (double)kSort3Fine / (double)(hi_key - lo_key) * (1.0 - 1e-9);
-        unsigned long long ent[kE];
-        double yv[kE], wv[kE];
-        int fb[kE];
+        u64x2 rec[kE];
+        double wv[kE];
+        vmem_wait_all();                                   // this wave's records of bin b have landed
+        pc.mark(22);
 #pragma unroll
         for (int e = 0; e < kE; ++e) {
-            ent[e] = ent_next[e]; yv[e] = y_next[e];
-            if constexpr (!UNIFORM_W) wv[e] = w_next[e];
+            u64x2 none; none.x = ~0ull; none.y = 0ull;
+            rec[e] = tid + e * nt < m ? landing[tid + e * nt] : none;
         }
-        for (int k = tid; k < kSort3Fine; k += nt) cnt[k] = 0u;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): the zone is read before it is refilled
+        if (b + 1 < B) request_bin(b + 1, tid);
+        pc.mark(23);
+        if constexpr (!UNIFORM_W) {
+            const long long base = (long long)b * kSort3BinCap;
+#pragma unroll
+            for (int e = 0; e < kE; ++e) wv[e] = tid + e * nt < m ? stream_load(g_w + base + tid + e * nt) : 0.0;
+        }
+        if (prev_m >= 0) copy_out_stream(c_out + prev_off, buf, prev_m + 1, tid);   // prefix sum of the previous bin
+        pc.mark(24);
+        for (int k = tid; k <= kSort3Fine; k += nt) cnt[k] = 0u;
         lds_barrier();
         pc.mark(0);
+        int fb[kE];
         unsigned int r[kE];
 #pragma unroll
         for (int e = 0; e < kE; ++e) {
-            const double rel = (double)((ent[e] >> 32) - lo_key);
-            int fbe = (int)(rel * scale);
+            const double rel = (double)((rec[e].x >> 32) - lo_key);
+            const int fbe = (int)(rel * scale);
             fb[e] = fbe < kSort3Fine - 1 ? fbe : kSort3Fine - 1;
             r[e] = tid + e * nt < m ? atomicAdd(&cnt[fb[e]], 1u) : 0u;
         }
         lds_barrier();
-        block_exclusive_scan8(cnt, kSort3Fine, wsum);
+        block_exclusive_scan8(cnt, kSort3Fine, wsum, tid);
+        if (tid == 0) cnt[kSort3Fine] = (unsigned int)m;   // the end of the last bucket
         pc.mark(1);
+        int lo[kE];
 #pragma unroll
-        for (int e = 0; e < kE; ++e) if (tid + e * nt < m) ent_s[cnt[fb[e]] + r[e]] = ent[e];
+        for (int e = 0; e < kE; ++e) lo[e] = (int)cnt[fb[e]];           // reads of all points in flight together
+#pragma unroll
+        for (int e = 0; e < kE; ++e) if (tid + e * nt < m) ent_s[lo[e] + (int)r[e]] = rec[e].x;
         lds_barrier();
-        int dest[kE];
+        int len[kE], rank[kE], longest = 0;
 #pragma unroll
         for (int e = 0; e < kE; ++e) {
-            dest[e] = -1;
-            if (tid + e * nt < m) {
-                const int lo = (int)cnt[fb[e]], hi = fb[e] + 1 < kSort3Fine ? (int)cnt[fb[e] + 1] : m;
-                const unsigned int key = (unsigned int)(ent[e] >> 32), id = (unsigned int)(ent[e] & 0xffffffffull);
-                int rank = 0;
-                for (int s2 = lo; s2 < hi; ++s2) {
-                    const unsigned long long o = ent_s[s2];
-                    const unsigned int okey = (unsigned int)(o >> 32), oid = (unsigned int)(o & 0xffffffffull);
+            len[e] = tid + e * nt < m ? (int)cnt[fb[e] + 1] - lo[e] : 0;
+            rank[e] = 0;
+            longest = len[e] > longest ? len[e] : longest;
+        }
+        // rank inside the fine bucket (1.5 points on average): the s-th member of every point's bucket is
+        // read in one batch, so the LDS latency is paid per step, not per point and step
+#pragma unroll
+        for (int delta = kWave / 2; delta > 0; delta >>= 1) {
+            const int o = __shfl_xor(longest, delta, kWave);
+            longest = o > longest ? o : longest;
+        }
+        for (int s2 = 0; s2 < longest; ++s2) {
+            unsigned long long o[kE];
+#pragma unroll
+            for (int e = 0; e < kE; ++e) o[e] = s2 < len[e] ? ent_s[lo[e] + s2] : ~0ull;
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                if (s2 < len[e]) {
+                    const unsigned int okey = (unsigned int)(o[e] >> 32), oid = (unsigned int)(o[e] & 0xffffffffull);
+                    const unsigned int key = (unsigned int)(rec[e].x >> 32), id = (unsigned int)(rec[e].x & 0xffffffffull);
                     bool less = okey < key;
                     if (okey == key && oid != id) {   // same 32-bit key (about once per period): the exact phases decide
                         const double pa = fold_phase(t[oid], period, 0.0), pm = fold_phase(t[id], period, 0.0);
                         less = pa < pm || (pa == pm && oid < id);
                     }
-                    rank += less ? 1 : 0;
+                    rank[e] += less ? 1 : 0;
                 }
-                dest[e] = lo + rank;
             }
         }
         pc.mark(4);
 #pragma unroll
-        for (int e = 0; e < kE; ++e) if (dest[e] >= 0) buf[1 + dest[e]] = yv[e];
+        for (int e = 0; e < kE; ++e)
+            if (tid + e * nt < m) buf[1 + lo[e] + rank[e]] = __longlong_as_double((long long)rec[e].y);
         lds_barrier();
         pc.mark(3);
         // the sorted flux of the bin: out to the slab, then through the prefix sum where it lies
-        for (int k = tid; k < m; k += nt) stream_store(&f_out[off + k], buf[1 + k]);
-        if (b + 1 < B) {   // the next bin's points are requested here, where few registers are live, and
-                           // arrive while the prefix sum runs
-            const int m1 = (int)g_cnt[b + 1];
-            const long long base = (long long)(b + 1) * kSort3BinCap;
-#pragma unroll
-            for (int e = 0; e < kE; ++e) {
-                const bool ok = tid + e * nt < m1;
-                ent_next[e] = ok ? stream_load(g_ent + base + tid + e * nt) : ~0ull;
-                y_next[e] = ok ? stream_load(g_y + base + tid + e * nt) : 0.0;
-                if constexpr (!UNIFORM_W) w_next[e] = ok ? stream_load(g_w + base + tid + e * nt) : 0.0;
-            }
-        }
-        carry = exact_cumsum<true>(buf + 1, buf, m, cs, dbg, carry);
-        vmem_wait_all();   // those loads (and the flux stores, a prefix sum old) BEFORE the stores below: see vmem_wait_all
-        for (int k = tid; k <= m; k += nt) stream_store(&c_out[off + k], buf[k]);
+        copy_out_stream(f_out + off, buf + 1, m, tid);
+        pc.mark(12);
+        // (inlined: a call would drain the vector-memory counter -- the flux stores just issued, the next
+        // bin's records in flight -- at its entry)
+        static_assert(kSort3BinCap <= 5 * 1024, "one block of 5 elements per thread covers a bin");
+        if (m > 0) carry = exact_cumsum_block_inline<5, true>(buf + 1, buf, 0, m, carry, cs, dbg);
+        else if (tid == 0) buf[0] = carry;
         if constexpr (!UNIFORM_W) {
+            // (rare path, not pipelined: the prefix sum leaves now, the weights take its place)
+            copy_out_stream(c_out + off, buf, m + 1, tid);
             lds_barrier();
 #pragma unroll
-            for (int e = 0; e < kE; ++e) if (dest[e] >= 0) buf[1 + dest[e]] = wv[e];
+            for (int e = 0; e < kE; ++e) if (tid + e * nt < m) buf[1 + lo[e] + rank[e]] = wv[e];
             lds_barrier();
-            for (int k = tid; k < m; k += nt) stream_store(&w_out[off + k], buf[1 + k]);
+            copy_out_stream(w_out + off, buf + 1, m, tid);
+            lds_barrier();
+            prev_m = -1;
+        } else {
+            prev_off = off; prev_m = m;
         }
         off += m;
-        lds_barrier();   // the LDS arrays are rewritten by the next bin
         pc.mark(5);
     }
+    if (prev_m >= 0) copy_out_stream(c_out + prev_off, buf, prev_m + 1, tid);
     __syncthreads();   // the folded flux is in memory: the patch below reads its head back
+    buf = reinterpret_cast<double*>(area);   // the patch round is longer than a bin: it takes the whole area
     // ---- patch: the prefix sum runs on over the first W samples (core.py:126-132) -------------------------
     for (int k0 = 0; k0 < W; k0 += kSort3Chunk) {
         const int len = W - k0 < kSort3Chunk ? W - k0 : kSort3Chunk;
         copy_in_flight4(buf + 1, f_out + k0, len);
         lds_barrier();
         carry = exact_cumsum<true>(buf + 1, buf, len, cs, dbg, carry);
-        for (int k = tid; k <= len; k += nt) stream_store(&c_out[n + k0 + k], buf[k]);
+        copy_out_stream(c_out + n + k0, buf, len + 1, tid);
         lds_barrier();
     }
     pc.mark(5);
@@ -2052,7 +2166,8 @@ tls_search_kernel(const SearchArgs a) {
                 fused = fold_sort_cumsum_tiled<UNIFORM_W>(a.t, a.y, a.w, n, W, period, regA, regB, regW,
                                                           a.sort3_scratch + (long long)blockIdx.x * sort3_scratch_doubles(n),
                                                           smem + a.hdr_bytes, wsum,
-                                                          reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), pc, a.phase_cycles);
+                                                          reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
+            if (a.sort3 && a.n_curves == 1) pc.start(a.phase_cycles);   // the call kept its own clock
             // series in HBM: the two-level sort with sequential HBM accesses, unless a phase bin overflows
             if (!fused && a.sort2)
                 sorted = fold_and_sort_tiled(a.t, n, period, 0.0, ph_orig, reinterpret_cast<unsigned int*>(idx_tmp),
@@ -2115,7 +2230,7 @@ tls_search_kernel(const SearchArgs a) {
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup
         if constexpr (RESIDENT) {
 #if TLS_CUMSUM2
-            exact_cumsum<false>(regA, regB, M, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
+            exact_cumsum<false, true, true>(regA, regB, M, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
 #else
             exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
 #endif
@@ -2873,7 +2988,7 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a) {
 __global__ void __launch_bounds__(1024) tls_cumsum_kernel(const double* f, double* out, int count, int variant,
                                                           unsigned long long* dbg) {
     __shared__ __attribute__((aligned(16))) unsigned char scratch[kCumsumScratchBytes];
-    if (variant == 0) exact_cumsum<false>(f, out, count, reinterpret_cast<Cumsum2Scratch*>(scratch), dbg);
+    if (variant == 0) exact_cumsum<false, false>(f, out, count, reinterpret_cast<Cumsum2Scratch*>(scratch), dbg);
     else exact_sequential_cumsum(f, out, count, reinterpret_cast<CumsumScratch*>(scratch));
 }
 
