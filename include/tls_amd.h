@@ -119,6 +119,10 @@ int tls_debug_phase_cycles(tls_ctx *ctx, uint64_t *cycles, int n);
  * sum (numpy.cumsum order, helpers.py:72) on an arbitrary series of non-negative values;
  * out has count + 1 entries, out[0] = 0. */
 int tls_debug_cumsum(tls_ctx *ctx, const double *f, int64_t count, double *out, int threads);
+/* developer instrumentation: the debug build (make -C tls_amd/csrc debug) tests every hand-computed
+ * bound of the search kernel on the device and counts violations per check (names in
+ * tls_amd/_lib.py::check_counts); returns 1 from a checked build, 0 (all counts zero) otherwise. */
+int tls_debug_check_counts(tls_ctx *ctx, uint64_t *counts, int n);
 /* block until the stream is idle */
 int tls_synchronize(tls_ctx *ctx);
 /* fetch: copy results (and counters, may be NULL) back; synchronises. */
@@ -145,6 +149,15 @@ int tls_plan_info(const tls_ctx *ctx, tls_counters *counters, int64_t *lds_bytes
 int tls_t0_fit(tls_ctx *ctx, const double *t, const double *y, int64_t n, double period,
                const double *signal, int64_t dur, const double *epochs, int64_t n_epochs,
                int64_t roll, double *out_residuals);
+
+/* ---- SDE spectra: the counterpart of stats.py:105-132 (spectra) with helpers.py:93-108 ---- */
+/* SR, power_raw (scaled to SDE_raw) and power (running-median detrended, scaled to SDE) for the
+ * chi^2 of every period; out_sde[0] = SDE_raw, out_sde[1] = SDE.  chi2 == NULL takes the chi^2 array
+ * that is still resident on the device from the last tls_execute / tls_search (n is then ignored);
+ * `kernel` = oversampling_factor * SDE_MEDIAN_KERNEL_SIZE as the reference forms it (made odd here,
+ * stats.py:114-117). */
+int tls_spectra(tls_ctx *ctx, const double *chi2, int64_t n, int64_t kernel, double *out_SR,
+                double *out_power_raw, double *out_power, double *out_sde);
 
 /* ---- host-only planning (no GPU needed) ------------------------------------------ */
 /* Trial cells (duration x T0 positions) each period will enumerate: the data-independent

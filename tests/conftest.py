@@ -57,7 +57,13 @@ def gpu():
     from tls_amd import _lib
     ctx = _lib.Context(0)
     yield ctx
+    # a checked build (make -C tls_amd/csrc debug, TLS_AMD_LIB=.../libtls_amd_debug.so) counts every violated
+    # device-side bound: after the whole session none may have fired
+    checked, counts = ctx.check_counts()
     ctx.close()
+    if checked:
+        print("\ndevice-side bound checks of the debug build:", counts)
+        assert not any(counts.values()), counts
 
 
 def oracle_search(oracle_lib, inp, periods=None, n_threads=0):

@@ -433,6 +433,33 @@ def test_t0_fit_kernel_vs_oracle_and_reference_residuals(gpu, oracle_lib):
     numpy.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
 
 
+def test_spectra_kernel_vs_reference_and_oracle(gpu, oracle_lib):
+    """tls_spectra (stats.py:105-132 + helpers.py:93-108 on the device) against outputs of the unmodified
+    reference (tests/golden/spectra_*.npz) and against the oracle at benchmark size, both for a chi^2
+    array handed in and for the one still resident after a search."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "spectra_*.npz")))
+    assert len(files) >= 3
+    for f in files:
+        g = numpy.load(f)
+        SR, praw, power, sde_raw, sde = gpu.spectra(int(g["oversampling_factor"]) * 30, g["chi2"])
+        numpy.testing.assert_allclose(SR, g["SR"], rtol=1e-13, err_msg=f)
+        numpy.testing.assert_allclose(praw, g["power_raw"], rtol=1e-10, atol=1e-11, err_msg=f)
+        numpy.testing.assert_allclose(power, g["power"], rtol=1e-10, atol=1e-11, err_msg=f)
+        numpy.testing.assert_allclose([sde_raw, sde], [float(g["SDE_raw"]), float(g["SDE"])], rtol=1e-11)
+        assert int(numpy.argmax(power)) == int(numpy.argmax(g["power"]))
+    inp = _inputs("k2_90d")
+    chi2 = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])[0]
+    for kernel in (90, 150, 31):
+        want = oracle_lib.spectra(chi2, kernel)
+        for got in (gpu.spectra(kernel, chi2), gpu.spectra(kernel)):      # handed in / resident
+            for x, y in zip(got[:3], want[:3]):
+                numpy.testing.assert_allclose(x, y, rtol=1e-10, atol=1e-11)
+            numpy.testing.assert_allclose(got[3:], want[3:], rtol=1e-11)
+            assert int(numpy.argmax(got[2])) == int(numpy.argmax(want[2]))
+    numpy.testing.assert_allclose(oracle_lib.spectra(chi2, 90)[4], 25.71647715, rtol=1e-7)   # SURVEY.md Appendix D
+
+
 def test_too_short_series_is_rejected(gpu):
     from conftest import SimpleTable
     t = numpy.linspace(0.0, 1.0, 9)

@@ -99,6 +99,8 @@ def test_power_gpu_equals_power_with_oracle_search(monkeypatch, oracle_lib, seed
             return oracle_lib.search(t_, y_, dy_, periods, table, transit_depth_min, R_star_min, R_star_max,
                                      M_star_min, M_star_max, T0_fit_margin)[:3]
 
+        monkeypatch.setattr(tls_amd.search, "spectra",
+                            lambda chi2_, osf_, **kw: oracle_lib.spectra(chi2_, int(osf_ * 30)))
         monkeypatch.setattr(tls_amd.search, "search_periods", oracle_search_periods)
         monkeypatch.setattr(tls_amd.search, "t0_fit_residuals",
                             lambda t_, y_, p_, s_, e_, r_, **kw: oracle_lib.t0_residuals(t_, y_, p_, s_, e_, r_))

@@ -21,6 +21,10 @@ def make_model(monkeypatch, oracle_lib):
     def host_t0_fit_residuals(t, y, period, signal, T0_array, roll, **_unused):
         return oracle_lib.t0_residuals(t, y, period, signal, T0_array, roll)   # oracle: stats.py:178-195
 
+    def oracle_spectra(chi2, oversampling_factor, **_unused):
+        return oracle_lib.spectra(chi2, int(oversampling_factor * 30))   # oracle: stats.py:105-132
+
+    monkeypatch.setattr(tls_amd.search, "spectra", oracle_spectra)
     monkeypatch.setattr(tls_amd.search, "search_periods", oracle_search_periods)
     monkeypatch.setattr(tls_amd.search, "t0_fit_residuals", host_t0_fit_residuals)
     return lambda t, y, dy: tls_amd.transitleastsquares(t, y, dy, verbose=False)

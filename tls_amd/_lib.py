@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("TLS_AMD_LIB") or os.path.join(_HERE, "libtls_amd.so")
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
     "tls_device_name", "tls_search", "tls_search_batch", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_t0_fit", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_check_counts",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
     "tls_comm_barrier", "tls_comm_max",
@@ -98,9 +98,13 @@ def load():
     lib.tls_kernel_timing.argtypes = [vp, ci, _c_double_p, _c_int64_p]
     lib.tls_debug_phase_cycles.restype = ci
     lib.tls_debug_phase_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ci]
+    lib.tls_debug_check_counts.restype = ci
+    lib.tls_debug_check_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ci]
     lib.tls_t0_fit.restype = ci
     lib.tls_t0_fit.argtypes = [vp, _c_double_p, _c_double_p, i64, dbl, _c_double_p, i64, _c_double_p,
                                i64, i64, _c_double_p]
+    lib.tls_spectra.restype = ci
+    lib.tls_spectra.argtypes = [vp, _c_double_p, i64, i64, _c_double_p, _c_double_p, _c_double_p, _c_double_p]
     lib.tls_debug_cumsum.restype = ci
     lib.tls_debug_cumsum.argtypes = [vp, _c_double_p, i64, _c_double_p, ci]
     lib.tls_grid_cells.restype = ci
@@ -264,6 +268,17 @@ class Context(object):
                                          len(signal), _dp(epochs), len(epochs), int(roll), _dp(out)))
         return out
 
+    def spectra(self, kernel, chi2=None):
+        """SR, power_raw, power, SDE_raw, SDE (stats.py:105-132) on the device; chi2=None takes the
+        chi^2 of the search that has just finished (still resident in HBM)."""
+        n = self._n_periods if chi2 is None else len(chi2)
+        block = numpy.empty(3 * n + 2, dtype=numpy.float64)     # one block: one device-to-host copy
+        SR, praw, power, sde = block[:n], block[n:2 * n], block[2 * n:3 * n], block[3 * n:]
+        c = None if chi2 is None else _f8(chi2)
+        self._check(self._lib.tls_spectra(self._h, None if c is None else _dp(c), n, int(kernel), _dp(SR), _dp(praw),
+                                          _dp(power), _dp(sde)))
+        return SR, praw, power, float(sde[0]), float(sde[1])
+
     def debug_cumsum(self, values, threads=512):
         """[0, cumsum(values)] computed by the kernel's exact parallel sequential-order scan."""
         v = _f8(values)
@@ -281,6 +296,16 @@ class Context(object):
                  "tile_staging", "predicate_dense", "cs_A", "cs_B1", "cs_B2", "cs_scan", "cs_D", "cs_E",
                  "tile_wait", "chi2_wait", "prune_e2", "prune_bounds", "prune_incumbent", "select_relist")
         return dict(zip(names, [int(v) for v in arr]))
+
+    def check_counts(self):
+        """(checked_build, {check name: violations}) -- device-side bound checks of the debug build."""
+        arr = (ctypes.c_uint64 * 16)()
+        rc = self._lib.tls_debug_check_counts(self._h, arr, 16)
+        if rc < 0:
+            self._check(rc)
+        names = ("lds_carve", "list_capacity", "dot_window", "predicate_read", "sort_window", "work_item",
+                 "singles_capacity", "tile_stage")
+        return bool(rc), dict(zip(names, [int(v) for v in arr]))
 
     def synchronize(self):
         self._check(self._lib.tls_synchronize(self._h))

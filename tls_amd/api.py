@@ -20,7 +20,7 @@ from .results import transitleastsquaresresults
 from .stats import (FAP, all_transit_times, calculate_fill_factor, calculate_stretch,
                     calculate_transit_duration_in_days, count_stats, final_T0_fit,
                     intransit_stats, model_lightcurve, period_uncertainty, rp_rs_from_depth,
-                    snr_stats, spectra)
+                    snr_stats)
 from .template import TemplateTable, fractional_transit, get_cache
 from .validate import validate_args, validate_inputs
 
@@ -121,7 +121,8 @@ class transitleastsquares(object):
             return self._results_without_fit(test_statistic_periods, chi2, chi2red, chi2_min,
                                              chi2red_min)
 
-        SR, power_raw, power, SDE_raw, SDE = spectra(chi2, self.oversampling_factor)
+        SR, power_raw, power, SDE_raw, SDE = _search.spectra(chi2, self.oversampling_factor, resident=True,
+                                                             context=kwargs.get("context"), device=kwargs.get("device"))
         # period and depth come from the detrended power peak, the template row from
         # the chi^2 minimum (main.py:198-200 vs 270-272)
         index_highest_power = numpy.argmax(power)

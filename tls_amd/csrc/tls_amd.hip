@@ -80,14 +80,28 @@ struct tls_ctx {
     DevBuf<int> d_order;
     DevBuf<tlsdev::PeriodRows> d_rows;
     DevBuf<tlsdev::WidthEntry> d_widths;
-    DevBuf<unsigned long long> d_counters, d_phase;
+    DevBuf<unsigned long long> d_counters, d_phase, d_check;
     DevBuf<unsigned int> d_queue, d_squeue, d_lists, d_perm;   // d_squeue: the search kernel's self-rewinding queue
     DevBuf<double> d_curve_S0, d_curve_w0;   // survey batches
+    // survey batches: two slots of device + pinned host buffers, a second stream for the transfers
+    struct BatchSlot {
+        DevBuf<double> d_y, d_w, d_S0, d_w0, d_chi2, d_depth;
+        DevBuf<long long> d_row;
+        double* h_in = nullptr; size_t h_in_cap = 0;     // pinned: y | w | S0 | w0 of one group
+        double* h_out = nullptr; size_t h_out_cap = 0;   // pinned: chi2 | row | depth of one group
+        hipEvent_t ev_in = nullptr, ev_kernel = nullptr, ev_out = nullptr;
+    } slot[2];
+    hipStream_t copy_stream = nullptr;
+    // enqueue() reads these when set (a batch slot); otherwise the context's own buffers
+    const double* over_y = nullptr; const double* over_w = nullptr;
+    const double* over_S0 = nullptr; const double* over_w0 = nullptr;
+    double* over_chi2 = nullptr; long long* over_row = nullptr; double* over_depth = nullptr;
     bool sort2 = false;                      // tiled variant: two-level sort
     bool sort3 = false;                      // tiled variant, one light curve: fused partition + per-bin sort + prefix sum
     DevBuf<unsigned long long> d_sort3;      // its pass-1 output
     int batch_curves = 1;                    // light curves the next launch searches (tls_search_batch)
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
+    DevBuf<double> d_spec;                                         // SDE spectra: SR | power_raw | power | sde[2] | chi2 copy
     size_t list_stride = 0;
     int hdr_bytes = 0, tile_len = 0, tile_halo = 0, region_pad = 0, p2_shift = 4;
     bool prune_kernel = false;        // launch the pruning variant (pruning_pays)
@@ -302,10 +316,13 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     if (count_work)
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
     tlsdev::SearchArgs a;
-    a.t = ctx->d_t.ptr; a.y = ctx->d_y.ptr; a.w = ctx->uniform_w ? nullptr : ctx->d_w.ptr;
+    a.t = ctx->d_t.ptr; a.y = ctx->over_y ? ctx->over_y : ctx->d_y.ptr;
+    a.w = ctx->uniform_w ? nullptr : (ctx->over_w ? ctx->over_w : ctx->d_w.ptr);
     a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.rows = ctx->d_rows.ptr;
     a.widths = ctx->d_widths.ptr; a.q = ctx->d_q.ptr; a.q2 = ctx->uniform_w ? nullptr : ctx->d_q2.ptr;
-    a.out_chi2 = ctx->d_chi2.ptr; a.out_row = ctx->d_row.ptr; a.out_depth = ctx->d_depth.ptr;
+    a.out_chi2 = ctx->over_chi2 ? ctx->over_chi2 : ctx->d_chi2.ptr;
+    a.out_row = ctx->over_row ? ctx->over_row : ctx->d_row.ptr;
+    a.out_depth = ctx->over_depth ? ctx->over_depth : ctx->d_depth.ptr;
     a.counters = count_work ? ctx->d_counters.ptr : nullptr;
     a.phase_cycles = nullptr;
     if (phase_clock) {
@@ -313,6 +330,14 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_phase.ptr, 0, tlsdev::kPhases * sizeof(unsigned long long), ctx->stream));
         a.phase_cycles = ctx->d_phase.ptr;
     }
+    a.check = nullptr; a.lds_bytes = (long long)ctx->lds_bytes;
+#ifdef TLS_DEBUG_CHECKS
+    if (!ctx->d_check.ptr) {
+        TLS_HIP(ctx, ctx->d_check.reserve(tlsdev::kChecks));
+        TLS_HIP(ctx, hipMemsetAsync(ctx->d_check.ptr, 0, tlsdev::kChecks * sizeof(unsigned long long), ctx->stream));
+    }
+    a.check = ctx->d_check.ptr;
+#endif
     a.queue = ctx->d_squeue.ptr;
     a.scratch = ctx->d_scratch.ptr;
     a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1 + ctx->region_pad);
@@ -322,7 +347,9 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
     a.sort2 = ctx->sort2 ? 1 : 0;
     a.sort3 = ctx->sort3 ? 1 : 0; a.sort3_scratch = ctx->d_sort3.ptr;
-    a.n_curves = ctx->batch_curves; a.curve_S0 = ctx->d_curve_S0.ptr; a.curve_w0 = ctx->d_curve_w0.ptr;
+    a.n_curves = ctx->batch_curves;
+    a.curve_S0 = ctx->over_S0 ? ctx->over_S0 : ctx->d_curve_S0.ptr;
+    a.curve_w0 = ctx->over_w0 ? ctx->over_w0 : ctx->d_curve_w0.ptr;
     a.perm_scratch = ctx->d_perm.ptr;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
@@ -405,8 +432,17 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_chi2.release(); ctx->d_depth.release(); ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release(); ctx->d_row.release(); ctx->d_order.release();
     ctx->d_rows.release(); ctx->d_widths.release(); ctx->d_counters.release();
-    ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
+    ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
+    for (auto& sl : ctx->slot) {
+        sl.d_y.release(); sl.d_w.release(); sl.d_S0.release(); sl.d_w0.release(); sl.d_chi2.release(); sl.d_depth.release(); sl.d_row.release();
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+        if (sl.ev_kernel) (void)hipEventDestroy(sl.ev_kernel);
+        if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (auto& evp : ctx->ev_pool) { (void)hipEventDestroy(evp.first); (void)hipEventDestroy(evp.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -679,6 +715,48 @@ int tls_t0_fit(tls_ctx* ctx, const double* t, const double* y, int64_t n, double
     return TLS_OK;
 }
 
+int tls_spectra(tls_ctx* ctx, const double* chi2, int64_t n, int64_t kernel, double* out_SR, double* out_power_raw,
+                double* out_power, double* out_sde) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!out_SR || !out_power_raw || !out_power || !out_sde) return fail(ctx, TLS_E_ARG, "null output");
+    if (kernel < 1 || kernel > 8191) return fail(ctx, TLS_E_ARG, "median kernel out of range [1, 8191]");
+    if (!chi2 && !(ctx->executed && ctx->n_periods > 0)) return fail(ctx, TLS_E_STATE, "tls_spectra without chi2 needs a finished search");
+    if (chi2 && (n < 1 || n > 100000000)) return fail(ctx, TLS_E_ARG, "n out of range");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!chi2) n = ctx->n_periods;
+    if (kernel % 2 == 0) kernel += 1;                                   // stats.py:115-117
+    const size_t nn = (size_t)n;
+    TLS_HIP(ctx, ctx->d_spec.reserve(4 * nn + 2));
+    double* d_in = ctx->d_chi2.ptr;
+    if (chi2) {
+        d_in = ctx->d_spec.ptr + 3 * nn + 2;
+        TLS_HIP(ctx, hipMemcpyAsync(d_in, chi2, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    tlsdev::SpectraArgs a;
+    a.chi2 = d_in; a.SR = ctx->d_spec.ptr; a.power_raw = ctx->d_spec.ptr + nn; a.power = ctx->d_spec.ptr + 2 * nn;
+    a.sde = ctx->d_spec.ptr + 3 * nn; a.n = (int)n; a.kernel = (int)kernel; a.detrend = n > 2 * kernel ? 1 : 0;
+    hipLaunchKernelGGL(tlsdev::tls_spectra_head, dim3(1), dim3(1024), 0, ctx->stream, a);
+    if (a.detrend) {
+        const int n_med = (int)(n - kernel + 1), threads = 256;
+        const size_t lds = (size_t)(threads + kernel) * 8;
+        hipLaunchKernelGGL(tlsdev::tls_spectra_median, dim3((unsigned)((n_med + threads - 1) / threads)), dim3(threads), lds,
+                           ctx->stream, a);
+        hipLaunchKernelGGL(tlsdev::tls_spectra_tail, dim3(1), dim3(1024), 0, ctx->stream, a);
+    }
+    TLS_HIP(ctx, hipGetLastError());
+    if (out_power_raw == out_SR + nn && out_power == out_power_raw + nn && out_sde == out_power + nn) {
+        // the caller's four outputs are one block, like the device's: one copy instead of four
+        TLS_HIP(ctx, hipMemcpyAsync(out_SR, a.SR, (3 * nn + 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        TLS_HIP(ctx, hipMemcpyAsync(out_SR, a.SR, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(out_power_raw, a.power_raw, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(out_power, a.power, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(out_sde, a.sde, 16, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TLS_OK;
+}
+
 int tls_debug_cumsum(tls_ctx* ctx, const double* f, int64_t count, double* out, int threads) {
     if (!ctx || !f || !out || count < 0 || count > 100000000) return fail(ctx, TLS_E_ARG, "bad argument");
     if (threads < 64 || threads > 1024 || threads % 64) return fail(ctx, TLS_E_ARG, "threads must be a multiple of 64 in [64, 1024]");
@@ -720,6 +798,23 @@ int tls_debug_phase_cycles(tls_ctx* ctx, uint64_t* cycles, int n) {
     TLS_HIP(ctx, hipMemcpy(host, ctx->d_phase.ptr, sizeof host, hipMemcpyDeviceToHost));
     for (int i = 0; i < n && i < tlsdev::kPhases; ++i) cycles[i] = host[i];
     return TLS_OK;
+}
+
+int tls_debug_check_counts(tls_ctx* ctx, uint64_t* counts, int n) {
+    if (!ctx || !counts || n < 1) return fail(ctx, TLS_E_ARG, "bad argument");
+    for (int i = 0; i < n; ++i) counts[i] = 0;
+#ifdef TLS_DEBUG_CHECKS
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_check.ptr) {
+        unsigned long long host[tlsdev::kChecks];
+        TLS_HIP(ctx, hipMemcpy(host, ctx->d_check.ptr, sizeof host, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n && i < tlsdev::kChecks; ++i) counts[i] = host[i];
+    }
+    return 1;   // a checked build
+#else
+    return TLS_OK;   // not a checked build: all zero
+#endif
 }
 
 int tls_synchronize(tls_ctx* ctx) {
@@ -820,46 +915,107 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
     if (n_periods == 0) return TLS_OK;
     // Curves go to the device in groups: ONE launch searches a whole group, and inside the kernel
     // the fold + sort of a period is done once for all curves of the group (it depends on t only).
+    // The groups are pipelined over two slots of device and pinned host buffers: while group g is
+    // searched, group g+1 is prepared on the host (weights, S0) and uploaded on a second stream, and the
+    // results of group g-1 travel back and are copied into the caller's arrays.
     const int64_t group = 32;
     const size_t np = (size_t)n_periods, nn = (size_t)n;
-    std::vector<double> w, w_all, S0s, w0s;
-    for (int64_t c0 = 0; c0 < n_curves; c0 += group) {
-        const int64_t gc = std::min(group, n_curves - c0);
-        S0s.assign((size_t)gc, 0.0); w0s.assign((size_t)gc, 1.0);
-        if (!ctx->uniform_w) w_all.resize((size_t)gc * nn);
+    const bool uni = ctx->uniform_w;
+    if (!ctx->copy_stream) TLS_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    const size_t in_doubles = (size_t)group * nn * (uni ? 1 : 2) + 2 * (size_t)group;
+    const size_t out_doubles = 3 * (size_t)group * np;
+    for (auto& sl : ctx->slot) {
+        if (!sl.ev_in) {
+            TLS_HIP(ctx, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+            TLS_HIP(ctx, hipEventCreateWithFlags(&sl.ev_kernel, hipEventDisableTiming));
+            TLS_HIP(ctx, hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+        }
+        if (sl.h_in_cap < in_doubles) {
+            if (sl.h_in) TLS_HIP(ctx, hipHostFree(sl.h_in));
+            sl.h_in = nullptr; sl.h_in_cap = 0;
+            TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.h_in), in_doubles * 8, hipHostMallocDefault));
+            sl.h_in_cap = in_doubles;
+        }
+        if (sl.h_out_cap < out_doubles) {
+            if (sl.h_out) TLS_HIP(ctx, hipHostFree(sl.h_out));
+            sl.h_out = nullptr; sl.h_out_cap = 0;
+            TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), out_doubles * 8, hipHostMallocDefault));
+            sl.h_out_cap = out_doubles;
+        }
+        TLS_HIP(ctx, sl.d_y.reserve((size_t)group * nn));
+        if (!uni) TLS_HIP(ctx, sl.d_w.reserve((size_t)group * nn));
+        TLS_HIP(ctx, sl.d_S0.reserve((size_t)group));
+        TLS_HIP(ctx, sl.d_w0.reserve((size_t)group));
+        TLS_HIP(ctx, sl.d_chi2.reserve((size_t)group * np));
+        TLS_HIP(ctx, sl.d_row.reserve((size_t)group * np));
+        TLS_HIP(ctx, sl.d_depth.reserve((size_t)group * np));
+    }
+    TLS_HIP(ctx, ctx->d_perm.reserve((size_t)ctx->blocks * nn));
+    const int64_t n_groups = (n_curves + group - 1) / group;
+    auto drain = [&](int64_t g) -> int {   // results of group g: wait for its download, copy to the caller's arrays
+        auto& sl = ctx->slot[g & 1];
+        const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
+        TLS_HIP(ctx, hipEventSynchronize(sl.ev_out));
+        const size_t cnt = (size_t)gc * np;
+        std::memcpy(out_chi2 + c0 * n_periods, sl.h_out, cnt * 8);
+        std::memcpy(out_row + c0 * n_periods, sl.h_out + (size_t)group * np, cnt * 8);
+        std::memcpy(out_depth + c0 * n_periods, sl.h_out + 2 * (size_t)group * np, cnt * 8);
+        return TLS_OK;
+    };
+    std::vector<double> w;
+    rc = TLS_OK;
+    for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
+        auto& sl = ctx->slot[g & 1];
+        const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
+        if (g >= 2 && (rc = drain(g - 2))) break;           // the slot's buffers are free again
+        // host side of the group: flux into the pinned staging area, weights, S0 (core.py:127)
+        double* h_y = sl.h_in;
+        double* h_w = sl.h_in + (size_t)group * nn;
+        double* h_S0 = sl.h_in + (size_t)group * nn * (uni ? 1 : 2);
+        double* h_w0 = h_S0 + group;
         double sigma_sum = 0.0;
         for (int64_t c = 0; c < gc; ++c) {
             bool uniform; double w0, S0;
             weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0);
-            if (uniform != ctx->uniform_w)
-                return fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy");
-            S0s[(size_t)c] = S0; w0s[(size_t)c] = w0;
-            if (!uniform) std::copy(w.begin(), w.end(), w_all.begin() + (size_t)c * nn);
+            if (uniform != uni) { rc = fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy"); break; }
+            h_S0[c] = S0; h_w0[c] = w0;
+            std::memcpy(h_y + (size_t)c * nn, y + (c0 + c) * n, nn * 8);
+            if (!uniform) std::memcpy(h_w + (size_t)c * nn, w.data(), nn * 8);
             sigma_sum += flux_scatter(y + (c0 + c) * n, n);
         }
-        if ((rc = upload(ctx, ctx->d_y, y + c0 * n, (size_t)gc * nn))) return rc;
-        if (!ctx->uniform_w && (rc = upload(ctx, ctx->d_w, w_all.data(), (size_t)gc * nn))) return rc;
-        if ((rc = upload(ctx, ctx->d_curve_S0, S0s.data(), (size_t)gc))) return rc;
-        if ((rc = upload(ctx, ctx->d_curve_w0, w0s.data(), (size_t)gc))) return rc;
-        TLS_HIP(ctx, ctx->d_chi2.reserve((size_t)gc * np));
-        TLS_HIP(ctx, ctx->d_row.reserve((size_t)gc * np));
-        TLS_HIP(ctx, ctx->d_depth.reserve((size_t)gc * np));
-        TLS_HIP(ctx, ctx->d_perm.reserve((size_t)ctx->blocks * nn));
-        ctx->S0 = S0s[0]; ctx->w0 = w0s[0];
-        ctx->prune_kernel = ctx->uniform_w && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident);
+        if (rc) break;
+        TLS_HIP(ctx, hipMemcpyAsync(sl.d_y.ptr, h_y, (size_t)gc * nn * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        if (!uni) TLS_HIP(ctx, hipMemcpyAsync(sl.d_w.ptr, h_w, (size_t)gc * nn * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        TLS_HIP(ctx, hipMemcpyAsync(sl.d_S0.ptr, h_S0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        TLS_HIP(ctx, hipMemcpyAsync(sl.d_w0.ptr, h_w0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        TLS_HIP(ctx, hipEventRecord(sl.ev_in, ctx->copy_stream));
+        TLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ev_in, 0));
+        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0];
+        ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident);
         ctx->batch_curves = (int)gc;
+        ctx->over_y = sl.d_y.ptr; ctx->over_w = uni ? nullptr : sl.d_w.ptr; ctx->over_S0 = sl.d_S0.ptr; ctx->over_w0 = sl.d_w0.ptr;
+        ctx->over_chi2 = sl.d_chi2.ptr; ctx->over_row = sl.d_row.ptr; ctx->over_depth = sl.d_depth.ptr;
         rc = enqueue(ctx, false);
         ctx->batch_curves = 1;
-        if (rc) return rc;
-        TLS_HIP(ctx, hipMemcpyAsync(out_chi2 + c0 * n_periods, ctx->d_chi2.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
-        TLS_HIP(ctx, hipMemcpyAsync(out_row + c0 * n_periods, ctx->d_row.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
-        TLS_HIP(ctx, hipMemcpyAsync(out_depth + c0 * n_periods, ctx->d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
-        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors above are reused by the next group
+        ctx->over_y = ctx->over_w = ctx->over_S0 = ctx->over_w0 = nullptr;
+        ctx->over_chi2 = nullptr; ctx->over_row = nullptr; ctx->over_depth = nullptr;
+        if (rc) break;
+        TLS_HIP(ctx, hipEventRecord(sl.ev_kernel, ctx->stream));
+        TLS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, sl.ev_kernel, 0));
+        TLS_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_chi2.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+        TLS_HIP(ctx, hipMemcpyAsync(sl.h_out + (size_t)group * np, sl.d_row.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+        TLS_HIP(ctx, hipMemcpyAsync(sl.h_out + 2 * (size_t)group * np, sl.d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+        TLS_HIP(ctx, hipEventRecord(sl.ev_out, ctx->copy_stream));
     }
-    // the context keeps the plan, but its device buffers now hold a group of curves: a staged
-    // execute must be preceded by tls_update_flux or a new tls_prepare
+    if (rc == TLS_OK) {
+        for (int64_t g = std::max<int64_t>(0, n_groups - 2); g < n_groups && rc == TLS_OK; ++g) rc = drain(g);
+    } else {
+        (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->copy_stream);
+    }
+    // the context keeps the plan, but the search ran on the batch slots: a staged execute
+    // must be preceded by tls_update_flux or a new tls_prepare
     ctx->executed = false;
-    return TLS_OK;
+    return rc;
 }
 
 int tls_grid_cells(const double* t, int64_t n, const double* periods, int64_t n_periods, const tls_template* tmpl,

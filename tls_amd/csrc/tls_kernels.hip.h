@@ -61,7 +61,29 @@
 #define TLS_WAVES_PER_EU 4
 #endif
 
+// Debug build (make -C tls_amd/csrc debug: -DTLS_DEBUG_CHECKS): every hand-computed bound of the kernel --
+// LDS carve-up, live-unit list capacity, tile/halo indices of the dot products, sort windows, work-queue
+// indices -- is tested on the device; a violation is COUNTED per check (SearchArgs::check, read back by
+// tls_debug_check_counts), never trapped, so one run reports every broken bound.
+#ifdef TLS_DEBUG_CHECKS
+#define TLS_CHECK(a, cond, code) do { if (!(cond) && (a).check) atomicAdd(&(a).check[(code)], 1ull); } while (0)
+#else
+#define TLS_CHECK(a, cond, code) do { } while (0)
+#endif
+
 namespace tlsdev {
+
+constexpr int kChecks = 16;   // slots of SearchArgs::check
+enum CheckCode {
+    kChkLdsCarve = 0,      // header + regions exceed the dynamic LDS of the launch
+    kChkListCap = 1,       // a live-unit list outgrew its row's slots
+    kChkDotWindow = 2,     // a dot product reads outside the staged samples
+    kChkPredicateRead = 3, // the depth predicate reads C outside [0, M + region_pad]
+    kChkSortWindow = 4,    // a sort bin outgrew its LDS window without being caught
+    kChkWorkItem = 5,      // period / row index out of range
+    kChkSinglesCap = 6,    // re-listed positions outgrew the row's slots
+    kChkTileStage = 7,     // a tile was staged beyond the LDS buffer
+};
 
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
@@ -290,6 +312,8 @@ struct SearchArgs {
     double* out_depth;      // [n_periods]
     unsigned long long* counters;      // [3] evaluated cells, inner steps, issued lane-FMAs (nullptr: off)
     unsigned long long* phase_cycles;  // [kPhases] shader cycles per phase (nullptr: off)
+    unsigned long long* check;         // [kChecks] violated bounds (debug build; nullptr: off)
+    long long lds_bytes;               // dynamic LDS of the launch (debug checks)
     unsigned int* queue;        // [2] next work item, workgroups done (both 0 at launch, rewound by the kernel)
     double* scratch;        // non-resident: per-workgroup slabs of the folded series
     unsigned int* chunk_lists;  // per-workgroup lists of live chunks (phase 3a -> 3b)
@@ -1457,7 +1481,8 @@ __host__ __device__ constexpr long long sort2_lds_bytes(int n) {
 __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, double period, double epoch, double* g_ph,
                                                     unsigned int* g_idx, unsigned int* perm, unsigned char* lds,
                                                     PhaseClock& pc, const double* y_gather = nullptr,
-                                                    const double* w_gather = nullptr, double* w_out_g = nullptr) {
+                                                    const double* w_gather = nullptr, double* w_out_g = nullptr,
+                                                    unsigned long long* dbg_check = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -1597,6 +1622,9 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
             const int b = b0 + wave;
             const unsigned int first = b < B ? g_start[b] : 0u;
             const int m = b < B ? (int)(g_start[b + 1] - first) : 0;
+#ifdef TLS_DEBUG_CHECKS
+            if (dbg_check && !(m <= kSort2BinCap) && lane == 0) atomicAdd(&dbg_check[kChkSortWindow], 1ull);
+#endif
             // fine bucket of a point inside its coarse bin: monotone in the phase
             int fb[kE];
 #pragma unroll
@@ -2126,6 +2154,12 @@ tls_search_kernel(const SearchArgs a) {
     IdxT* perm = idx_tmp + n;
     double* ph_orig = regA;  // phase by ORIGINAL index during the sort
 
+    if (tid == 0) {
+        [[maybe_unused]] const long long need = RESIDENT ? (long long)a.hdr_bytes + (UNIFORM_W ? 2 : 3) * 8LL * RS
+                                        : (long long)a.hdr_bytes + (UNIFORM_W ? (STAGE_C ? 2 : 1) : (STAGE_C ? 3 : 2)) * 8LL * (a.tile_len + a.tile_halo);
+        TLS_CHECK(a, need <= a.lds_bytes, kChkLdsCarve);
+        TLS_CHECK(a, (long long)kFixedHeader + 4LL * (3 * a.n_widths + 2) <= a.hdr_bytes, kChkLdsCarve);
+    }
     // the spare entries behind each region are only ever multiplied by zero: make them finite
     for (int k = tid; k < region_pad; k += nt) {
         regA[M + 1 + k] = 0.0;
@@ -2154,6 +2188,7 @@ tls_search_kernel(const SearchArgs a) {
             break;
         }
         const int p = a.order[work];
+        TLS_CHECK(a, p >= 0 && p < a.n_periods, kChkWorkItem);
         const double period = a.periods[p];
         PhaseClock pc;
         pc.start(a.phase_cycles);
@@ -2172,7 +2207,7 @@ tls_search_kernel(const SearchArgs a) {
             if (!fused && a.sort2)
                 sorted = fold_and_sort_tiled(a.t, n, period, 0.0, ph_orig, reinterpret_cast<unsigned int*>(idx_tmp),
                                              reinterpret_cast<unsigned int*>(perm), smem + a.hdr_bytes, pc,
-                                             a.n_curves == 1 ? a.y : nullptr, UNIFORM_W ? nullptr : a.w, regW);
+                                             a.n_curves == 1 ? a.y : nullptr, UNIFORM_W ? nullptr : a.w, regW, a.check);
         }
         if (!sorted && !fused) fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc);
         // survey mode: the permutation depends on (t, period) only, so every light curve of the
@@ -2226,6 +2261,7 @@ tls_search_kernel(const SearchArgs a) {
         const int k_hi = __builtin_amdgcn_readfirstlane(rows_c[p].k_hi);
         const int k_x = __builtin_amdgcn_readfirstlane(rows_c[p].k_x);
         const int n_rows = k_hi - k_lo;
+        TLS_CHECK(a, 0 <= k_lo && k_lo <= k_x && k_x <= k_hi && k_hi <= a.n_widths, kChkWorkItem);
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup
         if constexpr (RESIDENT) {
@@ -2338,6 +2374,7 @@ tls_search_kernel(const SearchArgs a) {
                 const int u0 = unit * kR;
                 const int u0c = u0 < M + 1 ? u0 : M + 1;  // lanes past the row read sentinels and are masked
                 double c_lo[kR];
+                TLS_CHECK(a, u0c >= p_lo && u0c + kR - 1 <= M + region_pad && (RESIDENT || u0c + kR - 1 < p_lo + a.tile_len + a.tile_halo), kChkPredicateRead);
 #pragma unroll
                 for (int r = 0; r < kR; ++r) c_lo[r] = c_base[u0c + r];
                 // Lane j collects the live mask of row k_lo + j of this 64-unit tile; the list slots of
@@ -2356,6 +2393,7 @@ tls_search_kernel(const SearchArgs a) {
                         dv[j] = widths_c[kk].width;
                         inv[j] = widths_c[kk].inv_d;
                         const int hi0 = u0 + dv[j] < M + 1 ? u0 + dv[j] : M + 1;  // past the grid: sentinels
+                        TLS_CHECK(a, hi0 + kR - 1 <= M + region_pad && (RESIDENT || unit >= unit_hi || hi0 + kR - 1 < p_lo + a.tile_len + a.tile_halo), kChkPredicateRead);
 #pragma unroll
                         for (int r = 0; r < kR; ++r) c_hi[j][r] = c_base[hi0 + r];
                     }
@@ -2392,6 +2430,7 @@ tls_search_kernel(const SearchArgs a) {
                         const int j = __ffsll((long long)left) - 1;
                         const unsigned long long mask = (unsigned long long)lane_value((long long)row_mask, j);
                         const unsigned int b0 = (unsigned int)lane_value((int)base, j);
+                        TLS_CHECK(a, b0 + (unsigned int)__popcll(mask) <= (unsigned int)widths_c[k_lo + j].n_chunks, kChkListCap);
                         if ((mask >> lane) & 1ull)
                             chunk_list[widths_c[k_lo + j].list_base + b0 + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
                     }
@@ -2450,6 +2489,7 @@ tls_search_kernel(const SearchArgs a) {
                     n_listed += (unsigned int)__popcll(mask);
                 }
             }
+            TLS_CHECK(a, n_listed <= (unsigned int)widths_c[k].n_chunks, kChkListCap);
             if (lane == 0) rt.live[k - k_lo] = n_listed;
         }
         __syncthreads();
@@ -2712,6 +2752,7 @@ tls_search_kernel(const SearchArgs a) {
                 }
                 if (count == 0) n_live = 0;   // every window of every selected chunk was pruned
             }
+            TLS_CHECK(a, (unsigned int)n_live + count <= (unsigned int)n_units, kChkSinglesCap);
             if (lane == 0) { rt.live[row] = (unsigned int)n_live; rt.singles[row] = count; }
         }
         pc.mark(25);
@@ -2777,6 +2818,8 @@ tls_search_kernel(const SearchArgs a) {
                     // kR windows per lane, xth samples apart
                     const int u0 = unit * kR;
                     const int b = u0 * xth;
+                    // the unrolled loop reads samples b .. b + ceil((L + (kR-1)*xth) / kU) * kU - 1
+                    TLS_CHECK(a, !have || (b >= p_lo && b + (L + (kR - 1) * xth + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + a.tile_len + a.tile_halo)), kChkDotWindow);
                     const double* e = e_base + b;
                     double Bv[kR], Av[kR];
 #pragma unroll
@@ -2816,6 +2859,7 @@ tls_search_kernel(const SearchArgs a) {
                 } else {
                     // wide T0 strides and re-listed sparse rows: one window per lane
                     const int i = unit * xth;
+                    TLS_CHECK(a, !have || (i >= p_lo && i + (L + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + a.tile_len + a.tile_halo)), kChkDotWindow);
                     const double* e = e_base + i;
                     double B0 = 0, B1 = 0, A0 = 0, A1 = 0;
                     if constexpr (UNIFORM_W) {
@@ -2981,6 +3025,117 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a) {
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// SDE spectra from the chi^2 of every period (reference stats.py:105-132 with the running median of
+// helpers.py:93-108), on the chi^2 array that is still resident after the search:
+//   tls_spectra_head    SR = min(chi2)/chi2, SDE_raw = (1 - mean SR)/std SR, power_raw scaled to SDE_raw
+//   tls_spectra_median  power = power_raw - running median (window `kernel`, odd; edges padded)
+//   tls_spectra_tail    power -= mean; SDE = max(power)/std(power); power scaled to SDE
+// Sums are fp64 tree reductions (numpy sums pairwise: the two agree to ~1e-16 relative).
+struct SpectraArgs {
+    const double* chi2;
+    double* SR;
+    double* power_raw;
+    double* power;
+    double* sde;        // [0] SDE_raw, [1] SDE
+    int n, kernel, detrend;   // detrend: n > 2 * kernel (stats.py:118)
+};
+
+template <typename Op>
+__device__ __forceinline__ double block_reduce(double v, Op op, double* red /* LDS [kMaxWaves + 1] */) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nw = blockDim.x / kWave;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v = op(v, __shfl_down(v, d, kWave));
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = red[0];
+        for (int k = 1; k < nw; ++k) r = op(r, red[k]);
+        red[kMaxWaves] = r;
+    }
+    __syncthreads();
+    return red[kMaxWaves];
+}
+
+__global__ void __launch_bounds__(1024) tls_spectra_head(const SpectraArgs a) {
+    __shared__ double red[kMaxWaves + 1];
+    const int tid = threadIdx.x, nt = blockDim.x, n = a.n;
+    auto add = [](double x, double y) { return x + y; };
+    auto mn = [](double x, double y) { return x < y ? x : y; };
+    auto mx = [](double x, double y) { return x > y ? x : y; };
+    double v = INFINITY;
+    for (int k = tid; k < n; k += nt) v = mn(v, a.chi2[k]);
+    const double cmin = block_reduce(v, mn, red);
+    v = 0.0;
+    for (int k = tid; k < n; k += nt) { const double sr = cmin / a.chi2[k]; a.SR[k] = sr; v += sr; }   // stats.py:106
+    const double mean = block_reduce(v, add, red) / (double)n;
+    v = 0.0;
+    for (int k = tid; k < n; k += nt) { const double d = a.SR[k] - mean; v += d * d; }
+    const double sd = sqrt(block_reduce(v, add, red) / (double)n);
+    const double sde_raw = (1 - mean) / sd;                                                    // :107
+    v = -INFINITY;
+    for (int k = tid; k < n; k += nt) v = mx(v, a.SR[k] - mean);
+    const double scale = sde_raw / block_reduce(v, mx, red);                                   // :111
+    for (int k = tid; k < n; k += nt) {
+        const double p = (a.SR[k] - mean) * scale;
+        a.power_raw[k] = p;
+        if (!a.detrend) a.power[k] = p;                                                        // :128
+    }
+    if (tid == 0) { a.sde[0] = sde_raw; if (!a.detrend) a.sde[1] = sde_raw; }
+}
+
+// one window per thread: the median of an odd window is its element of rank kernel/2
+__global__ void __launch_bounds__(256) tls_spectra_median(const SpectraArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* w = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, nt = blockDim.x, n = a.n, k = a.kernel;
+    const int n_med = n - k + 1, first = blockIdx.x * nt;
+    const int staged = (first + nt < n_med ? nt : n_med - first) + k - 1;
+    for (int j = tid; j < staged; j += nt) w[j] = a.power_raw[first + j];
+    __syncthreads();
+    const int i = first + tid;
+    if (i >= n_med) return;
+    const double* x = w + tid;
+    double med = x[0];
+    for (int j = 0; j < k; ++j) {
+        const double xj = x[j];
+        int rank = 0;
+        for (int l = 0; l < k; ++l) rank += (x[l] < xj || (x[l] == xj && l < j)) ? 1 : 0;
+        if (rank == k / 2) { med = xj; break; }
+    }
+    // helpers.py:100-108: the medians sit in the middle, the first/last one pads the edges
+    const int missing = n - n_med, front = (int)((double)missing * 0.5);
+    a.power[front + i] = a.power_raw[front + i] - med;                                         // stats.py:120
+    if (i == 0) for (int j = 0; j < front; ++j) a.power[j] = a.power_raw[j] - med;
+    if (i == n_med - 1) for (int j = front + n_med; j < n; ++j) a.power[j] = a.power_raw[j] - med;
+}
+
+__global__ void __launch_bounds__(1024) tls_spectra_tail(const SpectraArgs a) {
+    __shared__ double red[kMaxWaves + 1];
+    const int tid = threadIdx.x, nt = blockDim.x, n = a.n;
+    auto add = [](double x, double y) { return x + y; };
+    auto mx = [](double x, double y) { return x > y ? x : y; };
+    double v = 0.0;
+    for (int k = tid; k < n; k += nt) v += a.power[k];
+    const double mean = block_reduce(v, add, red) / (double)n;                                 // :123
+    v = 0.0;
+    double top = -INFINITY;
+    for (int k = tid; k < n; k += nt) { const double p = a.power[k] - mean; a.power[k] = p; top = mx(top, p); }
+    // mean of the shifted values (numpy.std subtracts it again)
+    v = 0.0;
+    for (int k = tid; k < n; k += nt) v += a.power[k];
+    const double mean2 = block_reduce(v, add, red) / (double)n;
+    v = 0.0;
+    for (int k = tid; k < n; k += nt) { const double d = a.power[k] - mean2; v += d * d; }
+    const double sd = sqrt(block_reduce(v, add, red) / (double)n);
+    const double pmax = block_reduce(top, mx, red);
+    const double sde = pmax / sd;                                                              // :124 (division is monotone)
+    const double scale = sde / pmax;                                                           // :126
+    for (int k = tid; k < n; k += nt) a.power[k] = a.power[k] * scale;
+    if (tid == 0) a.sde[1] = sde;
 }
 
 // Developer/test entry: the exact sequential cumsum on an arbitrary non-negative series

@@ -44,3 +44,17 @@ def t0_fit_residuals(t, y, period, signal, T0_array, roll, context=None, device=
     tls_amd.stats.t0_fit_residuals_host."""
     ctx = context if context is not None else default_context(device)
     return ctx.t0_fit_residuals(t, y, period, signal, T0_array, roll)
+
+
+def spectra(chi2, oversampling_factor, context=None, device=None, resident=False):
+    """SR, power_raw, power, SDE_raw, SDE from the chi^2 of every period (reference stats.py:105-132),
+    evaluated on the device (tls_spectra: reductions + running-median detrend)."""
+    # (search_periods is looked up at call time: a test that injects a CPU search also injects this function)
+    from . import constants as C
+    kernel = oversampling_factor * C.SDE_MEDIAN_KERNEL_SIZE
+    if kernel != int(kernel):
+        # (the reference indexes past the end of its window array for such a kernel, helpers.py:95-97)
+        raise ValueError("oversampling_factor * %d must be an integer" % C.SDE_MEDIAN_KERNEL_SIZE)
+    ctx = context if context is not None else default_context(device)
+    # resident: chi2 is exactly what the search that has just finished on this context left in HBM
+    return ctx.spectra(int(kernel), None if resident else chi2)

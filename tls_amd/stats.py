@@ -1,4 +1,4 @@
-"""Post-search statistics on the host: SDE spectra, the final T0 fit, transit
+"""Post-search statistics on the host: the final T0 fit (its loop on the device), transit
 times, per-transit depth/SNR/count statistics, FAP lookup.
 
 Host numpy.  Behaviour follows the reference's stats.py:10-469 including the
@@ -96,28 +96,6 @@ def period_uncertainty(periods, power):
         return 0.5 * (periods[upper] - periods[lower])
     except Exception:
         return float("inf")
-
-
-def spectra(chi2, oversampling_factor):
-    """Signal residue and detection efficiency spectra from chi^2 per period:
-    returns SR, power_raw, power, SDE_raw, SDE (reference stats.py:105-132)."""
-    SR = numpy.min(chi2) / chi2
-    SDE_raw = (1 - numpy.mean(SR)) / numpy.std(SR)
-    power_raw = SR - numpy.mean(SR)
-    power_raw = power_raw * (SDE_raw / numpy.max(power_raw))
-
-    kernel = oversampling_factor * C.SDE_MEDIAN_KERNEL_SIZE
-    if kernel % 2 == 0:
-        kernel = kernel + 1
-    if len(power_raw) > 2 * kernel:
-        power = power_raw - running_median(power_raw, kernel)
-        power = power - numpy.mean(power)
-        SDE = numpy.max(power / numpy.std(power))
-        power = power * (SDE / numpy.max(power))
-    else:
-        power = power_raw
-        SDE = SDE_raw
-    return SR, power_raw, power, SDE_raw, SDE
 
 
 def final_T0_fit(signal, depth, t, y, dy, period, T0_fit_margin, show_progress_bar, verbose,
