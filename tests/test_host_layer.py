@@ -228,3 +228,40 @@ def test_running_median_fast_path_is_identical():
         front = int(missing * 0.5)
         want = numpy.concatenate([numpy.full(front, med[0]), med, numpy.full(missing - front, med[-1])])
         numpy.testing.assert_array_equal(running_median(data, k), want)
+
+
+def test_transit_model_other_laws_and_eccentric_orbits():
+    """The laws without a closed form (batman: nonlinear, squareroot, logarithmic, exponential, power2)
+    are integrated numerically; with coefficients that reduce them to the quadratic / linear law they
+    must reproduce the closed form (to the 2e-8 of its Hastings polynomials).  Eccentric orbits: the
+    transit stays centred on t0, e -> 0 is the circular orbit, and the template builder accepts them
+    (the reference hands ecc, w, u, limb_dark to batman under transit_template='default',
+    transit.py:14-25)."""
+    from tls_amd import transit_model as tm
+    t = numpy.linspace(-0.3, 0.3, 2001)
+    args = (0.0, 12.9, 0.03, 23.1, 89.21)
+    u1, u2 = 0.4804, 0.1867
+    quad = tm.light_curve(t, *args, 0, 90, [u1, u2], "quadratic")
+    nonl = tm.light_curve(t, *args, 0, 90, [0.0, u1 + 2 * u2, 0.0, -u2], "nonlinear")
+    numpy.testing.assert_allclose(nonl, quad, rtol=0, atol=3e-8)
+    lin = tm.light_curve(t, 0.0, 12.9, 0.1, 23.1, 89.5, 0, 90, [0.5], "linear")
+    for law, u in (("squareroot", [0.5, 0.0]), ("power2", [0.5, 1.0]), ("logarithmic", [0.5, 0.0])):
+        numpy.testing.assert_allclose(tm.light_curve(t, 0.0, 12.9, 0.1, 23.1, 89.5, 0, 90, u, law), lin, rtol=0, atol=3e-8)
+    grazing = tm.light_curve(t, 0.0, 12.9, 0.2, 10.0, 85.0, 0, 90, [0.4, 0.3], "quadratic")
+    numpy.testing.assert_allclose(tm.light_curve(t, 0.0, 12.9, 0.2, 10.0, 85.0, 0, 90, [0.0, 1.0, 0.0, -0.3], "nonlinear"),
+                                  grazing, rtol=0, atol=3e-8)
+    with pytest.raises(ValueError):
+        tm.light_curve(t, *args, 0, 90, [0.1], "nonlinear")
+    # eccentric orbit: deepest point at the conjunction t0, shorter transit near periastron than the circular one
+    ecc = tm.light_curve(t, 0.0, 12.9, 0.1, 23.1, 89.5, 0.3, 90, [0.5], "linear")
+    assert abs(t[numpy.argmin(ecc)]) < 2 * (t[1] - t[0])
+    assert 0 < (ecc < 1).sum() < (lin < 1).sum()
+    numpy.testing.assert_allclose(tm.light_curve(t, 0.0, 12.9, 0.1, 23.1, 89.5, 1e-7, 90, [0.5], "linear"), lin, atol=1e-7)
+    with pytest.raises(ValueError):
+        tm.projected_separation(t, 0.0, 12.9, 23.1, 89.5, 1.2, 90)
+    # through the template builder, as power(limb_dark=..., u=..., ecc=..., w=...) would
+    from tls_amd import synthetic
+    tt, f = synthetic.light_curve(20.0, 24, 2e-4, per=4.0, rp=0.05, a=12)
+    inp = synthetic.search_inputs(tt, f, period_min=3.0, period_max=5.0, limb_dark="nonlinear", u=[0.1, 0.5, 0.1, -0.1],
+                                  ecc=0.2, w=60)
+    assert inp["table"].n_rows > 3 and numpy.all(numpy.isfinite(inp["table"].values))

@@ -5,6 +5,7 @@ raised as RuntimeError with the library's message.  No torch, no fallback: if th
 shared library is missing, or no GPU is usable, the error surfaces here.
 """
 import ctypes
+import hashlib
 import os
 
 import numpy
@@ -135,6 +136,11 @@ def load():
     return lib
 
 
+def _digest(a):
+    """128-bit content digest of an array: the key under which a prepared device plan is reused."""
+    return hashlib.blake2b(memoryview(numpy.ascontiguousarray(a)).cast("B"), digest_size=16).digest()
+
+
 def _f8(a):
     return numpy.ascontiguousarray(a, dtype=numpy.float64)
 
@@ -204,9 +210,10 @@ class Context(object):
         (a survey, or repeated power() calls) reuse the prepared plan: only the flux and the
         weights are replaced (tls_update_flux), the host planning and the uploads are skipped."""
         t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)
-        key = (len(t), hash(t.tobytes()), len(periods), hash(periods.tobytes()),
-               hash(_f8(table.values).tobytes()), hash(_i8(table.width).tobytes()),
-               hash(_f8(table.overshoot).tobytes()), tuple(sorted((k, float(v)) for k, v in params.items())),
+        key = (len(t), _digest(t), len(periods), _digest(periods),
+               _digest(_f8(table.values)), _digest(_i8(table.offset)), _digest(_i8(table.length)),
+               _digest(_i8(table.width)), _digest(_f8(table.overshoot)),
+               tuple(sorted((k, float(v)) for k, v in params.items())),
                os.environ.get("TLS_PRUNE"), os.environ.get("TLS_PRUNE_MIN_LIVE"), os.environ.get("TLS_SORT2"),
                os.environ.get("TLS_SORT3"))
         reused = False
@@ -214,7 +221,11 @@ class Context(object):
             try:
                 self.update_flux(y, dy)
                 reused = True
-            except RuntimeError:     # e.g. uniform dy after per-point dy: the plan differs after all
+            except RuntimeError as exc:
+                # uniform dy after per-point dy (or the reverse): the prepared plan differs after all.
+                # Anything else (a HIP error) is not ours to swallow.
+                if "weight structure" not in str(exc):
+                    raise
                 reused = False
         if not reused:
             self.prepare(t, y, dy, periods, table, params)

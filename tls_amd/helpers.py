@@ -71,15 +71,21 @@ def running_mean_equal_length(data, width_signal):
 def running_median(data, kernel):
     """Sliding median of width `kernel`, padded to len(data)
     (reference helpers.py:93-108).  For odd kernels the median is an element of the
-    window, so scipy's rank filter returns the identical values ~40x faster; even
-    kernels (mean of the two middle elements) keep the numpy formulation."""
+    window, so scipy's rank filter (when scipy is installed; it is optional) returns the
+    identical values ~40x faster; otherwise, and for even kernels (mean of the two middle
+    elements), the numpy formulation.  A non-integer kernel counts as the reference's
+    numpy.arange(kernel) does: rounded up."""
     data = numpy.asarray(data, dtype=float)
-    kernel = int(kernel)
+    kernel = int(numpy.ceil(kernel))
+    med = None
     if kernel % 2 == 1 and 1 < kernel <= len(data):
-        from scipy import ndimage
-        half = kernel // 2
-        med = ndimage.median_filter(data, size=kernel, mode="nearest")[half: len(data) - half]
-    else:
+        try:
+            from scipy import ndimage
+            half = kernel // 2
+            med = ndimage.median_filter(data, size=kernel, mode="nearest")[half: len(data) - half]
+        except ImportError:
+            med = None
+    if med is None:
         windows = numpy.lib.stride_tricks.sliding_window_view(data, kernel)
         med = numpy.median(windows, axis=1)
     return _pad_to(med, len(data))
