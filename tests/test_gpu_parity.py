@@ -619,6 +619,31 @@ def test_both_slab_sort_paths_vs_oracle(gpu, oracle_lib, monkeypatch, name, stri
     assert got[3]["inner_steps"] == int(want[3][2])
 
 
+@pytest.mark.parametrize("per_point", [False, True])
+def test_quarter_million_points_vs_oracle(gpu, oracle_lib, per_point):
+    """N = 250 560 (174 d at 1-min cadence): the widest trial windows (30 068 samples) are longer than an LDS
+    tile can hold, so those rows are evaluated straight from the HBM slab ("oversize" rows) while the
+    others go through the LDS tiles.  The reference has no size limit (core.py:96-188)."""
+    t, f = synthetic.light_curve(174.0, 1440, 3e-4, per=7.77, rp=0.03, a=15)
+    dy = None
+    if per_point:
+        dy = numpy.random.RandomState(4).uniform(0.7, 1.5, len(f)) * 3e-4
+    inp = synthetic.search_inputs(t, f, dy)
+    assert len(inp["t"]) == 250560 and int(inp["table"].width.max()) > 30000
+    periods = inp["periods"]
+    near = numpy.argsort(numpy.abs(periods - 7.77))[:6]
+    sel = numpy.unique(numpy.concatenate([numpy.arange(0, len(periods), 450), near, [len(periods) - 1]]))
+    got = gpu.search(inp["t"], inp["y"], inp["dy"], periods[sel], inp["table"], inp["params"], count_work=True)
+    assert not gpu.plan_info()["resident"]
+    want = oracle_search(oracle_lib, inp, periods=periods[sel])
+    assert_parity(got, want, len(inp["t"]))
+    assert got[3]["grid_cells"] == int(want[3][0])
+    assert got[3]["evaluated_cells"] == int(want[3][1])
+    assert got[3]["inner_steps"] == int(want[3][2])
+    assert got[0].min() < len(inp["t"]) - 100          # the injected planet is found
+    assert abs(periods[sel][int(numpy.argmin(got[0]))] - 7.77) < 0.02
+
+
 @pytest.mark.parametrize("name,stride", [("tess_27d", 60), ("kepler_4yr", 9000)])
 def test_large_series_with_per_point_weights(gpu, oracle_lib, name, stride):
     """Tiled (non-resident) variant with per-point dy: e*w and w staged per tile; for the

@@ -208,6 +208,7 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
             we.xth = xth < 1 ? 1 : xth;
         }
         we.tiled = tlsdev::row_is_tiled(we.width, we.xth) ? 1 : 0;
+        we.oversize = 0; we.pad_ = 0;
         // rows are stored zero padded (pad_front before, pad_back after, then up to a multiple
         // of 8 doubles) so that the unrolled dot product needs no edge handling; the pads grow
         // with the stride of a tiled row (its kR windows reach (kR-1)*xth samples further)
@@ -530,8 +531,29 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // sort histogram: one bucket per point while the counters fit the LDS (fewer points per
         // bucket = fewer comparisons in the in-bucket ranking)
         ctx->nb = (int)std::min<int64_t>(n, (int64_t)((kLdsPerCU - hdr) / 4));
-        const size_t halo = (size_t)W + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
+        size_t halo = (size_t)W + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
         const size_t unit = (size_t)tlsdev::kR * tlsdev::kWave;  // tile bounds: multiples of 320
+        {
+            // Very long series (N beyond ~150 k with the default duration grid): the widest windows are longer
+            // than an LDS tile.  Rows wider than half the tile capacity are marked `oversize`: their (few,
+            // widely strided) trial positions are listed and evaluated straight from the slab, one window per
+            // wavefront, and the tile halo only has to cover the other rows.  The reference has no size
+            // limit (core.py:96-188).
+            const size_t cap1 = (kLdsPerCU - hdr) / 8 / ((uniform ? 1 : 2));
+            if (cap1 < halo + 4 * unit) {
+                const size_t halo_cap = cap1 / 2;
+                size_t widest_fit = 1;
+                int stride_fit = 1;
+                for (auto& we : widths) {
+                    const size_t need = (size_t)we.width + (size_t)(tlsdev::kR - 1) * (size_t)std::max(we.tiled ? we.xth : 1, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
+                    if (need > halo_cap) { we.oversize = 1; we.tiled = 0; we.prunable = 0; }
+                    else { widest_fit = std::max(widest_fit, (size_t)we.width); if (we.tiled) stride_fit = std::max(stride_fit, we.xth); }
+                }
+                widest_stride = stride_fit;
+                ctx->region_pad = tlsdev::region_pad_for(widest_stride);
+                halo = widest_fit + (widest_fit & 1) + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
+            }
+        }
         // staged per tile: e (or e*w), w for per-point weights, and the prefix sum C beside them only
         // if that costs no extra tiles.  Otherwise C takes the samples' place for the predicate pass
         // and the samples follow for the dot products: two stagings per tile, but fewer and larger

@@ -285,6 +285,8 @@ struct WidthEntry {
     double inv_d;     // 1/d
     int tiled;        // row_is_tiled(width, xth)
     int prunable;     // cell_bound() is valid for this row (q_len == width, k_mono >= 0, depth_min >= 0)
+    int oversize;     // slab variant: the window is wider than an LDS tile can hold -- predicate and dot
+    int pad_;         //   product of this row read the slab directly (very long series, N beyond ~150 k)
     double var_q;     // sum_j (q_j - mean q)^2
     double k_mono;    // sum_j q_j - overshoot * sum_j q_j^2
     double c_proxy;   // 4 * overshoot * k_mono: c_proxy * mean^2 ranks the cells of all rows by promise
@@ -999,6 +1001,7 @@ struct Cumsum2Scratch {
 };
 static_assert(sizeof(Cumsum2Scratch) <= kCumsumScratchBytes, "cumsum scratch does not fit its slot");
 static_assert(kMaxSpecial <= kWave && kMaxWaves <= kWave, "the tables are held one entry per lane");
+static_assert(128 <= 2 * kWave, "the bin scan of the slab sort holds two bins per lane");
 
 //     C[k0] = s0,  C[k+1] = fl(C[k] + f[k])  for k in [k0, kb),   kb - k0 <= blockDim.x * PER.
 // Thread T owns `per` <= PER consecutive elements (slots past its range hold 0.0).
@@ -1748,7 +1751,7 @@ constexpr int kSort3BinCap = 4096;      // points one coarse phase bin may hold
 constexpr int kSort3BinMean = 3072;     // target points per coarse bin
 constexpr int kSort3Fine = 2048;        // fine buckets of the per-bin LDS sort
 constexpr int kSort3Chunk = 16384;      // points partitioned per pass-1 round
-constexpr int kSort3MaxBins = 64;
+constexpr int kSort3MaxBins = 128;
 __host__ __device__ constexpr int sort3_bins(int n) {
     return (n + kSort3BinMean - 1) / kSort3BinMean < 1 ? 1 : (n + kSort3BinMean - 1) / kSort3BinMean;
 }
@@ -1873,8 +1876,9 @@ __device__ __forceinline__ bool fold_sort_cumsum_tiled(const double* t, const do
                 rank[e] = tid + e * nt < cn ? atomicAdd(&l_cnt[bin], 1u) : 0u;
             }
             lds_barrier();
-            if (tid < kWave) {   // exclusive scan over the bins (B <= 64: one lane each) and the capacity test
-                const unsigned int c = tid < B ? l_cnt[tid] : 0u;
+            if (tid < kWave) {   // exclusive scan over the bins (B <= 128: two per lane) and the capacity test
+                const unsigned int c0b = 2 * tid < B ? l_cnt[2 * tid] : 0u, c1b = 2 * tid + 1 < B ? l_cnt[2 * tid + 1] : 0u;
+                const unsigned int c = c0b + c1b;
                 unsigned int incl = c;
                 incl += (unsigned int)dpp_i32<kDppRowShr1, 0xF>((int)incl);
                 incl += (unsigned int)dpp_i32<kDppRowShr2, 0xF>((int)incl);
@@ -1882,9 +1886,13 @@ __device__ __forceinline__ bool fold_sort_cumsum_tiled(const double* t, const do
                 incl += (unsigned int)dpp_i32<kDppRowShr8, 0xF>((int)incl);
                 incl += (unsigned int)dpp_i32<kDppBcast15, 0xA>((int)incl);
                 incl += (unsigned int)dpp_i32<kDppBcast31, 0xC>((int)incl);
-                if (tid < B) {
-                    l_start[tid] = incl - c;
-                    if (g_cnt[tid] + c > (unsigned int)kSort3BinCap) flags[0] = 1u;
+                if (2 * tid < B) {
+                    l_start[2 * tid] = incl - c;
+                    if (g_cnt[2 * tid] + c0b > (unsigned int)kSort3BinCap) flags[0] = 1u;
+                }
+                if (2 * tid + 1 < B) {
+                    l_start[2 * tid + 1] = incl - c + c0b;
+                    if (g_cnt[2 * tid + 1] + c1b > (unsigned int)kSort3BinCap) flags[0] = 1u;
                 }
             }
             lds_barrier();
@@ -2450,6 +2458,10 @@ tls_search_kernel(const SearchArgs a) {
             // the row belongs to this wave alone: its list tail is a register, not an LDS atomic
             unsigned int n_listed = 0;
             const unsigned long long below = (1ull << lane) - 1ull;
+            // a window wider than an LDS tile: the row is listed once (with the first tile), from the slab
+            const bool oversize = !RESIDENT && widths_c[k].oversize != 0;
+            const double* c_row = oversize ? regB : c_base;
+            if (oversize && p_lo != 0) continue;
             if (widths_c[k].tiled) {
                 const int span = kR * xth;  // samples between the first windows of two units
                 const int unit_lo = (p_lo + span - 1) / span;
@@ -2473,14 +2485,14 @@ tls_search_kernel(const SearchArgs a) {
                     n_listed += (unsigned int)__popcll(mask);
                 }
             } else {
-                const int unit_lo = (p_lo + xth - 1) / xth;
-                const int unit_hi = (p_hi + xth - 1) / xth < n_pos ? (p_hi + xth - 1) / xth : n_pos;
+                const int unit_lo = oversize ? 0 : (p_lo + xth - 1) / xth;
+                const int unit_hi = oversize ? n_pos : ((p_hi + xth - 1) / xth < n_pos ? (p_hi + xth - 1) / xth : n_pos);
                 for (int tile = 0; unit_lo + tile * kWave < unit_hi; ++tile) {
                     const int unit = unit_lo + tile * kWave + lane;
                     bool live = false;
                     if (unit < unit_hi) {
                         const int i = unit * xth;
-                        const double dC = c_base[i + d] - c_base[i];
+                        const double dC = c_row[i + d] - c_row[i];
                         const int cls = depth_class(dC, inv_d, dmin);
                         live = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
                     }
@@ -2605,7 +2617,8 @@ tls_search_kernel(const SearchArgs a) {
 #pragma unroll
                     for (int j = 0; j < kGroups; ++j) {
                         const int b = unit[j] * step;
-                        double dC_min = c_base[b + d] - c_base[b], dC_max = dC_min;
+                        const double* c_row = (!RESIDENT && widths_c[k].oversize) ? regB : c_base;
+                        double dC_min = c_row[b + d] - c_row[b], dC_max = dC_min;
                         if (tiled) {
 #pragma unroll
                             for (int r = 1; r < kR; ++r) {
@@ -2858,6 +2871,39 @@ tls_search_kernel(const SearchArgs a) {
                     }
                 } else {
                     // wide T0 strides and re-listed sparse rows: one window per lane
+                    if (!RESIDENT && widths_c[k].oversize) {
+                        // the window does not fit an LDS tile: the wave takes the batch's windows one after
+                        // the other, lanes over the template taps, samples straight from the slab
+                        // (e = 1 - f with the patch mapping of stage_samples)
+                        const double* qg = a.q + q_offset;
+                        const double* q2g = UNIFORM_W ? nullptr : a.q2 + q_offset;
+                        const unsigned long long have_mask = __ballot(have);
+                        double myB = 0.0, myA = sum_q2;
+                        for (int s2 = 0; s2 < kWave; ++s2) {
+                            if (!((have_mask >> s2) & 1ull)) continue;
+                            const int iu = lane_value(unit, s2) * xth;
+                            double Bs = 0.0, As = 0.0;
+                            for (int tt = lane; tt < L; tt += kWave) {
+                                const int pp = iu + tt, src = pp < n ? pp : pp - n;
+                                double ev = 1.0 - regA[src];
+                                if constexpr (!UNIFORM_W) { const double ww = regW[src]; As = fma(q2g[tt], ww, As); ev *= ww; }
+                                Bs = fma(qg[tt], ev, Bs);
+                            }
+#pragma unroll
+                            for (int delta = kWave / 2; delta > 0; delta >>= 1) {
+                                Bs += __shfl_down(Bs, delta, kWave);
+                                if constexpr (!UNIFORM_W) As += __shfl_down(As, delta, kWave);
+                            }
+                            const double Bt = lane_value(Bs, 0), At = lane_value(As, 0);
+                            if (lane == s2) { myB = Bt; if constexpr (!UNIFORM_W) myA = At; }
+                        }
+                        if (have) {
+                            const int i = unit * xth;
+                            consider(best, regB[i], regB[i + d], i, inv_d, dd, dmin, overshoot, myA, myB, k, n_eval);
+                        }
+                        n_steps += (n_eval - evals_before) * (unsigned long long)L;
+                        continue;
+                    }
                     const int i = unit * xth;
                     TLS_CHECK(a, !have || (i >= p_lo && i + (L + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + a.tile_len + a.tile_halo)), kChkDotWindow);
                     const double* e = e_base + i;
