@@ -591,11 +591,12 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // one light curve per launch: partition into large phase bins, per-bin LDS sort fused with the prefix sum
         const size_t sort3_bytes = hdr + (size_t)tlsdev::sort3_lds_bytes();
         const char* env_sort3 = std::getenv("TLS_SORT3");
-        // (measured: it moves 15 % fewer HBM bytes than the two-level sort at the same kernel time for the
-        // Kepler-size series, but is 15 % slower for the TESS-size one: the default follows the size,
-        // TLS_SORT3=0/1 forces either)
+        // (measured on the Kepler-size series: 15 % fewer HBM bytes than the two-level sort -- 6.3 vs 7.4 MB per
+        // period -- but 12 % more kernel time, its 23 bin rounds of eleven barriers each cost more than the
+        // gather they avoid; on the TESS-size series 15 % slower.  The two-level sort stays the default,
+        // TLS_SORT3=1 selects this path; both are tested.)
         ctx->sort3 = sort3_bytes <= kLdsPerCU && tlsdev::sort3_bins((int)n) <= tlsdev::kSort3MaxBins && (int64_t)W <= n &&
-                     (env_sort3 ? std::atoi(env_sort3) != 0 : n >= 32768);
+                     (env_sort3 ? std::atoi(env_sort3) != 0 : false);
         if (ctx->sort3) {
             ctx->lds_bytes = std::max(ctx->lds_bytes, sort3_bytes);
             TLS_HIP(ctx, ctx->d_sort3.reserve((size_t)ctx->blocks * (size_t)tlsdev::sort3_scratch_doubles((int)n)));

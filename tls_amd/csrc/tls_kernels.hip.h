@@ -2288,7 +2288,7 @@ tls_search_kernel(const SearchArgs a) {
                 copy_in_flight4(f_l, regA + c0, len);
                 __syncthreads();
 #if TLS_CUMSUM2
-                exact_cumsum<false>(f_l, c_l, len, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles, carry);
+                exact_cumsum<false, true, true>(f_l, c_l, len, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles, carry);
 #else
                 exact_sequential_cumsum(f_l, c_l, len, cumsum_scratch, a.phase_cycles, carry);
 #endif
