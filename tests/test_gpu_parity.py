@@ -590,6 +590,8 @@ def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
         except ValueError:
             continue  # degenerate template table for this size (the reference raises too)
         sel = inp["periods"][:: max(1, len(inp["periods"]) // 150)]
+        if os.environ.get("TLS_FUZZ_VERBOSE"):
+            print("fuzz", seed, case, len(t), dy is not None, kwargs, int(inp["table"].width.max()), flush=True)
         got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
         want = oracle_search(oracle_lib, inp, periods=sel)
         assert_parity(got, want, len(inp["t"]), allow_tie=True)

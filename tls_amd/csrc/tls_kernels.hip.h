@@ -2459,8 +2459,9 @@ tls_search_kernel(const SearchArgs a) {
             unsigned int n_listed = 0;
             const unsigned long long below = (1ull << lane) - 1ull;
             // a window wider than an LDS tile: the row is listed once (with the first tile), from the slab
+            // (two separate loads below, never a pointer select: c_base is an LDS pointer biased by -p_lo, and a
+            // select with a global pointer would turn it into a flat address outside the LDS aperture)
             const bool oversize = !RESIDENT && widths_c[k].oversize != 0;
-            const double* c_row = oversize ? regB : c_base;
             if (oversize && p_lo != 0) continue;
             if (widths_c[k].tiled) {
                 const int span = kR * xth;  // samples between the first windows of two units
@@ -2492,7 +2493,9 @@ tls_search_kernel(const SearchArgs a) {
                     bool live = false;
                     if (unit < unit_hi) {
                         const int i = unit * xth;
-                        const double dC = c_row[i + d] - c_row[i];
+                        double dC;
+                        if (oversize) dC = regB[i + d] - regB[i];
+                        else dC = c_base[i + d] - c_base[i];
                         const int cls = depth_class(dC, inv_d, dmin);
                         live = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
                     }
@@ -2617,8 +2620,10 @@ tls_search_kernel(const SearchArgs a) {
 #pragma unroll
                     for (int j = 0; j < kGroups; ++j) {
                         const int b = unit[j] * step;
-                        const double* c_row = (!RESIDENT && widths_c[k].oversize) ? regB : c_base;
-                        double dC_min = c_row[b + d] - c_row[b], dC_max = dC_min;
+                        double dC_min, dC_max;
+                        if (!RESIDENT && widths_c[k].oversize) dC_min = regB[b + d] - regB[b];   // (no pointer select, see phase 3a)
+                        else dC_min = c_base[b + d] - c_base[b];
+                        dC_max = dC_min;
                         if (tiled) {
 #pragma unroll
                             for (int r = 1; r < kR; ++r) {
