@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): rocprofv3 kernel trace + HBM counter passes of bench.py.
 # Outputs land in gpurun_out/prof_$TAG/; tools/summarize_profile.py turns them into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -1,17 +1,23 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): HBM traffic of the Kepler-size configuration (BASELINE config 3),
-# a spread sample of its periods.  Separate --pmc passes, kernel trace for the duration.
+# a spread sample of its periods, for the default slab sort and for the fused one (TLS_SORT3=1).
+# Separate --pmc passes, kernel trace for the duration.  Writes gpurun_out/prof_kepler_<tag>.json.
 set -u
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_kepler
-mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/tools/gpu_kepler_time.py 64"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- $CMD > "$OUT/trace.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o k -- $CMD > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o k -- $CMD > "$OUT/write.log" 2>&1
-python - <<PY
-import csv, glob
+echo "[" > $ROOT/gpurun_out/prof_kepler_$TAG.json
+SEP=""
+for VAR in default sort3; do
+  OUT=$ROOT/gpurun_out/prof_kepler_${TAG}_$VAR
+  mkdir -p "$OUT"
+  if [ $VAR = sort3 ]; then export TLS_SORT3=1; else unset TLS_SORT3; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- $CMD > "$OUT/trace.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o k -- $CMD > "$OUT/fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o k -- $CMD > "$OUT/write.log" 2>&1
+  python - <<PY >> $ROOT/gpurun_out/prof_kepler_$TAG.json
+import csv, glob, json
 def mean(path, name):
     v = [float(r["Counter_Value"]) for f in glob.glob(path) for r in csv.DictReader(open(f))
          if "tls_search" in r["Kernel_Name"] and r["Counter_Name"] == name]
@@ -19,8 +25,15 @@ def mean(path, name):
 f, nf = mean("$OUT/fetch/*counter_collection.csv", "FETCH_SIZE")
 w, nw = mean("$OUT/write/*counter_collection.csv", "WRITE_SIZE")
 dur = [float(r["AverageNs"]) for f2 in glob.glob("$OUT/trace/*kernel_stats.csv") for r in csv.DictReader(open(f2)) if "tls_search" in r["Name"]]
-print("launches", nf, nw, "FETCH_SIZE KiB", f, "WRITE_SIZE KiB", w, "kernel avg ns", dur)
-if dur:
-    bytes_ = (2 * f + w) * 1024   # gfx950: FETCH_SIZE counts 64 B per 128 B request (MI355X_MICROARCH.md)
-    print("HBM bytes per launch %.3e -> %.1f GB/s" % (bytes_, bytes_ / (dur[0] * 1e-9) / 1e9))
+n_periods = 2850
+algo = n_periods * (24 * 70128 + 24)
+b = (2 * f + w) * 1024   # gfx950: FETCH_SIZE counts 64 B per 128 B request (MI355X_MICROARCH.md)
+print("$SEP" + json.dumps({"name": "$VAR", "n_periods": n_periods, "fetch_kib": f, "write_kib": w, "launches": [nf, nw],
+      "kernel_ms": dur[0] * 1e-6 if dur else None, "bytes_per_launch": b, "bytes_per_period": b / n_periods,
+      "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": b / algo,
+      "hbm_GBps": b / (dur[0] * 1e-9) / 1e9 if dur else None}))
 PY
+  SEP=","
+done
+echo "]" >> $ROOT/gpurun_out/prof_kepler_$TAG.json
+cat $ROOT/gpurun_out/prof_kepler_$TAG.json

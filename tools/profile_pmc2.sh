@@ -1,7 +1,7 @@
 #!/bin/bash
 # Second-level PMC passes for the search kernel (issue/stall mix); run via gpurun.
 set -u
-TAG=${1:-r01b}
+TAG=${1:-r02b}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

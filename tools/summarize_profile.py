@@ -42,14 +42,36 @@ with open(os.path.join(dst, "%s_k2_90d_pmc_summary.csv" % tag), "w") as fh:
         m = means[k]
         fh.write("%s,%d,%.6g,%.6g,%.6g\n" % (k, m["launches"], m["mean"], m["min"], m["max"]))
 
+def update_traffic_record(rec):
+    """profiles/hbm_traffic.json keeps one record per configuration, labelled with the commit it was measured at."""
+    path = os.path.join(dst, "hbm_traffic.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    recs = [r for r in doc.get("records", []) if r.get("config") != rec["config"]]
+    recs.append(rec)
+    doc["records"] = recs
+    doc.setdefault("note", "read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128 B request); "
+                           "separate --pmc passes; bench.py labels roofline.traffic with the commit of the record")
+    json.dump(doc, open(path, "w"), indent=1)
+
+
+commit = os.environ.get("TLS_COMMIT", "unknown")
 if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
     fetch_kib, write_kib = means["FETCH_SIZE"]["mean"], means["WRITE_SIZE"]["mean"]
-    rec = {"config": "k2_90d", "n_periods": 9679, "tag": tag,
+    rec = {"config": "k2_90d", "n_periods": 9679, "commit": commit,
+           "source": "FETCH_SIZE x2 + WRITE_SIZE, profiles/%s_k2_90d_pmc_summary.csv" % tag,
            "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
-           "bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
-           "bytes_per_launch_uncorrected": (fetch_kib + write_kib) * 1024.0,
-           "note": "read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per "
-                   "128 B request); separate --pmc passes of `bench.py --steps 20`"}
-    json.dump(rec, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+           "bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0}
+    update_traffic_record(rec)
     print(rec)
+kep = os.path.join(root, "gpurun_out", "prof_kepler_" + tag + ".json")
+if os.path.exists(kep):
+    k = json.load(open(kep))
+    for variant in k:
+        rec = {"config": "kepler_4yr" if variant["name"] == "default" else "kepler_4yr/" + variant["name"], "n_periods": variant["n_periods"],
+               "commit": commit, "source": "FETCH_SIZE x2 + WRITE_SIZE, profiles/%s_kepler_hbm_traffic.json (every 64th period)" % tag,
+               "fetch_size_kib_raw": variant["fetch_kib"], "write_size_kib_raw": variant["write_kib"],
+               "bytes_per_launch": (2.0 * variant["fetch_kib"] + variant["write_kib"]) * 1024.0, "kernel_avg_ms": variant["kernel_ms"]}
+        update_traffic_record(rec)
+    json.dump(k, open(os.path.join(dst, "%s_kepler_hbm_traffic.json" % tag), "w"), indent=1)
+    print(k)
 print(open(os.path.join(dst, "%s_k2_90d_kernel_stats.csv" % tag)).read())
