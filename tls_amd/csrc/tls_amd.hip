@@ -523,6 +523,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         ctx->lds_bytes = resident_bytes;
         const size_t per_cu = kLdsPerCU / resident_bytes;
         ctx->threads = per_cu >= 2 ? 512 : 1024;
+        if (const char* env = std::getenv("TLS_THREADS")) ctx->threads = std::max(64, std::min(1024, std::atoi(env) / 64 * 64));   // developer switch
         const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)ctx->threads);
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)wg_per_cu * ctx->n_cu);
     } else {

@@ -1557,7 +1557,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                     rank[e] = atomicAdd(&l_cnt[bin[e]], 1u);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (wave == 0) {   // chunk-local exclusive scan; reserve the bins' output segments
                 const int per = (B + kWave - 1) / kWave;
                 const int lo = lane * per < B ? lane * per : B, hi = lo + per < B ? lo + per : B;
@@ -1572,7 +1572,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 unsigned int run = incl - local;
                 for (int b = lo; b < hi; ++b) { l_start[b] = run; run += l_cnt[b]; }
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int e = 0; e < kPer; ++e) {
                 if (bin[e] >= 0) {
@@ -1582,7 +1582,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                     st_bin[s] = (unsigned short)bin[e];
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // every bin's points of this chunk leave as one contiguous segment
             for (int sidx = tid; sidx < cn; sidx += nt) {
                 const int b = st_bin[sidx];
@@ -1590,11 +1590,12 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 g_ph[dst] = st_ph[sidx];
                 g_idx[dst] = st_idx[sidx];
             }
-            __syncthreads();
+            lds_barrier();
             for (int b = tid; b < B; b += nt) { g_cur[b] += l_cnt[b]; l_cnt[b] = 0; }
-            __syncthreads();
+            lds_barrier();
         }
     }
+    __syncthreads();   // (the barriers inside the rounds order LDS only: the partitioned points are in memory HERE)
     pc.mark(2);
 
     // ---- pass 2: one coarse bin per wavefront, sorted inside its LDS window -----------------------
