@@ -300,12 +300,13 @@ class Context(object):
     def phase_cycles(self):
         """Developer instrumentation: per-phase shader-cycle sums of the last
         execute(phase_clock=True)."""
-        arr = (ctypes.c_uint64 * 26)()
-        self._check(self._lib.tls_debug_phase_cycles(self._h, arr, 26))
+        arr = (ctypes.c_uint64 * 32)()
+        self._check(self._lib.tls_debug_phase_cycles(self._h, arr, 32))
         names = ("fold_count", "scan", "scatter", "rank", "gather_patch", "cumsum", "batch_prefix",
                  "chi2", "e_convert", "predicate_strided", "cumsum_blocks", "cumsum_fallbacks",
                  "tile_staging", "predicate_dense", "cs_A", "cs_B1", "cs_B2", "cs_scan", "cs_D", "cs_E",
-                 "tile_wait", "chi2_wait", "prune_e2", "prune_bounds", "prune_incumbent", "select_relist")
+                 "tile_wait", "chi2_wait", "prune_e2", "prune_bounds", "prune_incumbent", "select_relist",
+                 "slab_copy_in", "slab_copy_out", "part_fold", "part_scan", "part_lds", "part_store")
         return dict(zip(names, [int(v) for v in arr]))
 
     def check_counts(self):

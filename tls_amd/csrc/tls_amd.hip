@@ -341,7 +341,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
 #endif
     a.queue = ctx->d_squeue.ptr;
     a.scratch = ctx->d_scratch.ptr;
-    a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * (ctx->M + 1 + ctx->region_pad);
+    a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * ((ctx->M + 1 + ctx->region_pad + 1) & ~1);   // even regions (kernel: RS)
     a.region_pad = ctx->region_pad;
     a.chunk_lists = ctx->d_lists.ptr; a.list_stride = 2 * (long long)ctx->list_stride; a.list_cap = (long long)ctx->list_stride;
     a.prune_min_live = ctx->prune_min_live; a.p2_shift = ctx->p2_shift; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
@@ -577,10 +577,34 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         size_t tile = (((size_t)M + n_tiles - 1) / n_tiles + unit - 1) / unit * unit;
         if (tile > cap_tile) tile = cap_tile;
         ctx->tile_len = (int)tile; ctx->tile_halo = (int)halo;
-        const size_t cumsum_bytes = 8 * (2 * (size_t)tlsdev::kCumsumChunk + 2);
+        // Per period the halo only has to cover the widest IN-RANGE window (core.py:148-156): long periods try
+        // narrow windows only, so their tiles can be longer (fewer tiles, less of the slab staged twice).  The
+        // LDS tile stays `tile + halo` doubles; PeriodRows::pad carries the period's own tile length.
+        {
+            const size_t staged = tile + halo;
+            for (int64_t p = 0; p < n_periods; ++p) {
+                tlsdev::PeriodRows& pr = prow[(size_t)p];
+                size_t wmax = 1; int stride_p = 1;
+                for (int k = pr.k_lo; k < pr.k_hi; ++k) {
+                    const auto& we = widths[(size_t)k];
+                    if (we.oversize) continue;
+                    wmax = std::max(wmax, (size_t)we.width);
+                    if (we.tiled) stride_p = std::max(stride_p, we.xth);
+                }
+                const size_t halo_p = wmax + (wmax & 1) + (size_t)(tlsdev::kR - 1) * (size_t)std::max(stride_p, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
+                if (halo_p >= halo) continue;   // (pad 0: the plan's tile length)
+                const size_t cap_p = (staged - halo_p) / unit * unit;
+                const size_t tiles_p = ((size_t)M + cap_p - 1) / cap_p;
+                size_t tile_p = (((size_t)M + tiles_p - 1) / tiles_p + unit - 1) / unit * unit;
+                if (tile_p > cap_p) tile_p = cap_p;
+                if (tile_p > tile) pr.pad = (int)tile_p;
+            }
+        }
+        const size_t cumsum_bytes = 8 * (2 * (size_t)tlsdev::kCumsumChunk + 4);
         ctx->lds_bytes = hdr + std::max<size_t>(std::max<size_t>(4 * (size_t)ctx->nb, cumsum_bytes),
                                                 buffers * 8 * (tile + halo));
         ctx->threads = 1024;
+        if (const char* env = std::getenv("TLS_THREADS")) ctx->threads = std::max(64, std::min(1024, std::atoi(env) / 64 * 64));   // developer switch
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)ctx->n_cu);
         if (const char* env = std::getenv("TLS_BLOCKS"))   // developer switch: workgroups in flight (memory-system experiments)
             ctx->blocks = std::max(1, std::min(ctx->blocks, std::atoi(env)));
@@ -602,7 +626,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             ctx->lds_bytes = std::max(ctx->lds_bytes, sort3_bytes);
             TLS_HIP(ctx, ctx->d_sort3.reserve((size_t)ctx->blocks * (size_t)tlsdev::sort3_scratch_doubles((int)n)));
         }
-        TLS_HIP(ctx, ctx->d_scratch.reserve((size_t)ctx->blocks * regions * region_doubles));
+        TLS_HIP(ctx, ctx->d_scratch.reserve((size_t)ctx->blocks * regions * (region_doubles + 1) + 16));
     }
     // per-width work units of phase 3 (M is fixed for the plan, so these are period independent)
     // and the layout of one workgroup's live-unit lists: every unit of every width has a slot

@@ -57,6 +57,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef TLS_LAUNCH_THREADS
+#define TLS_LAUNCH_THREADS 1024   // developer builds: 512 doubles the register budget (launch with TLS_THREADS=512)
+#endif
 #ifndef TLS_WAVES_PER_EU
 #define TLS_WAVES_PER_EU 4
 #endif
@@ -87,7 +90,7 @@ enum CheckCode {
 
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
-constexpr int kPhases = 26;    // phase-clock slots (tls_amd/_lib.py names them)
+constexpr int kPhases = 32;    // phase-clock slots (tls_amd/_lib.py names them)
 #ifndef TLS_KR
 #define TLS_KR 5
 #endif
@@ -207,10 +210,43 @@ __device__ __forceinline__ void vmem_wait_all() {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt untouched (gfx9 encoding)
 }
 
+#ifndef TLS_SLAB_DMA
+#define TLS_SLAB_DMA 1
+#endif
+// Slab -> LDS without registers: `count` doubles (rounded up to a pair) travel by global_load_lds_dwordx4, 1 KiB
+// per wave-instruction, all of them in flight together -- a copy through registers keeps 32-64 B per thread
+// in flight, which at ~1.5 us of loaded HBM latency is the ~10 B/cycle a workgroup was seen to move.  Element k
+// of the destination is src[p < n ? p : p - n], p = p0 + k (the patch mapping of core.py:126; n = INT_MAX for a
+// plain copy).  p0 and n even, dst and src 16-byte aligned.  The data is in LDS behind vmem_wait_all() + a
+// barrier.  (Inline assembly: see fold_sort_cumsum_tiled for why not the builtin.)
+__device__ __forceinline__ void slab_to_lds_async(double* dst_lds, const double* src, int p0, int count, int n, int tid) {
+    const int nt = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const unsigned int dst_addr = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) double*)dst_lds;
+    const int pairs = (count + 1) / 2;
+    for (int q0 = 0; q0 < pairs; q0 += nt) {
+        const int q = q0 + tid;
+        const unsigned int dst = (unsigned int)__builtin_amdgcn_readfirstlane((int)(dst_addr + 16u * (unsigned int)(q0 + wave * kWave)));
+        if (q < pairs) {
+            const int p = p0 + 2 * q;
+            const double* g = src + (p < n ? p : p - n);
+            unsigned int m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+#if TLS_NT
+                         " nt"
+#endif
+                         "\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "v"(g), "s"(dst) : "memory");
+        }
+    }
+}
+
 // dst[k] = src[k] for k in [0, count), all threads of the workgroup, four global reads in flight per
 // thread (the compiler does not overlap them itself: the store of one may alias the read of the next)
 __device__ __forceinline__ void copy_in_flight4(double* dst, const double* src, int count) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // opaque: see fold_and_sort_tiled
+    const int nt = blockDim.x;
     for (int k = tid; k < count; k += 4 * nt) {
         const int k1 = k + nt, k2 = k + 2 * nt, k3 = k + 3 * nt;
         const double v0 = stream_load(src + k);     // the source is a slab in HBM
@@ -231,7 +267,9 @@ __device__ __forceinline__ void copy_in_flight4(double* dst, const double* src, 
 template <bool UNIFORM_W>
 __device__ __forceinline__ void stage_samples(double* tile_e, double* tile_w, const double* f, const double* w,
                                               int p_lo, int count, int n, int M) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // opaque: see fold_and_sort_tiled
+    const int nt = blockDim.x;
     constexpr int kInFlight = 8;
     for (int k0 = tid; k0 < count; k0 += kInFlight * nt) {
         double fv[kInFlight], wv[kInFlight];
@@ -252,6 +290,27 @@ __device__ __forceinline__ void stage_samples(double* tile_e, double* tile_w, co
                 tile_e[k] = e;
             }
         }
+    }
+}
+
+// The same in two steps without registers: the raw flux (and weights) travel into the tile by LDS-direct loads
+// (stage_samples_async), and once they have landed (vmem_wait_all + barrier) every thread turns its share into
+// e = 1 - f (or e*w), zero from position M on (finish_samples).  n even.
+template <bool UNIFORM_W>
+__device__ __forceinline__ void stage_samples_async(double* tile_e, double* tile_w, const double* f, const double* w,
+                                                    int p_lo, int count, int n, int M, int tid) {
+    const int have = M - p_lo < count ? (M - p_lo > 0 ? M - p_lo : 0) : count;   // positions below M
+    slab_to_lds_async(tile_e, f, p_lo, have, n, tid);
+    if constexpr (!UNIFORM_W) slab_to_lds_async(tile_w, w, p_lo, have, n, tid);
+}
+template <bool UNIFORM_W>
+__device__ __forceinline__ void finish_samples(double* tile_e, double* tile_w, int p_lo, int count, int M, int tid) {
+    const int nt = blockDim.x;
+    for (int k = tid; k < count; k += nt) {
+        const bool ok = p_lo + k < M;
+        double e = ok ? 1.0 - tile_e[k] : 0.0;
+        if constexpr (!UNIFORM_W) { const double ww = ok ? tile_w[k] : 0.0; e *= ww; tile_w[k] = ww; }
+        tile_e[k] = e;
     }
 }
 
@@ -296,7 +355,8 @@ struct WidthEntry {
 // In-range widths of one period (core.py:143-156): the contiguous range [k_lo, k_hi) of the
 // ascending width table; rows below k_x have the dense T0 grid (stride 1).  Host-computed.
 struct PeriodRows {
-    int k_lo, k_hi, k_x, pad;
+    int k_lo, k_hi, k_x;
+    int pad;   // slab variant: tile length of this period (0: SearchArgs::tile_len)
 };
 
 struct SearchArgs {
@@ -916,6 +976,14 @@ __device__ __forceinline__ double dpp_f64(double v) {
 constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
 constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;
 
+// the counter update of the slab sort's partition passes (bin < 0: no point in this lane)
+template <bool WANT_TICKET>
+__device__ __forceinline__ unsigned int bin_inc(unsigned int* cnt, int bin) {
+    // (one atomic per RUN of equal bins in a wave -- time-ordered samples share a coarse bin -- was tried: the
+    // ballot/shuffle bookkeeping costs more than the same-address serialisation it removes)
+    return bin >= 0 ? atomicAdd(&cnt[bin], 1u) : 0u;
+}
+
 // inclusive prefix sum over the 64 lanes (0.0 is what the lanes without a source contribute)
 __device__ __forceinline__ double wave_inclusive_sum(double v) {
     v += dpp_f64<kDppRowShr1, 0xF>(v);
@@ -1486,7 +1554,10 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                                                     PhaseClock& pc, const double* y_gather = nullptr,
                                                     const double* w_gather = nullptr, double* w_out_g = nullptr,
                                                     unsigned long long* dbg_check = nullptr) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // opaque: indices derived from it are formed here, not hoisted out of the
+                                    // period loop and spilled (a spill reload between two loads waits for vmcnt(0))
+    const int nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int B = sort2_bins(n);
@@ -1500,13 +1571,13 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
     // ---- counts per coarse bin ------------------------------------------------------------------
     for (int b = tid; b <= B; b += nt) { g_start[b] = 0; l_cnt[b] = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += 4 * nt) {   // four time stamps in flight per thread
-        const int i1 = i + nt, i2 = i + 2 * nt, i3 = i + 3 * nt;
-        const double t0 = t[i], t1 = i1 < n ? t[i1] : 0.0, t2 = i2 < n ? t[i2] : 0.0, t3 = i3 < n ? t[i3] : 0.0;
-        atomicAdd(&g_start[bucket_of(fold_phase(t0, period, epoch), B_d, B)], 1u);
-        if (i1 < n) atomicAdd(&g_start[bucket_of(fold_phase(t1, period, epoch), B_d, B)], 1u);
-        if (i2 < n) atomicAdd(&g_start[bucket_of(fold_phase(t2, period, epoch), B_d, B)], 1u);
-        if (i3 < n) atomicAdd(&g_start[bucket_of(fold_phase(t3, period, epoch), B_d, B)], 1u);
+    for (int i0 = 0; i0 < n; i0 += 8 * nt) {   // eight time stamps in flight per thread; whole waves take part
+        double tv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tv[j] = i0 + tid + j * nt < n ? t[i0 + tid + j * nt] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            bin_inc<false>(g_start, i0 + tid + j * nt < n ? bucket_of(fold_phase(tv[j], period, epoch), B_d, B) : -1);
     }
     __syncthreads();
     // exclusive scan over the bins by wave 0 (B <= 1024: 16 per lane), and the overflow test
@@ -1550,14 +1621,17 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 #pragma unroll
             for (int e = 0; e < kPer; ++e) {
                 const int k = tid + e * nt;
-                bin[e] = -1;
-                if (k < cn) {
-                    ph[e] = fold_phase(t[c0 + k], period, epoch);
-                    bin[e] = bucket_of(ph[e], B_d, B);
-                    rank[e] = atomicAdd(&l_cnt[bin[e]], 1u);
-                }
+                ph[e] = k < cn ? t[c0 + k] : 0.0;      // the time stamp for now: all reads of the round in flight together
+            }
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) {
+                const int k = tid + e * nt;
+                ph[e] = fold_phase(ph[e], period, epoch);
+                bin[e] = k < cn ? bucket_of(ph[e], B_d, B) : -1;
+                rank[e] = bin_inc<true>(l_cnt, bin[e]);
             }
             lds_barrier();
+            pc.mark(28);
             if (wave == 0) {   // chunk-local exclusive scan; reserve the bins' output segments
                 const int per = (B + kWave - 1) / kWave;
                 const int lo = lane * per < B ? lane * per : B, hi = lo + per < B ? lo + per : B;
@@ -1573,6 +1647,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 for (int b = lo; b < hi; ++b) { l_start[b] = run; run += l_cnt[b]; }
             }
             lds_barrier();
+            pc.mark(29);
 #pragma unroll
             for (int e = 0; e < kPer; ++e) {
                 if (bin[e] >= 0) {
@@ -1583,6 +1658,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 }
             }
             lds_barrier();
+            pc.mark(30);
             // every bin's points of this chunk leave as one contiguous segment
             for (int sidx = tid; sidx < cn; sidx += nt) {
                 const int b = st_bin[sidx];
@@ -1591,6 +1667,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 g_idx[dst] = st_idx[sidx];
             }
             lds_barrier();
+            pc.mark(31);
             for (int b = tid; b < B; b += nt) { g_cur[b] += l_cnt[b]; l_cnt[b] = 0; }
             lds_barrier();
         }
@@ -2114,7 +2191,7 @@ __device__ __forceinline__ bool fold_sort_cumsum_tiled(const double* t, const do
 }
 
 template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false>
-__global__ void __launch_bounds__(1024, TLS_WAVES_PER_EU)
+__global__ void __launch_bounds__(TLS_LAUNCH_THREADS, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -2122,7 +2199,8 @@ tls_search_kernel(const SearchArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform by construction
     const int n = a.n, W = a.W, M = a.M, nb = a.nb;
     const int region_pad = a.region_pad;
-    const int RS = M + 1 + region_pad;  // region stride in doubles
+    // region stride in doubles; even in the slab so that every region starts on a 16-byte boundary
+    const int RS = RESIDENT ? M + 1 + region_pad : ((M + 1 + region_pad + 1) & ~1);
 
     // ---- memory carve-up -----------------------------------------------------------
     unsigned int* wsum = reinterpret_cast<unsigned int*>(smem);            // 32 words
@@ -2253,7 +2331,7 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
         // ---- phase 2: patch (core.py:126-132) and sequential cumsum ----------------
-        if (RESIDENT || !fused) {
+        if (RESIDENT) {   // (the slab keeps the folded series once; its patch is an index mapping)
             for (int k = tid; k < W; k += nt) {
                 regA[n + k] = regA[k];
                 if constexpr (!UNIFORM_W) regW[n + k] = regW[k];
@@ -2280,24 +2358,39 @@ tls_search_kernel(const SearchArgs a) {
             exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
 #endif
         } else if (!fused) {
-            // the series is in the HBM slab: run the scan on LDS copies, kCumsumChunk elements a time
-            double* f_l = reinterpret_cast<double*>(smem + a.hdr_bytes);
-            double* c_l = f_l + kCumsumChunk;
+            // the series is in the HBM slab: the scan runs through LDS, 16 K elements a round, in place
+            // (C[k+1] over f[k]); the patch (core.py:126: the first W samples again) is an index mapping
+            // of the copy-in; LDS-only barriers, so the prefix-sum stores of a round stay in flight
+            double* buf = reinterpret_cast<double*>(smem + a.hdr_bytes) + 1;   // C[0..len], f = buf + 1 (16-byte aligned)
+            constexpr int kRound = 2 * kCumsumChunk;
             double carry = 0.0;
-            for (int c0 = 0; c0 < M; c0 += kCumsumChunk) {
-                const int len = M - c0 < kCumsumChunk ? M - c0 : kCumsumChunk;
-                copy_in_flight4(f_l, regA + c0, len);
-                __syncthreads();
-#if TLS_CUMSUM2
-                exact_cumsum<false, true, true>(f_l, c_l, len, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles, carry);
-#else
-                exact_sequential_cumsum(f_l, c_l, len, cumsum_scratch, a.phase_cycles, carry);
-#endif
-                __syncthreads();
-                for (int k = tid; k <= len; k += nt) regB[c0 + k] = c_l[k];
-                // the slab keeps f: e = 1 - f (or e*w) is formed when a tile is staged (stage_samples)
-                carry = c_l[len];
-                __syncthreads();
+            const bool dma = TLS_SLAB_DMA && (n & 1) == 0;   // pairs of samples never straddle the patch boundary
+            for (int c0 = 0; c0 < M; c0 += kRound) {
+                const int len = M - c0 < kRound ? M - c0 : kRound;
+                constexpr int kInFlight = 8;
+                if (dma) { slab_to_lds_async(buf + 1, regA, c0, len, n, tid); vmem_wait_all(); }
+                for (int k0 = tid; k0 < (dma ? 0 : len); k0 += kInFlight * nt) {
+                    double v[kInFlight];
+#pragma unroll
+                    for (int j = 0; j < kInFlight; ++j) {
+                        const int k = k0 + j * nt, pp = c0 + k;
+                        v[j] = k < len ? stream_load(regA + (pp < n ? pp : pp - n)) : 0.0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < kInFlight; ++j) if (k0 + j * nt < len) buf[1 + k0 + j * nt] = v[j];
+                }
+                lds_barrier();
+                pc.mark(26);
+                if (len <= 16 * nt) {
+                    carry = exact_cumsum_block_inline<16, true>(buf + 1, buf, 0, len, carry,
+                                                                reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
+                } else {   // fewer than 1024 threads: several blocks per round
+                    carry = exact_cumsum<true>(buf + 1, buf, len, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles, carry);
+                }
+                pc.mark(5);
+                copy_out_stream(regB + c0, buf, len + 1, tid);
+                lds_barrier();
+                pc.mark(27);
             }
         }
         // sentinels behind C: a window that would start past the end of the T0 grid sees an
@@ -2328,7 +2421,9 @@ tls_search_kernel(const SearchArgs a) {
         // one tile, the folded series already sits in LDS.  Otherwise the series is in the HBM slab
         // and each tile (+ halo = widest window) is staged into LDS first; windows are owned by the
         // tile that contains their first sample.
-        const int tile_len = RESIDENT ? (1 << 30) : a.tile_len;
+        // (the slab variant's tile length is the period's own: its halo covers the widest in-range window only)
+        const int tile_len_p = RESIDENT ? 0 : __builtin_amdgcn_readfirstlane(rows_c[p].pad);
+        const int tile_len = RESIDENT ? (1 << 30) : (tile_len_p > 0 ? tile_len_p : a.tile_len);
         for (int p_lo = 0; p_lo < M; p_lo += tile_len) {
         const int p_hi = p_lo + tile_len;
         const double* e_base = regA;   // e_base[b] = sample b of e (or e*w)
@@ -2345,8 +2440,16 @@ tls_search_kernel(const SearchArgs a) {
                 {
                     const int avail = M + 1 + region_pad - p_lo;            // entries the slab still holds
                     const int valid = avail < staged ? (avail > 0 ? avail : 0) : staged;
-                    stage_samples<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M);
-                    copy_in_flight4(tile_c, regB + p_lo, valid);
+                    if (TLS_SLAB_DMA && (n & 1) == 0) {
+                        stage_samples_async<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M, tid);
+                        slab_to_lds_async(tile_c, regB, p_lo, valid, 0x7fffffff, tid);
+                        vmem_wait_all();
+                        lds_barrier();
+                        finish_samples<UNIFORM_W>(tile_e, tile_w, p_lo, staged, M, tid);
+                    } else {
+                        stage_samples<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M);
+                        copy_in_flight4(tile_c, regB + p_lo, valid);
+                    }
                     for (int k = valid + tid; k < staged; k += nt) tile_c[k] = (double)(p_lo + k - M) * 1.0e300;
                 }
                 e_base = tile_e - p_lo;
@@ -2359,7 +2462,12 @@ tls_search_kernel(const SearchArgs a) {
                 {
                     const int avail = M + 1 + region_pad - p_lo;            // entries the slab still holds
                     const int valid = avail < staged ? (avail > 0 ? avail : 0) : staged;
-                    copy_in_flight4(tile_e, regB + p_lo, valid);
+                    if (TLS_SLAB_DMA) {
+                        slab_to_lds_async(tile_e, regB, p_lo, valid, 0x7fffffff, tid);   // (p_lo even, regions 16-byte aligned)
+                        vmem_wait_all();
+                    } else {
+                        copy_in_flight4(tile_e, regB + p_lo, valid);
+                    }
                     for (int k = valid + tid; k < staged; k += nt) tile_e[k] = (double)(p_lo + k - M) * 1.0e300;
                 }
                 c_base = tile_e - p_lo;
@@ -2516,7 +2624,14 @@ tls_search_kernel(const SearchArgs a) {
             const int staged = a.tile_len + a.tile_halo;
             double* tile_w = tile_e + staged;
             {
-                stage_samples<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M);
+                if (TLS_SLAB_DMA && (n & 1) == 0) {
+                    stage_samples_async<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M, tid);
+                    vmem_wait_all();
+                    lds_barrier();
+                    finish_samples<UNIFORM_W>(tile_e, tile_w, p_lo, staged, M, tid);
+                } else {
+                    stage_samples<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M);
+                }
             }
             e_base = tile_e - p_lo;
             w_base = tile_w - p_lo;
