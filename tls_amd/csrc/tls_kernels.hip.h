@@ -184,13 +184,60 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
+// The same for LDS traffic only: the wave's LDS operations are complete, its global loads and stores STAY IN
+// FLIGHT.  (wave_sync()'s fences compile to s_waitcnt vmcnt(0) lgkmcnt(0): in the slab sort's per-wave bin
+// rounds every one of them waited for the prefetch of the next bin and the gather issued a few lines above --
+// the whole HBM round trip exposed, six times a round.)
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // A pointer into LDS that reached a real (non-inlined) function as a generic pointer: handing it back
 // through its own address space lets the compiler use ds_* instructions again.  Without this every "LDS"
 // access of such a function is a FLAT instruction -- through the vector-memory pipe, counted on vmcnt AND
 // lgkmcnt, several times slower (found in the ISA of the first non-inlined version of the slab sort).
+// A wave-uniform value that reached us in vector registers (arguments of a __noinline__ device function do):
+// back into scalar registers, so that addresses formed from it stay scalar base + vector offset.
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffull));
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL));
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 template <typename T>
 __device__ __forceinline__ T* as_lds(T* p) {
     return (T*)(__attribute__((address_space(3))) T*)p;
+}
+// ... and likewise a pointer into global memory (flat_load/flat_store count on lgkmcnt as well: every LDS wait
+// of the function would also wait for its global traffic)
+template <typename T>
+__device__ __forceinline__ T* as_global(T* p) {
+    return (T*)(__attribute__((address_space(1))) T*)p;
+}
+// Pointer arguments of a __noinline__ function, uniform and in their address space again (the value is made
+// scalar INSIDE the address space: an integer round trip of the generic pointer loses it)
+template <typename T>
+__device__ __forceinline__ T* lds_arg(T* p) {
+    typedef __attribute__((address_space(3))) T* lds_t;
+    const unsigned int v = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(uintptr_t)(lds_t)p);
+    return (T*)(lds_t)(uintptr_t)v;
+}
+template <typename T>
+__device__ __forceinline__ T* global_arg(T* p) {
+    typedef __attribute__((address_space(1))) T* glob_t;
+    const unsigned long long b = (unsigned long long)(uintptr_t)(glob_t)p;
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffull));
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return (T*)(glob_t)(uintptr_t)(((unsigned long long)hi << 32) | lo);
 }
 
 // Workgroup barrier that orders LDS traffic only: the LDS operations of every wave are complete, global
@@ -995,6 +1042,16 @@ __device__ __forceinline__ double wave_inclusive_sum(double v) {
     return v;
 }
 
+__device__ __forceinline__ unsigned int wave_inclusive_sum_u32(unsigned int v) {
+    v += (unsigned int)dpp_i32<kDppRowShr1, 0xF>((int)v);
+    v += (unsigned int)dpp_i32<kDppRowShr2, 0xF>((int)v);
+    v += (unsigned int)dpp_i32<kDppRowShr4, 0xF>((int)v);
+    v += (unsigned int)dpp_i32<kDppRowShr8, 0xF>((int)v);
+    v += (unsigned int)dpp_i32<kDppBcast15, 0xA>((int)v);
+    v += (unsigned int)dpp_i32<kDppBcast31, 0xC>((int)v);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------
 // One block of the exact sequential prefix sum, elements held in registers (second formulation).
 //
@@ -1543,17 +1600,21 @@ __host__ __device__ constexpr long long sort2_lds_bytes(int n) {
     // counters (4 arrays of bins+1 words) + the larger of the pass-1 staging and the pass-2 windows
     const long long counters = 4LL * 4 * (sort2_bins(n) + 1);
     const long long stage = 14LL * kSort2Chunk;                                      // f64 + u32 + u16 per point
-    const long long windows = (long long)kMaxWaves * (8 + 4 + 4 + 4 + 4) * kSort2BinCap;  // ph, idx, cnt, slot, out
+    const long long windows = (long long)kMaxWaves * ((8 + 4 + 4) * kSort2BinCap + 16);  // phase, index, counter (+ end)
     return (counters + 15) / 16 * 16 + (stage > windows ? stage : windows);
 }
 
 //   y_gather (may be null): the folded flux y[perm[k]] is written over g_ph[k] on the way (and
 //   w_gather -> w_out likewise), which saves the separate gather pass of a single light curve.
+template <bool HAS_W>
 __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, double period, double epoch, double* g_ph,
                                                     unsigned int* g_idx, unsigned int* perm, unsigned char* lds,
                                                     PhaseClock& pc, const double* y_gather = nullptr,
                                                     const double* w_gather = nullptr, double* w_out_g = nullptr,
                                                     unsigned long long* dbg_check = nullptr) {
+    // (Carrying the flux WITH the points -- pass 1 reading y beside t and writing it into the bin segments,
+    // pass 2 reading it back with the phases instead of gathering y[index] -- was built and measured: the
+    // gather disappears, but the partition pass grows by more (Kepler-size sample 6.5 vs 5.65 ms).)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // opaque: indices derived from it are formed here, not hoisted out of the
                                     // period loop and spilled (a spill reload between two loads waits for vmcnt(0))
@@ -1676,13 +1737,18 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
     pc.mark(2);
 
     // ---- pass 2: one coarse bin per wavefront, sorted inside its LDS window -----------------------
+    // Every lane keeps its (up to kE) points of the bin in registers and ranks them itself: the points are
+    // counted into fine buckets, laid out bucket by bucket (phase and index side by side), and a point's rank
+    // is its bucket's start plus the members of its bucket that precede it in (phase, index) order -- the
+    // order of numpy's stable sort.  The s-th member of all buckets is read in one batch, so the LDS
+    // latency is paid once per step, not per point and step.  Results leave through the window in rank order,
+    // i.e. as coalesced stores.  The kE slots of a lane are walked only as far as the bin is filled (160 points
+    // on average, the window holds 384), under wave-uniform branches.
     {
-        unsigned char* win = area + (size_t)wave * ((8 + 4 + 4 + 4 + 4) * kSort2BinCap);
-        double* w_ph = reinterpret_cast<double*>(win);
-        unsigned int* w_idx = reinterpret_cast<unsigned int*>(w_ph + kSort2BinCap);
-        unsigned int* w_cnt = w_idx + kSort2BinCap;
-        unsigned int* w_slot = w_cnt + kSort2BinCap;
-        unsigned int* w_out = w_slot + kSort2BinCap;
+        unsigned char* win = area + (size_t)wave * ((8 + 4 + 4) * kSort2BinCap + 16);
+        double* s_ph = reinterpret_cast<double*>(win);                 // phases, bucket by bucket
+        unsigned int* s_idx = reinterpret_cast<unsigned int*>(s_ph + kSort2BinCap);
+        unsigned int* w_cnt = s_idx + kSort2BinCap;
         constexpr int kE = kSort2BinCap / kWave;   // entries per lane
         // the points of a wave's NEXT bin are requested before the current one is sorted: their HBM
         // latency hides behind the sort
@@ -1701,110 +1767,195 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
         }
         for (int b0 = 0; b0 < B; b0 += nw) {
             const int b = b0 + wave;
-            const unsigned int first = b < B ? g_start[b] : 0u;
-            const int m = b < B ? (int)(g_start[b + 1] - first) : 0;
+            const unsigned int first = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b < B ? g_start[b] : 0u));
+            const int m = __builtin_amdgcn_readfirstlane(b < B ? (int)(g_start[b + 1] - first) : 0);
+            const int e_used = (m + kWave - 1) / kWave;   // slots per lane that hold a point in some lane
+            const int bn = b + nw;
+            const unsigned int first_n = (unsigned int)__builtin_amdgcn_readfirstlane((int)(bn < B ? g_start[bn] : 0u));
+            const int m_n = __builtin_amdgcn_readfirstlane(bn < B ? (int)(g_start[bn + 1] - first_n) : 0);
 #ifdef TLS_DEBUG_CHECKS
             if (dbg_check && !(m <= kSort2BinCap) && lane == 0) atomicAdd(&dbg_check[kChkSortWindow], 1ull);
 #endif
-            // fine bucket of a point inside its coarse bin: monotone in the phase
-            int fb[kE];
+            double ph[kE];
+            unsigned int id[kE];
+            double yv[kE];
+            [[maybe_unused]] double wv[HAS_W ? kE : 1];
+            int fb[kE];   // fine bucket of a point inside its coarse bin: monotone in the phase
 #pragma unroll
             for (int e = 0; e < kE; ++e) {
-                const int j = lane + e * kWave;
-                w_cnt[j] = 0;
-                fb[e] = 0;
-                if (j < m) {
-                    const double ph = nx_ph[e];
-                    w_ph[j] = ph;
-                    w_idx[j] = nx_idx[e];
-                    const int f = (int)((ph * B_d - (double)b) * (double)kSort2BinCap);
-                    fb[e] = f < 0 ? 0 : (f < kSort2BinCap - 1 ? f : kSort2BinCap - 1);
+                ph[e] = nx_ph[e];
+                id[e] = nx_idx[e];
+                w_cnt[lane + e * kWave] = 0;
+            }
+            if (y_gather) {
+#pragma unroll
+                for (int e = 0; e < kE; ++e) if (e < e_used) yv[e] = y_gather[id[e]];       // (index 0 in the unused lanes)
+                if constexpr (HAS_W) {
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) if (e < e_used) wv[e] = w_gather[id[e]];
                 }
             }
-            {
-                const int bn = b + nw;
-                const unsigned int first_n = bn < B ? g_start[bn] : 0u;
-                const int m_n = bn < B ? (int)(g_start[bn + 1] - first_n) : 0;
 #pragma unroll
-                for (int e = 0; e < kE; ++e) {
+            for (int e = 0; e < kE; ++e) {
+                if (e * kWave < m_n) {
                     const int j = lane + e * kWave;
                     nx_ph[e] = j < m_n ? g_ph[first_n + j] : 0.0;
                     nx_idx[e] = j < m_n ? g_idx[first_n + j] : 0u;
                 }
             }
-            wave_sync();
 #pragma unroll
-            for (int e = 0; e < kE; ++e) if (lane + e * kWave < m) atomicAdd(&w_cnt[fb[e]], 1u);
-            wave_sync();
-            {   // exclusive scan of the kSort2BinCap counters of this window: kE consecutive per lane
+            for (int e = 0; e < kE; ++e) {
+                fb[e] = 0;
+                if (e < e_used) {
+                    const int f = (int)((ph[e] * B_d - (double)b) * (double)kSort2BinCap);
+                    fb[e] = f < 0 ? 0 : (f < kSort2BinCap - 1 ? f : kSort2BinCap - 1);
+                }
+            }
+            wave_lds_sync();
+            unsigned int tk[kE];   // ticket of the point inside its fine bucket (arrival order: arbitrary)
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                tk[e] = 0u;
+                if (e < e_used) { if (lane + e * kWave < m) tk[e] = atomicAdd(&w_cnt[fb[e]], 1u); }
+            }
+            wave_lds_sync();
+            {   // exclusive scan of the kSort2BinCap counters of this window: kE consecutive per lane, the
+                // wave's part on the DPP crossbar (no LDS round trips)
                 unsigned int c[kE], local = 0;
 #pragma unroll
                 for (int e = 0; e < kE; ++e) { c[e] = w_cnt[lane * kE + e]; local += c[e]; }
-                unsigned int incl = local;
-#pragma unroll
-                for (int dlt = 1; dlt < kWave; dlt <<= 1) {
-                    const unsigned int o = __shfl_up(incl, dlt, kWave);
-                    if (lane >= dlt) incl += o;
-                }
-                unsigned int run = incl - local;
+                unsigned int run = wave_inclusive_sum_u32(local) - local;
 #pragma unroll
                 for (int e = 0; e < kE; ++e) { w_cnt[lane * kE + e] = run; run += c[e]; }
+                if (lane == kWave - 1) w_cnt[kSort2BinCap] = run;   // the end of the last bucket
             }
-            wave_sync();
+            wave_lds_sync();
+            int lo[kE], len[kE], rank[kE], longest = 0;
 #pragma unroll
             for (int e = 0; e < kE; ++e) {
-                const int j = lane + e * kWave;
-                if (j < m) w_slot[atomicAdd(&w_cnt[fb[e]], 1u)] = (unsigned int)j;   // w_cnt[f] becomes the END of bucket f
+                lo[e] = 0; len[e] = 0; rank[e] = 0;
+                if (e < e_used) {
+                    const bool have = lane + e * kWave < m;
+                    lo[e] = have ? (int)w_cnt[fb[e]] : 0;
+                    len[e] = have ? (int)w_cnt[fb[e] + 1] - lo[e] : 0;
+                }
             }
-            wave_sync();
 #pragma unroll
             for (int e = 0; e < kE; ++e) {
-                const int sidx = lane + e * kWave;
-                if (sidx < m) {
-                    const int j = (int)w_slot[sidx];
-                    const double ph = w_ph[j];
-                    const unsigned int id = w_idx[j];
-                    const int f = (int)((ph * B_d - (double)b) * (double)kSort2BinCap);
-                    const int fbj = f < 0 ? 0 : (f < kSort2BinCap - 1 ? f : kSort2BinCap - 1);
-                    const int lo = fbj ? (int)w_cnt[fbj - 1] : 0, hi = (int)w_cnt[fbj];
-                    int rank = 0;
-                    for (int s2 = lo; s2 < hi; ++s2) {
-                        const int j2 = (int)w_slot[s2];
-                        const double ph2 = w_ph[j2];
-                        rank += (ph2 < ph || (ph2 == ph && w_idx[j2] < id)) ? 1 : 0;
-                    }
-                    w_out[lo + rank] = id;
-                }
-            }
-            wave_sync();
-            {
-                unsigned int id[kE];
-#pragma unroll
-                for (int e = 0; e < kE; ++e) {
-                    const int sidx = lane + e * kWave;
-                    id[e] = sidx < m ? w_out[sidx] : 0u;
-                    if (sidx < m) perm[first + sidx] = id[e];
-                }
-                if (y_gather) {   // this bin's phases are in the window: their slab entries may go
-                    double v[kE];
-#pragma unroll
-                    for (int e = 0; e < kE; ++e) v[e] = y_gather[id[e]];
-#pragma unroll
-                    for (int e = 0; e < kE; ++e) if (lane + e * kWave < m) g_ph[first + lane + e * kWave] = v[e];
-                    if (w_gather) {
-#pragma unroll
-                        for (int e = 0; e < kE; ++e) v[e] = w_gather[id[e]];
-#pragma unroll
-                        for (int e = 0; e < kE; ++e) if (lane + e * kWave < m) w_out_g[first + lane + e * kWave] = v[e];
+                if (e < e_used) {
+                    if (lane + e * kWave < m) {
+                        s_ph[lo[e] + (int)tk[e]] = ph[e];
+                        s_idx[lo[e] + (int)tk[e]] = id[e];
                     }
                 }
             }
-            wave_sync();
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < kE; ++e) longest = len[e] > longest ? len[e] : longest;
+            constexpr int kHalf = kE / 2;   // the batch of a step in two halves: fewer registers in flight
+            for (int sidx = 0; __ballot(sidx < longest) != 0ull; ++sidx) {
+#pragma unroll
+                for (int h = 0; h < kE; h += kHalf) {
+                    if (h < e_used) {
+                        double ph2[kHalf];
+#pragma unroll
+                        for (int e = 0; e < kHalf; ++e) ph2[e] = s_ph[sidx < len[h + e] ? lo[h + e] + sidx : 0];
+                        bool tie = false;
+#pragma unroll
+                        for (int e = 0; e < kHalf; ++e) {
+                            const bool in = sidx < len[h + e];
+                            rank[h + e] += (in && ph2[e] < ph[h + e]) ? 1 : 0;
+                            tie |= in && ph2[e] == ph[h + e] && sidx != (int)tk[h + e];   // (its own entry aside)
+                        }
+                        if (__ballot(tie) != 0ull) {   // equal phases (rare): the index decides, as in a stable sort
+#pragma unroll
+                            for (int e = 0; e < kHalf; ++e) {
+                                const bool in = sidx < len[h + e];
+                                const unsigned int id2 = s_idx[in ? lo[h + e] + sidx : 0];
+                                rank[h + e] += (in && ph2[e] == ph[h + e] && id2 < id[h + e]) ? 1 : 0;
+                            }
+                        }
+                    }
+                }
+            }
+            // One wait per round, here: the flux is needed now, and the next bin's points -- requested at the
+            // top of this round -- have had the whole sort to arrive.  The stores below then have the whole
+            // NEXT round: gfx9 counts loads and stores on one counter, so a wait for a load issued before
+            // them (the compiler's vmcnt(0) whenever stores are pending) would expose their round trip.
+            vmem_wait_all();
+            wave_lds_sync();   // every lane is done with the bucket lists: the window now carries the results
+            // in rank order through the window, out as coalesced stores (the bin's phases are all in
+            // registers: their slab entries may go)
+            if (perm) {
+#pragma unroll
+                for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_idx[lo[e] + rank[e]] = id[e]; }
+            }
+            if (y_gather) {
+#pragma unroll
+                for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_ph[lo[e] + rank[e]] = yv[e]; }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                if (e < e_used) {
+                    const int j = lane + e * kWave;
+                    if (j < m) {
+                        if (perm) perm[first + j] = s_idx[j];
+                        if (y_gather) g_ph[first + j] = s_ph[j];
+                    }
+                }
+            }
+            if constexpr (HAS_W) {
+                if (y_gather) {
+                    wave_lds_sync();
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_ph[lo[e] + rank[e]] = wv[e]; }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) w_out_g[first + lane + e * kWave] = s_ph[lane + e * kWave]; }
+                }
+            }
+            wave_lds_sync();
         }
     }
-    __syncthreads();   // the permutation (and the gathered flux) is complete
+    __syncthreads();
     pc.mark(3);
     return true;
+}
+
+// The same as a real function with its own register allocation.  Inlined into the search kernel the sort
+// shares the 128 registers with everything the kernel keeps alive across a period; the allocator then spills
+// inside the sort's loops, and a spill reload is a scratch load whose s_waitcnt vmcnt(0) also waits for every
+// global load in flight -- the reads of a round went out one at a time (twice the time of the partition pass,
+// and which loops were hit changed with unrelated edits elsewhere in the kernel).
+// The arguments arrive in vector registers: the uniform ones are moved back to scalars, the LDS pointer to
+// its address space.  Keeps its own phase clock.
+// Pointer parameters typed by address space (a generic pointer parameter makes every access a FLAT instruction,
+// counted on vmcnt AND lgkmcnt); the LDS window travels as its 32-bit LDS address.
+template <typename T> using global_ptr = __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ T* from_global_arg(global_ptr<T> p) {   // uniform again, then generic for the callee's code
+    const unsigned long long b = (unsigned long long)(uintptr_t)p;
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffull));
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return (T*)(global_ptr<T>)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ unsigned int lds_address(T* p) {
+    return (unsigned int)(uintptr_t)(__attribute__((address_space(3))) T*)p;
+}
+template <bool HAS_W>
+__device__ __noinline__ bool fold_and_sort_tiled_call(global_ptr<const double> t, int n, double period, global_ptr<double> g_ph,
+                                                      global_ptr<unsigned int> g_idx, global_ptr<unsigned int> perm,
+                                                      unsigned int lds_addr, global_ptr<unsigned long long> clock_out,
+                                                      global_ptr<const double> y_gather, global_ptr<const double> w_gather,
+                                                      global_ptr<double> w_out_g, global_ptr<unsigned long long> dbg_check) {
+    PhaseClock pc; pc.start(from_global_arg(clock_out));
+    typedef __attribute__((address_space(3))) unsigned char* lds_t;
+    unsigned char* lds = (unsigned char*)(lds_t)(uintptr_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    return fold_and_sort_tiled<HAS_W>(from_global_arg(t), uniform_i32(n), uniform_f64(period), 0.0, from_global_arg(g_ph),
+                                from_global_arg(g_idx), from_global_arg(perm), lds, pc, from_global_arg(y_gather),
+                                from_global_arg(w_gather), from_global_arg(w_out_g), from_global_arg(dbg_check));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2291,10 +2442,20 @@ tls_search_kernel(const SearchArgs a) {
                                                           reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
             if (a.sort3 && a.n_curves == 1) pc.start(a.phase_cycles);   // the call kept its own clock
             // series in HBM: the two-level sort with sequential HBM accesses, unless a phase bin overflows
-            if (!fused && a.sort2)
-                sorted = fold_and_sort_tiled(a.t, n, period, 0.0, ph_orig, reinterpret_cast<unsigned int*>(idx_tmp),
-                                             reinterpret_cast<unsigned int*>(perm), smem + a.hdr_bytes, pc,
-                                             a.n_curves == 1 ? a.y : nullptr, UNIFORM_W ? nullptr : a.w, regW, a.check);
+            if (!fused && a.sort2) {
+                typedef global_ptr<const double> gcd;
+                typedef global_ptr<double> gd;
+                typedef global_ptr<unsigned int> gu;
+                typedef global_ptr<unsigned long long> gull;
+                // (one light curve: the flux is gathered on the way and no permutation is written)
+                // (one light curve: the flux is gathered on the way and no permutation is written)
+                sorted = fold_and_sort_tiled_call<!UNIFORM_W>((gcd)a.t, n, period, (gd)ph_orig, (gu) reinterpret_cast<unsigned int*>(idx_tmp),
+                                                              (gu)(a.n_curves == 1 ? nullptr : reinterpret_cast<unsigned int*>(perm)),
+                                                              lds_address(smem + a.hdr_bytes), (gull)a.phase_cycles,
+                                                              (gcd)(a.n_curves == 1 ? a.y : nullptr), (gcd)(UNIFORM_W ? nullptr : a.w),
+                                                              (gd)regW, (gull)a.check);
+                pc.start(a.phase_cycles);   // (the call kept its own clock)
+            }
         }
         if (!sorted && !fused) fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc);
         // survey mode: the permutation depends on (t, period) only, so every light curve of the
