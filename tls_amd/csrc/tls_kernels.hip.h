@@ -158,9 +158,15 @@ __device__ __forceinline__ void load_taps(const double* p, double (&x)[kU]) {
 #ifndef TLS_NT
 #define TLS_NT 1
 #endif
+#ifndef TLS_NT_LOAD
+#define TLS_NT_LOAD TLS_NT
+#endif
+#ifndef TLS_NT_STORE
+#define TLS_NT_STORE TLS_NT
+#endif
 template <typename T>
 __device__ __forceinline__ T stream_load(const T* p) {
-#if TLS_NT
+#if TLS_NT_LOAD
     return __builtin_nontemporal_load(p);
 #else
     return *p;
@@ -168,7 +174,7 @@ __device__ __forceinline__ T stream_load(const T* p) {
 }
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
-#if TLS_NT
+#if TLS_NT_STORE
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;
@@ -260,6 +266,9 @@ __device__ __forceinline__ void vmem_wait_all() {
 #ifndef TLS_SLAB_DMA
 #define TLS_SLAB_DMA 1
 #endif
+#ifndef TLS_GATHER_DEPTH
+#define TLS_GATHER_DEPTH 3   // flux values a thread gathers per step (their L2 round trips overlap)
+#endif
 // Slab -> LDS without registers: `count` doubles (rounded up to a pair) travel by global_load_lds_dwordx4, 1 KiB
 // per wave-instruction, all of them in flight together -- a copy through registers keeps 32-64 B per thread
 // in flight, which at ~1.5 us of loaded HBM latency is the ~10 B/cycle a workgroup was seen to move.  Element k
@@ -279,7 +288,7 @@ __device__ __forceinline__ void slab_to_lds_async(double* dst_lds, const double*
             const double* g = src + (p < n ? p : p - n);
             unsigned int m0_saved;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-#if TLS_NT
+#if TLS_NT_LOAD
                          " nt"
 #endif
                          "\n\ts_mov_b32 m0, %0"
@@ -1578,6 +1587,20 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
     pc.mark(3);
 }
 
+// Pointer parameters typed by address space (a generic pointer parameter makes every access a FLAT instruction,
+// counted on vmcnt AND lgkmcnt); the LDS window travels as its 32-bit LDS address.
+template <typename T> using global_ptr = __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ T* from_global_arg(global_ptr<T> p) {   // uniform again, then generic for the callee's code
+    const unsigned long long b = (unsigned long long)(uintptr_t)p;
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffull));
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return (T*)(global_ptr<T>)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ unsigned int lds_address(T* p) {
+    return (unsigned int)(uintptr_t)(__attribute__((address_space(3))) T*)p;
+}
 // ---------------------------------------------------------------------------------------
 // The same order for a series that lives in HBM (tiled variant): a two-level sort whose HBM accesses
 // are all sequential.  fold_and_sort scatters and ranks through global memory with one random
@@ -1591,6 +1614,10 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
 //   caller then falls back to fold_and_sort.
 constexpr int kSort2Chunk = 10240;    // points bucketed per pass-1 round
 constexpr int kSort2BinCap = 384;     // points one wavefront can sort in its LDS window
+#ifndef TLS_SORT2_FINE
+#define TLS_SORT2_FINE 384
+#endif
+constexpr int kSort2Fine = TLS_SORT2_FINE;   // fine buckets of a bin (<= kSort2BinCap: the counters share its window slot)
 constexpr int kSort2BinMean = 160;    // target points per coarse bin
 constexpr int kSort2MaxBins = 1024;
 __host__ __device__ constexpr int sort2_bins(int n) {
@@ -1750,6 +1777,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
         unsigned int* s_idx = reinterpret_cast<unsigned int*>(s_ph + kSort2BinCap);
         unsigned int* w_cnt = s_idx + kSort2BinCap;
         constexpr int kE = kSort2BinCap / kWave;   // entries per lane
+        constexpr int kF = kSort2Fine / kWave;     // fine-bucket counters per lane
         // the points of a wave's NEXT bin are requested before the current one is sorted: their HBM
         // latency hides behind the sort
         double nx_ph[kE];
@@ -1785,8 +1813,9 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
             for (int e = 0; e < kE; ++e) {
                 ph[e] = nx_ph[e];
                 id[e] = nx_idx[e];
-                w_cnt[lane + e * kWave] = 0;
             }
+#pragma unroll
+            for (int e = 0; e < kF; ++e) w_cnt[lane + e * kWave] = 0;
             if (y_gather) {
 #pragma unroll
                 for (int e = 0; e < kE; ++e) if (e < e_used) yv[e] = y_gather[id[e]];       // (index 0 in the unused lanes)
@@ -1807,8 +1836,8 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
             for (int e = 0; e < kE; ++e) {
                 fb[e] = 0;
                 if (e < e_used) {
-                    const int f = (int)((ph[e] * B_d - (double)b) * (double)kSort2BinCap);
-                    fb[e] = f < 0 ? 0 : (f < kSort2BinCap - 1 ? f : kSort2BinCap - 1);
+                    const int f = (int)((ph[e] * B_d - (double)b) * (double)kSort2Fine);
+                    fb[e] = f < 0 ? 0 : (f < kSort2Fine - 1 ? f : kSort2Fine - 1);
                 }
             }
             wave_lds_sync();
@@ -1819,15 +1848,15 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 if (e < e_used) { if (lane + e * kWave < m) tk[e] = atomicAdd(&w_cnt[fb[e]], 1u); }
             }
             wave_lds_sync();
-            {   // exclusive scan of the kSort2BinCap counters of this window: kE consecutive per lane, the
+            {   // exclusive scan of the kSort2Fine counters of this window: kF consecutive per lane, the
                 // wave's part on the DPP crossbar (no LDS round trips)
-                unsigned int c[kE], local = 0;
+                unsigned int c[kF], local = 0;
 #pragma unroll
-                for (int e = 0; e < kE; ++e) { c[e] = w_cnt[lane * kE + e]; local += c[e]; }
+                for (int e = 0; e < kF; ++e) { c[e] = w_cnt[lane * kF + e]; local += c[e]; }
                 unsigned int run = wave_inclusive_sum_u32(local) - local;
 #pragma unroll
-                for (int e = 0; e < kE; ++e) { w_cnt[lane * kE + e] = run; run += c[e]; }
-                if (lane == kWave - 1) w_cnt[kSort2BinCap] = run;   // the end of the last bucket
+                for (int e = 0; e < kF; ++e) { w_cnt[lane * kF + e] = run; run += c[e]; }
+                if (lane == kWave - 1) w_cnt[kSort2Fine] = run;   // the end of the last bucket
             }
             wave_lds_sync();
             int lo[kE], len[kE], rank[kE], longest = 0;
@@ -1930,20 +1959,6 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 // and which loops were hit changed with unrelated edits elsewhere in the kernel).
 // The arguments arrive in vector registers: the uniform ones are moved back to scalars, the LDS pointer to
 // its address space.  Keeps its own phase clock.
-// Pointer parameters typed by address space (a generic pointer parameter makes every access a FLAT instruction,
-// counted on vmcnt AND lgkmcnt); the LDS window travels as its 32-bit LDS address.
-template <typename T> using global_ptr = __attribute__((address_space(1))) T*;
-template <typename T>
-__device__ __forceinline__ T* from_global_arg(global_ptr<T> p) {   // uniform again, then generic for the callee's code
-    const unsigned long long b = (unsigned long long)(uintptr_t)p;
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffull));
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b >> 32));
-    return (T*)(global_ptr<T>)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-}
-template <typename T>
-__device__ __forceinline__ unsigned int lds_address(T* p) {
-    return (unsigned int)(uintptr_t)(__attribute__((address_space(3))) T*)p;
-}
 template <bool HAS_W>
 __device__ __noinline__ bool fold_and_sort_tiled_call(global_ptr<const double> t, int n, double period, global_ptr<double> g_ph,
                                                       global_ptr<unsigned int> g_idx, global_ptr<unsigned int> perm,
@@ -2200,7 +2215,7 @@ __device__ __forceinline__ bool fold_sort_cumsum_tiled(const double* t, const do
             unsigned int m0_saved;
             if (i < mb)   // M0 carries the LDS base of the transfer; it is put back (the compiler may own it)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-#if TLS_NT
+#if TLS_NT_LOAD
                              " nt"
 #endif
                              "\n\ts_mov_b32 m0, %0"
@@ -2469,26 +2484,28 @@ tls_search_kernel(const SearchArgs a) {
         }
         for (int curve = 0; curve < a.n_curves; ++curve) {
         const double* y_c = a.y + (long long)curve * n;
-        // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  Three
+        // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  kG
         // elements per step: their global reads (L2 latency) are in flight together -- the compiler
         // cannot overlap them itself, the LDS store of one may alias the index read of the next
         const bool gathered = !RESIDENT && (fused || (sorted && a.n_curves == 1));   // the sort did it on the way
-        for (int k = tid; k < (gathered ? 0 : n); k += 3 * nt) {
-            const int k1 = k + nt, k2 = k + 2 * nt;
-            const int i0 = (int)perm_use[k];
-            const int i1 = k1 < n ? (int)perm_use[k1] : i0;
-            const int i2 = k2 < n ? (int)perm_use[k2] : i0;
-            const double v0 = y_c[i0], v1 = y_c[i1], v2 = y_c[i2];
+        constexpr int kG = TLS_GATHER_DEPTH;
+        for (int k0 = tid; k0 < (gathered ? 0 : n); k0 += kG * nt) {
+            int idx[kG];
+            double v[kG];
+#pragma unroll
+            for (int g = 0; g < kG; ++g) idx[g] = (int)perm_use[k0 + g * nt < n ? k0 + g * nt : k0];
+#pragma unroll
+            for (int g = 0; g < kG; ++g) v[g] = y_c[idx[g]];
             if constexpr (!UNIFORM_W) {
                 const double* w_c = a.w + (long long)curve * n;
-                const double u0 = w_c[i0], u1 = w_c[i1], u2 = w_c[i2];
-                regW[k] = u0;
-                if (k1 < n) regW[k1] = u1;
-                if (k2 < n) regW[k2] = u2;
+                double u[kG];
+#pragma unroll
+                for (int g = 0; g < kG; ++g) u[g] = w_c[idx[g]];
+#pragma unroll
+                for (int g = 0; g < kG; ++g) if (k0 + g * nt < n) regW[k0 + g * nt] = u[g];
             }
-            regA[k] = v0;
-            if (k1 < n) regA[k1] = v1;
-            if (k2 < n) regA[k2] = v2;
+#pragma unroll
+            for (int g = 0; g < kG; ++g) if (k0 + g * nt < n) regA[k0 + g * nt] = v[g];
         }
         __syncthreads();
         // ---- phase 2: patch (core.py:126-132) and sequential cumsum ----------------
