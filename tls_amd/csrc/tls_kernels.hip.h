@@ -2796,6 +2796,14 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
         pc.mark(9);
+        if constexpr (!RESIDENT) {
+            // a tile in which no cell passed the depth predicate has nothing to evaluate: its samples are
+            // not staged (second staging of the tile) and the dot-product phase is skipped
+            unsigned int tile_live = 0;
+#pragma unroll 1
+            for (int row = 0; row < n_rows; ++row) tile_live += rt.live[row];
+            if (__builtin_amdgcn_readfirstlane((int)tile_live) == 0) { __syncthreads(); continue; }
+        }
         if constexpr (!RESIDENT && !STAGE_C) {
             // the folded samples replace C in the tile; the few C values phase 3b needs come from the slab
             double* tile_e = reinterpret_cast<double*>(smem + a.hdr_bytes);
