@@ -616,8 +616,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // one light curve per launch: partition into large phase bins, per-bin LDS sort fused with the prefix sum
         const size_t sort3_bytes = hdr + (size_t)tlsdev::sort3_lds_bytes();
         const char* env_sort3 = std::getenv("TLS_SORT3");
-        // (measured on the Kepler-size series: 15 % fewer HBM bytes than the two-level sort -- 6.3 vs 7.4 MB per
-        // period -- but 12 % more kernel time, its 23 bin rounds of eleven barriers each cost more than the
+        // (measured on the Kepler-size series: 8 % fewer HBM bytes than the two-level sort -- 5.2 vs 5.7 MB per
+        // period -- but 32 % more kernel time, its 23 bin rounds of eleven barriers each cost more than the
         // gather they avoid; on the TESS-size series 15 % slower.  The two-level sort stays the default,
         // TLS_SORT3=1 selects this path; both are tested.)
         ctx->sort3 = sort3_bytes <= kLdsPerCU && tlsdev::sort3_bins((int)n) <= tlsdev::kSort3MaxBins && (int64_t)W <= n &&
