@@ -466,6 +466,12 @@ __device__ __forceinline__ double fold_phase(double t, double period, double epo
     return x - floor(x);
 }
 
+// 32-bit fixed-point phase: monotone in the phase (the scaling is exact), so it orders two points whenever it
+// differs; equal keys are decided by the exact fp64 phase, then the index.
+__device__ __forceinline__ unsigned int phase_key(double ph) {
+    return ph < 1.0 ? (unsigned int)(ph * 4294967296.0) : 0xffffffffu;
+}
+
 __device__ __forceinline__ int bucket_of(double phase, double nb_d, int nb) {
     int b = (int)(phase * nb_d);  // monotone in phase
     return b < nb - 1 ? b : nb - 1;
@@ -1626,19 +1632,21 @@ __host__ __device__ constexpr int sort2_bins(int n) {
 __host__ __device__ constexpr long long sort2_lds_bytes(int n) {
     // counters (4 arrays of bins+1 words) + the larger of the pass-1 staging and the pass-2 windows
     const long long counters = 4LL * 4 * (sort2_bins(n) + 1);
-    const long long stage = 14LL * kSort2Chunk;                                      // f64 + u32 + u16 per point
-    const long long windows = (long long)kMaxWaves * ((8 + 4 + 4) * kSort2BinCap + 16);  // phase, index, counter (+ end)
+    const long long stage = 10LL * kSort2Chunk;                                      // record (u64) + bin (u16) per point
+    const long long windows = (long long)kMaxWaves * ((8 + 4) * kSort2BinCap + 16);  // record, counter (+ end)
     return (counters + 15) / 16 * 16 + (stage > windows ? stage : windows);
 }
 
 //   y_gather (may be null): the folded flux y[perm[k]] is written over g_ph[k] on the way (and
 //   w_gather -> w_out likewise), which saves the separate gather pass of a single light curve.
+//   g_rec[n]: HBM scratch, the partitioned points as 8-byte records (32-bit phase key << 32 | original index),
+//   grouped by coarse bin; f_out[n] (y_gather given): the folded flux.  f_out may BE g_rec: a bin's records are
+//   in registers before its flux is stored.
 template <bool HAS_W>
-__device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, double period, double epoch, double* g_ph,
-                                                    unsigned int* g_idx, unsigned int* perm, unsigned char* lds,
-                                                    PhaseClock& pc, const double* y_gather = nullptr,
-                                                    const double* w_gather = nullptr, double* w_out_g = nullptr,
-                                                    unsigned long long* dbg_check = nullptr) {
+__device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, double period, double epoch,
+                                                    unsigned long long* g_rec, unsigned int* perm, unsigned char* lds,
+                                                    PhaseClock& pc, const double* y_gather, const double* w_gather,
+                                                    double* f_out, double* w_out_g, unsigned long long* dbg_check) {
     // (Carrying the flux WITH the points -- pass 1 reading y beside t and writing it into the bin segments,
     // pass 2 reading it back with the phases instead of gathering y[index] -- was built and measured: the
     // gather disappears, but the partition pass grows by more (Kepler-size sample 6.5 vs 5.65 ms).)
@@ -1696,9 +1704,8 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 
     // ---- pass 1: partition, one chunk of points per round ---------------------------------------
     {
-        double* st_ph = reinterpret_cast<double*>(area);
-        unsigned int* st_idx = reinterpret_cast<unsigned int*>(st_ph + kSort2Chunk);
-        unsigned short* st_bin = reinterpret_cast<unsigned short*>(st_idx + kSort2Chunk);
+        unsigned long long* st_rec = reinterpret_cast<unsigned long long*>(area);
+        unsigned short* st_bin = reinterpret_cast<unsigned short*>(st_rec + kSort2Chunk);
         constexpr int kPer = kSort2Chunk / 1024;   // points per thread and round (1024-thread workgroups)
         const int chunk = kPer * nt < kSort2Chunk ? kPer * nt : kSort2Chunk;
         for (int c0 = 0; c0 < n; c0 += chunk) {
@@ -1725,13 +1732,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 const int lo = lane * per < B ? lane * per : B, hi = lo + per < B ? lo + per : B;
                 unsigned int local = 0;
                 for (int b = lo; b < hi; ++b) local += l_cnt[b];
-                unsigned int incl = local;
-#pragma unroll
-                for (int dlt = 1; dlt < kWave; dlt <<= 1) {
-                    const unsigned int o = __shfl_up(incl, dlt, kWave);
-                    if (lane >= dlt) incl += o;
-                }
-                unsigned int run = incl - local;
+                unsigned int run = wave_inclusive_sum_u32(local) - local;
                 for (int b = lo; b < hi; ++b) { l_start[b] = run; run += l_cnt[b]; }
             }
             lds_barrier();
@@ -1740,8 +1741,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
             for (int e = 0; e < kPer; ++e) {
                 if (bin[e] >= 0) {
                     const unsigned int s = l_start[bin[e]] + rank[e];
-                    st_ph[s] = ph[e];
-                    st_idx[s] = (unsigned int)(c0 + tid + e * nt);
+                    st_rec[s] = ((unsigned long long)phase_key(ph[e]) << 32) | (unsigned long long)(unsigned int)(c0 + tid + e * nt);
                     st_bin[s] = (unsigned short)bin[e];
                 }
             }
@@ -1750,9 +1750,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
             // every bin's points of this chunk leave as one contiguous segment
             for (int sidx = tid; sidx < cn; sidx += nt) {
                 const int b = st_bin[sidx];
-                const unsigned int dst = g_cur[b] + ((unsigned int)sidx - l_start[b]);
-                g_ph[dst] = st_ph[sidx];
-                g_idx[dst] = st_idx[sidx];
+                g_rec[g_cur[b] + ((unsigned int)sidx - l_start[b])] = st_rec[sidx];
             }
             lds_barrier();
             pc.mark(31);
@@ -1772,27 +1770,22 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
     // i.e. as coalesced stores.  The kE slots of a lane are walked only as far as the bin is filled (160 points
     // on average, the window holds 384), under wave-uniform branches.
     {
-        unsigned char* win = area + (size_t)wave * ((8 + 4 + 4) * kSort2BinCap + 16);
-        double* s_ph = reinterpret_cast<double*>(win);                 // phases, bucket by bucket
-        unsigned int* s_idx = reinterpret_cast<unsigned int*>(s_ph + kSort2BinCap);
-        unsigned int* w_cnt = s_idx + kSort2BinCap;
+        unsigned char* win = area + (size_t)wave * ((8 + 4) * kSort2BinCap + 16);
+        unsigned long long* s_rec = reinterpret_cast<unsigned long long*>(win);   // records, bucket by bucket; then the results
+        unsigned int* w_cnt = reinterpret_cast<unsigned int*>(s_rec + kSort2BinCap);
         constexpr int kE = kSort2BinCap / kWave;   // entries per lane
         constexpr int kF = kSort2Fine / kWave;     // fine-bucket counters per lane
         // the points of a wave's NEXT bin are requested before the current one is sorted: their HBM
         // latency hides behind the sort
-        double nx_ph[kE];
-        unsigned int nx_idx[kE];
+        unsigned long long nx_rec[kE];
         {
             const int b = wave;
             const unsigned int first = b < B ? g_start[b] : 0u;
             const int m = b < B ? (int)(g_start[b + 1] - first) : 0;
 #pragma unroll
-            for (int e = 0; e < kE; ++e) {
-                const int j = lane + e * kWave;
-                nx_ph[e] = j < m ? g_ph[first + j] : 0.0;
-                nx_idx[e] = j < m ? g_idx[first + j] : 0u;
-            }
+            for (int e = 0; e < kE; ++e) nx_rec[e] = lane + e * kWave < m ? g_rec[first + lane + e * kWave] : 0ull;
         }
+        const double key_scale = (double)kSort2Fine * B_d / 4294967296.0;   // fine buckets per key unit
         for (int b0 = 0; b0 < B; b0 += nw) {
             const int b = b0 + wave;
             const unsigned int first = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b < B ? g_start[b] : 0u));
@@ -1804,39 +1797,31 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 #ifdef TLS_DEBUG_CHECKS
             if (dbg_check && !(m <= kSort2BinCap) && lane == 0) atomicAdd(&dbg_check[kChkSortWindow], 1ull);
 #endif
-            double ph[kE];
-            unsigned int id[kE];
+            unsigned long long rec[kE];
             double yv[kE];
             [[maybe_unused]] double wv[HAS_W ? kE : 1];
-            int fb[kE];   // fine bucket of a point inside its coarse bin: monotone in the phase
+            int fb[kE];   // fine bucket of a point inside its coarse bin: monotone in the key
 #pragma unroll
-            for (int e = 0; e < kE; ++e) {
-                ph[e] = nx_ph[e];
-                id[e] = nx_idx[e];
-            }
+            for (int e = 0; e < kE; ++e) rec[e] = nx_rec[e];
 #pragma unroll
             for (int e = 0; e < kF; ++e) w_cnt[lane + e * kWave] = 0;
             if (y_gather) {
 #pragma unroll
-                for (int e = 0; e < kE; ++e) if (e < e_used) yv[e] = y_gather[id[e]];       // (index 0 in the unused lanes)
+                for (int e = 0; e < kE; ++e) if (e < e_used) yv[e] = y_gather[(unsigned int)rec[e]];       // (index 0 in the unused lanes)
                 if constexpr (HAS_W) {
 #pragma unroll
-                    for (int e = 0; e < kE; ++e) if (e < e_used) wv[e] = w_gather[id[e]];
+                    for (int e = 0; e < kE; ++e) if (e < e_used) wv[e] = w_gather[(unsigned int)rec[e]];
                 }
             }
 #pragma unroll
-            for (int e = 0; e < kE; ++e) {
-                if (e * kWave < m_n) {
-                    const int j = lane + e * kWave;
-                    nx_ph[e] = j < m_n ? g_ph[first_n + j] : 0.0;
-                    nx_idx[e] = j < m_n ? g_idx[first_n + j] : 0u;
-                }
-            }
+            for (int e = 0; e < kE; ++e)
+                if (e * kWave < m_n) nx_rec[e] = lane + e * kWave < m_n ? g_rec[first_n + lane + e * kWave] : 0ull;
+            const double key_lo = (double)b * (4294967296.0 / B_d);   // about the smallest key of the bin
 #pragma unroll
             for (int e = 0; e < kE; ++e) {
                 fb[e] = 0;
                 if (e < e_used) {
-                    const int f = (int)((ph[e] * B_d - (double)b) * (double)kSort2Fine);
+                    const int f = (int)(((double)(unsigned int)(rec[e] >> 32) - key_lo) * key_scale);
                     fb[e] = f < 0 ? 0 : (f < kSort2Fine - 1 ? f : kSort2Fine - 1);
                 }
             }
@@ -1870,14 +1855,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 }
             }
 #pragma unroll
-            for (int e = 0; e < kE; ++e) {
-                if (e < e_used) {
-                    if (lane + e * kWave < m) {
-                        s_ph[lo[e] + (int)tk[e]] = ph[e];
-                        s_idx[lo[e] + (int)tk[e]] = id[e];
-                    }
-                }
-            }
+            for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_rec[lo[e] + (int)tk[e]] = rec[e]; }
             wave_lds_sync();
 #pragma unroll
             for (int e = 0; e < kE; ++e) longest = len[e] > longest ? len[e] : longest;
@@ -1886,22 +1864,28 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 #pragma unroll
                 for (int h = 0; h < kE; h += kHalf) {
                     if (h < e_used) {
-                        double ph2[kHalf];
+                        unsigned long long rec2[kHalf];
 #pragma unroll
-                        for (int e = 0; e < kHalf; ++e) ph2[e] = s_ph[sidx < len[h + e] ? lo[h + e] + sidx : 0];
+                        for (int e = 0; e < kHalf; ++e) rec2[e] = s_rec[sidx < len[h + e] ? lo[h + e] + sidx : 0];
                         bool tie = false;
 #pragma unroll
                         for (int e = 0; e < kHalf; ++e) {
                             const bool in = sidx < len[h + e];
-                            rank[h + e] += (in && ph2[e] < ph[h + e]) ? 1 : 0;
-                            tie |= in && ph2[e] == ph[h + e] && sidx != (int)tk[h + e];   // (its own entry aside)
+                            const bool same_key = (unsigned int)(rec2[e] >> 32) == (unsigned int)(rec[h + e] >> 32);
+                            rank[h + e] += (in && !same_key && rec2[e] < rec[h + e]) ? 1 : 0;
+                            tie |= in && same_key && rec2[e] != rec[h + e];   // (its own entry aside)
                         }
-                        if (__ballot(tie) != 0ull) {   // equal phases (rare): the index decides, as in a stable sort
+                        if (__ballot(tie) != 0ull) {
+                            // equal 32-bit keys (rare): the exact phases decide, then the index -- a stable sort
 #pragma unroll
                             for (int e = 0; e < kHalf; ++e) {
                                 const bool in = sidx < len[h + e];
-                                const unsigned int id2 = s_idx[in ? lo[h + e] + sidx : 0];
-                                rank[h + e] += (in && ph2[e] == ph[h + e] && id2 < id[h + e]) ? 1 : 0;
+                                const bool same_key = (unsigned int)(rec2[e] >> 32) == (unsigned int)(rec[h + e] >> 32);
+                                if (in && same_key && rec2[e] != rec[h + e]) {
+                                    const unsigned int i1 = (unsigned int)rec[h + e], i2 = (unsigned int)rec2[e];
+                                    const double p1 = fold_phase(t[i1], period, epoch), p2 = fold_phase(t[i2], period, epoch);
+                                    rank[h + e] += (p2 < p1 || (p2 == p1 && i2 < i1)) ? 1 : 0;
+                                }
                             }
                         }
                     }
@@ -1913,35 +1897,31 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
             // them (the compiler's vmcnt(0) whenever stores are pending) would expose their round trip.
             vmem_wait_all();
             wave_lds_sync();   // every lane is done with the bucket lists: the window now carries the results
-            // in rank order through the window, out as coalesced stores (the bin's phases are all in
+            // in rank order through the window, out as coalesced stores (the bin's records are all in
             // registers: their slab entries may go)
             if (perm) {
+                unsigned int* s_out = reinterpret_cast<unsigned int*>(s_rec);
 #pragma unroll
-                for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_idx[lo[e] + rank[e]] = id[e]; }
+                for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_out[lo[e] + rank[e]] = (unsigned int)rec[e]; }
+                wave_lds_sync();
+#pragma unroll
+                for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) perm[first + lane + e * kWave] = s_out[lane + e * kWave]; }
+                wave_lds_sync();
             }
             if (y_gather) {
+                double* s_out = reinterpret_cast<double*>(s_rec);
 #pragma unroll
-                for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_ph[lo[e] + rank[e]] = yv[e]; }
-            }
-            wave_lds_sync();
+                for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_out[lo[e] + rank[e]] = yv[e]; }
+                wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < kE; ++e) {
-                if (e < e_used) {
-                    const int j = lane + e * kWave;
-                    if (j < m) {
-                        if (perm) perm[first + j] = s_idx[j];
-                        if (y_gather) g_ph[first + j] = s_ph[j];
-                    }
-                }
-            }
-            if constexpr (HAS_W) {
-                if (y_gather) {
+                for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) f_out[first + lane + e * kWave] = s_out[lane + e * kWave]; }
+                if constexpr (HAS_W) {
                     wave_lds_sync();
 #pragma unroll
-                    for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_ph[lo[e] + rank[e]] = wv[e]; }
+                    for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) s_out[lo[e] + rank[e]] = wv[e]; }
                     wave_lds_sync();
 #pragma unroll
-                    for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) w_out_g[first + lane + e * kWave] = s_ph[lane + e * kWave]; }
+                    for (int e = 0; e < kE; ++e) if (e < e_used) { if (lane + e * kWave < m) w_out_g[first + lane + e * kWave] = s_out[lane + e * kWave]; }
                 }
             }
             wave_lds_sync();
@@ -1960,17 +1940,18 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 // The arguments arrive in vector registers: the uniform ones are moved back to scalars, the LDS pointer to
 // its address space.  Keeps its own phase clock.
 template <bool HAS_W>
-__device__ __noinline__ bool fold_and_sort_tiled_call(global_ptr<const double> t, int n, double period, global_ptr<double> g_ph,
-                                                      global_ptr<unsigned int> g_idx, global_ptr<unsigned int> perm,
+__device__ __noinline__ bool fold_and_sort_tiled_call(global_ptr<const double> t, int n, double period,
+                                                      global_ptr<unsigned long long> g_rec, global_ptr<unsigned int> perm,
                                                       unsigned int lds_addr, global_ptr<unsigned long long> clock_out,
                                                       global_ptr<const double> y_gather, global_ptr<const double> w_gather,
-                                                      global_ptr<double> w_out_g, global_ptr<unsigned long long> dbg_check) {
+                                                      global_ptr<double> f_out, global_ptr<double> w_out_g,
+                                                      global_ptr<unsigned long long> dbg_check) {
     PhaseClock pc; pc.start(from_global_arg(clock_out));
     typedef __attribute__((address_space(3))) unsigned char* lds_t;
     unsigned char* lds = (unsigned char*)(lds_t)(uintptr_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)lds_addr);
-    return fold_and_sort_tiled<HAS_W>(from_global_arg(t), uniform_i32(n), uniform_f64(period), 0.0, from_global_arg(g_ph),
-                                from_global_arg(g_idx), from_global_arg(perm), lds, pc, from_global_arg(y_gather),
-                                from_global_arg(w_gather), from_global_arg(w_out_g), from_global_arg(dbg_check));
+    return fold_and_sort_tiled<HAS_W>(from_global_arg(t), uniform_i32(n), uniform_f64(period), 0.0, from_global_arg(g_rec),
+                                      from_global_arg(perm), lds, pc, from_global_arg(y_gather), from_global_arg(w_gather),
+                                      from_global_arg(f_out), from_global_arg(w_out_g), from_global_arg(dbg_check));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2016,9 +1997,6 @@ __host__ __device__ constexpr long long sort3_scratch_doubles(int n) {   // pass
 }
 
 // 32-bit fixed-point phase: monotone in the phase, uniform resolution 2^-32
-__device__ __forceinline__ unsigned int phase_key(double ph) {
-    return ph < 1.0 ? (unsigned int)(ph * 4294967296.0) : 0xffffffffu;
-}
 
 // exclusive prefix sum of cnt[0..nb) (LDS) in place, nb <= 8 * blockDim.x; two LDS barriers
 __device__ __forceinline__ void block_exclusive_scan8(unsigned int* cnt, int nb, unsigned int* wsum, int tid) {
@@ -2464,11 +2442,11 @@ tls_search_kernel(const SearchArgs a) {
                 typedef global_ptr<unsigned long long> gull;
                 // (one light curve: the flux is gathered on the way and no permutation is written)
                 // (one light curve: the flux is gathered on the way and no permutation is written)
-                sorted = fold_and_sort_tiled_call<!UNIFORM_W>((gcd)a.t, n, period, (gd)ph_orig, (gu) reinterpret_cast<unsigned int*>(idx_tmp),
+                sorted = fold_and_sort_tiled_call<!UNIFORM_W>((gcd)a.t, n, period, (gull) reinterpret_cast<unsigned long long*>(regA),
                                                               (gu)(a.n_curves == 1 ? nullptr : reinterpret_cast<unsigned int*>(perm)),
                                                               lds_address(smem + a.hdr_bytes), (gull)a.phase_cycles,
                                                               (gcd)(a.n_curves == 1 ? a.y : nullptr), (gcd)(UNIFORM_W ? nullptr : a.w),
-                                                              (gd)regW, (gull)a.check);
+                                                              (gd)regA, (gd)regW, (gull)a.check);
                 pc.start(a.phase_cycles);   // (the call kept its own clock)
             }
         }
