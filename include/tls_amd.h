@@ -119,6 +119,10 @@ int tls_debug_phase_cycles(tls_ctx *ctx, uint64_t *cycles, int n);
  * sum (numpy.cumsum order, helpers.py:72) on an arbitrary series of non-negative values;
  * out has count + 1 entries, out[0] = 0. */
 int tls_debug_cumsum(tls_ctx *ctx, const double *f, int64_t count, double *out, int threads);
+/* developer/test entry: runs the prepared search once more and returns, for every period of the plan, the
+ * folded flux y[argsort(phase, stable)] exactly as the kernel's sort left it (core.py:120-123) -- the direct
+ * check of the sort order, ties included; out holds n_periods * n doubles (capacity in doubles). */
+int tls_debug_folded(tls_ctx *ctx, double *out, int64_t capacity);
 /* developer instrumentation: the debug build (make -C tls_amd/csrc debug) tests every hand-computed
  * bound of the search kernel on the device and counts violations per check (names in
  * tls_amd/_lib.py::check_counts); returns 1 from a checked build, 0 (all counts zero) otherwise. */

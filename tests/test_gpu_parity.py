@@ -282,9 +282,9 @@ def test_commensurate_periods_cluster_the_phases(gpu, oracle_lib):
 
 
 def test_tiled_sort_ties_order_and_clustered_phases(gpu, oracle_lib):
-    """The HBM-slab variant sorts in two levels (fold_and_sort_tiled): unsorted input, exact ties and
-    its fallback (phases piled into a few bins by periods commensurate with the cadence) must all
-    give the stable order of the reference."""
+    """The HBM-slab variant sorts in two levels (fold_and_sort_tiled) on 32-bit phase keys: unsorted input,
+    exact ties, equal keys with different phases, and its fallback (phases piled into a few bins by periods
+    commensurate with the cadence) must all give the stable order of the reference."""
     n = 19440
     t = 3.0 + numpy.arange(n) / 720.0            # exact binary-friendly 2-min cadence
     rng = numpy.random.RandomState(3)
@@ -294,6 +294,10 @@ def test_tiled_sort_ties_order_and_clustered_phases(gpu, oracle_lib):
     t, y = t[shuffle], y[shuffle]
     t[500:520] = t[500]                           # exact ties
     t[9000] = t[42]
+    # near ties: phases closer than 2^-32, i.e. equal 32-bit sort keys with different exact phases, stored in an
+    # order that is neither their phase order nor their index order
+    t[1300:1310] = t[77] + numpy.array([7, 2, 9, 1, 4, 8, 3, 6, 5, 0]) * 2.0 ** -36
+    t[15000] = t[1300] - 2.0 ** -37
     inp = synthetic.search_inputs(t, y, period_max=9.0)
     periods = numpy.sort(numpy.concatenate([inp["periods"][::120], [0.025, 0.05, 0.75, 1.0, 2.5, 3.7, 8.0]]))  # 0.025, 0.05: 18 and 36 distinct phases -> the fallback
     got = gpu.search(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"], count_work=True)
@@ -301,6 +305,40 @@ def test_tiled_sort_ties_order_and_clustered_phases(gpu, oracle_lib):
     want = oracle_search(oracle_lib, inp, periods=periods)
     assert_parity(got, want, len(inp["t"]))
     assert got[3]["evaluated_cells"] == int(want[3][1])
+
+
+def _folded_reference(t, y, period):
+    """core.py:15-18 + 120-123: phases by IEEE division, stable argsort, gather."""
+    x = t / period
+    phases = x - numpy.floor(x)
+    return y[numpy.argsort(phases, kind="mergesort")]
+
+
+@pytest.mark.parametrize("path", ["resident", "slab", "slab_fused", "slab_weighted"])
+def test_sort_order_is_the_stable_argsort_bit_for_bit(gpu, path, monkeypatch):
+    """The folded flux as the kernel's sort leaves it (tls_debug_folded) against numpy's stable argsort of the
+    same phases, element by element: unsorted input, exact ties, phases closer than the 2^-32 resolution of the
+    slab sort's keys, periods that pile the phases into a few bins (the general fallback path)."""
+    rng = numpy.random.RandomState(17)
+    n = 4320 if path == "resident" else 19440
+    t = 3.0 + numpy.arange(n) / (48.0 if path == "resident" else 720.0)
+    y = 1 + rng.normal(0, 2e-4, n)
+    shuffle = rng.permutation(n)
+    t, y = t[shuffle], y[shuffle]
+    t[500:520] = t[500]                                                    # exact ties
+    t[1300:1310] = t[77] + numpy.array([7, 2, 9, 1, 4, 8, 3, 6, 5, 0]) * 2.0 ** -36   # equal keys, different phases
+    t[n // 2] = t[1300] - 2.0 ** -37
+    t[n // 3] = t[42]
+    dy = rng.uniform(1e-4, 3e-4, n) if path == "slab_weighted" else None
+    if path == "slab_fused":
+        monkeypatch.setenv("TLS_SORT3", "1")
+    inp = synthetic.search_inputs(t, y, dy=dy, period_max=9.0)
+    periods = numpy.sort(numpy.concatenate([inp["periods"][::300], [0.025, 0.05, 0.75, 1.0, 2.5, 3.7, 8.0]]))
+    gpu.prepare(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
+    assert gpu.plan_info()["resident"] == (path == "resident")
+    got = gpu.folded(len(periods), n)
+    for k, period in enumerate(periods):
+        numpy.testing.assert_array_equal(got[k], _folded_reference(inp["t"], inp["y"], period), err_msg="period %r" % period)
 
 
 def test_bad_arguments_raise(gpu):

@@ -313,7 +313,7 @@ hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
     return hipGetLastError();
 }
 
-int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
+int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* debug_folded = nullptr) {
     if (count_work)
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
     tlsdev::SearchArgs a;
@@ -331,6 +331,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false) {
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_phase.ptr, 0, tlsdev::kPhases * sizeof(unsigned long long), ctx->stream));
         a.phase_cycles = ctx->d_phase.ptr;
     }
+    a.debug_folded = debug_folded;
     a.check = nullptr; a.lds_bytes = (long long)ctx->lds_bytes;
 #ifdef TLS_DEBUG_CHECKS
     if (!ctx->d_check.ptr) {
@@ -802,6 +803,24 @@ int tls_spectra(tls_ctx* ctx, const double* chi2, int64_t n, int64_t kernel, dou
         TLS_HIP(ctx, hipMemcpyAsync(out_sde, a.sde, 16, hipMemcpyDeviceToHost, ctx->stream));
     }
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TLS_OK;
+}
+
+int tls_debug_folded(tls_ctx* ctx, double* out, int64_t capacity) {
+    if (!ctx || !out) return fail(ctx, TLS_E_ARG, "bad argument");
+    if (!ctx->prepared) return fail(ctx, TLS_E_STATE, "tls_debug_folded before tls_prepare");
+    const int64_t need = ctx->n_periods * ctx->n;
+    if (capacity < need) return fail(ctx, TLS_E_ARG, "tls_debug_folded: out holds fewer than n_periods * n doubles");
+    if (need == 0) return TLS_OK;
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<double> d_out;
+    TLS_HIP(ctx, d_out.reserve((size_t)need));
+    int rc = enqueue(ctx, false, false, d_out.ptr);
+    if (rc) { d_out.release(); return rc; }
+    ctx->executed = true;
+    TLS_HIP(ctx, hipMemcpyAsync(out, d_out.ptr, (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    d_out.release();
     return TLS_OK;
 }
 

@@ -441,6 +441,7 @@ struct SearchArgs {
     int sort2;                  // tiled variant: use fold_and_sort_tiled (its LDS fits)
     int sort3;                  // tiled variant, one light curve: fold_sort_cumsum_tiled
     unsigned long long* sort3_scratch;   // [blocks][sort3_scratch_doubles(n)] pass-1 output of that path
+    double* debug_folded;                // test entry (tls_debug_folded): [n_periods][n] folded flux of every period, or nullptr
     int n_curves;               // >= 1; curve c reads y + c*n (w + c*n), writes out_* + c*n_periods
     const double* curve_S0;     // [n_curves] S0 per curve (n_curves > 1; else S0 / w0 below)
     const double* curve_w0;     // [n_curves]
@@ -1785,7 +1786,11 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 #pragma unroll
             for (int e = 0; e < kE; ++e) nx_rec[e] = lane + e * kWave < m ? g_rec[first + lane + e * kWave] : 0ull;
         }
-        const double key_scale = (double)kSort2Fine * B_d / 4294967296.0;   // fine buckets per key unit
+        // fine bucket of a key inside its coarse bin: INTEGER arithmetic -- points with equal keys must land in the
+        // same bucket, and a floating-point expression evaluated in several unrolled places need not round alike
+        // (contraction is per instance): two of four equal phases on a bucket boundary were ordered by bucket.
+        const unsigned int fine_per_key = (unsigned int)kSort2Fine * (unsigned int)B;   // buckets per 2^32 keys
+        const unsigned int keys_per_bin = 0xffffffffu / (unsigned int)B;                // (rounded down: any value common to the bin serves)
         for (int b0 = 0; b0 < B; b0 += nw) {
             const int b = b0 + wave;
             const unsigned int first = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b < B ? g_start[b] : 0u));
@@ -1816,13 +1821,14 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 #pragma unroll
             for (int e = 0; e < kE; ++e)
                 if (e * kWave < m_n) nx_rec[e] = lane + e * kWave < m_n ? g_rec[first_n + lane + e * kWave] : 0ull;
-            const double key_lo = (double)b * (4294967296.0 / B_d);   // about the smallest key of the bin
+            const unsigned int key_lo = (unsigned int)(b < B ? b : 0) * keys_per_bin;   // about the smallest key of the bin
 #pragma unroll
             for (int e = 0; e < kE; ++e) {
                 fb[e] = 0;
                 if (e < e_used) {
-                    const int f = (int)(((double)(unsigned int)(rec[e] >> 32) - key_lo) * key_scale);
-                    fb[e] = f < 0 ? 0 : (f < kSort2Fine - 1 ? f : kSort2Fine - 1);
+                    const unsigned int key = (unsigned int)(rec[e] >> 32);
+                    const unsigned int f = key > key_lo ? __umulhi(key - key_lo, fine_per_key) : 0u;   // monotone in the key
+                    fb[e] = f < (unsigned int)(kSort2Fine - 1) ? (int)f : kSort2Fine - 1;
                 }
             }
             wave_lds_sync();
@@ -2486,6 +2492,10 @@ tls_search_kernel(const SearchArgs a) {
             for (int g = 0; g < kG; ++g) if (k0 + g * nt < n) regA[k0 + g * nt] = v[g];
         }
         __syncthreads();
+        if (a.debug_folded && curve == 0) {   // test entry: the folded flux as the sort left it (core.py:120-123)
+            for (int k = tid; k < n; k += nt) a.debug_folded[(long long)p * n + k] = regA[k];
+            __syncthreads();
+        }
         // ---- phase 2: patch (core.py:126-132) and sequential cumsum ----------------
         if (RESIDENT) {   // (the slab keeps the folded series once; its patch is an index mapping)
             for (int k = tid; k < W; k += nt) {
