@@ -123,6 +123,10 @@ int tls_debug_cumsum(tls_ctx *ctx, const double *f, int64_t count, double *out, 
  * folded flux y[argsort(phase, stable)] exactly as the kernel's sort left it (core.py:120-123) -- the direct
  * check of the sort order, ties included; out holds n_periods * n doubles (capacity in doubles). */
 int tls_debug_folded(tls_ctx *ctx, double *out, int64_t capacity);
+/* developer/test entry: likewise the prefix sum C[0..M] of the patched folded flux of every period
+ * (helpers.py:72 numpy.cumsum order, core.py:126 patch), M = n + widest window; *row_length = M + 1 (out may be
+ * NULL to query it), out holds n_periods * row_length doubles. */
+int tls_debug_prefix(tls_ctx *ctx, double *out, int64_t capacity, int64_t *row_length);
 /* developer instrumentation: the debug build (make -C tls_amd/csrc debug) tests every hand-computed
  * bound of the search kernel on the device and counts violations per check (names in
  * tls_amd/_lib.py::check_counts); returns 1 from a checked build, 0 (all counts zero) otherwise. */

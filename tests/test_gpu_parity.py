@@ -317,7 +317,7 @@ def _folded_reference(t, y, period):
 @pytest.mark.parametrize("path", ["resident", "slab", "slab_fused", "slab_weighted"])
 def test_sort_order_is_the_stable_argsort_bit_for_bit(gpu, path, monkeypatch):
     """The folded flux as the kernel's sort leaves it (tls_debug_folded) against numpy's stable argsort of the
-    same phases, element by element: unsorted input, exact ties, phases closer than the 2^-32 resolution of the
+    same phases, and the prefix sum the predicate reads (tls_debug_prefix) against numpy.cumsum, element by element: unsorted input, exact ties, phases closer than the 2^-32 resolution of the
     slab sort's keys, periods that pile the phases into a few bins (the general fallback path)."""
     rng = numpy.random.RandomState(17)
     n = 4320 if path == "resident" else 19440
@@ -339,6 +339,14 @@ def test_sort_order_is_the_stable_argsort_bit_for_bit(gpu, path, monkeypatch):
     got = gpu.folded(len(periods), n)
     for k, period in enumerate(periods):
         numpy.testing.assert_array_equal(got[k], _folded_reference(inp["t"], inp["y"], period), err_msg="period %r" % period)
+    # ... and the prefix sum the depth predicate reads: numpy.cumsum of the patched series (core.py:126, helpers.py:72)
+    C = gpu.prefix_sums(len(periods))
+    W = C.shape[1] - 1 - n
+    assert W > 0 and W % 2 == 0
+    for k, period in enumerate(periods):
+        f = _folded_reference(inp["t"], inp["y"], period)
+        want = numpy.cumsum(numpy.insert(numpy.append(f, f[:W]), 0, 0))
+        numpy.testing.assert_array_equal(C[k], want, err_msg="prefix sum, period %r" % period)
 
 
 def test_bad_arguments_raise(gpu):

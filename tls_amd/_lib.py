@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("TLS_AMD_LIB") or os.path.join(_HERE, "libtls_amd.so")
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
     "tls_device_name", "tls_search", "tls_search_batch", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_check_counts",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
     "tls_comm_barrier", "tls_comm_max",
@@ -108,6 +108,8 @@ def load():
     lib.tls_spectra.argtypes = [vp, _c_double_p, i64, i64, _c_double_p, _c_double_p, _c_double_p, _c_double_p]
     lib.tls_debug_folded.restype = ci
     lib.tls_debug_folded.argtypes = [vp, _c_double_p, i64]
+    lib.tls_debug_prefix.restype = ci
+    lib.tls_debug_prefix.argtypes = [vp, _c_double_p, i64, ctypes.POINTER(ctypes.c_int64)]
     lib.tls_debug_cumsum.restype = ci
     lib.tls_debug_cumsum.argtypes = [vp, _c_double_p, i64, _c_double_p, ci]
     lib.tls_grid_cells.restype = ci
@@ -304,6 +306,14 @@ class Context(object):
         kernel's sort left it."""
         out = numpy.empty((int(n_periods), int(n)), dtype=numpy.float64)
         self._check(self._lib.tls_debug_folded(self._h, _dp(out), out.size))
+        return out
+
+    def prefix_sums(self, n_periods):
+        """Developer/test entry: the prefix sum C[0..M] of the patched folded flux of every period, (n_periods, M + 1)."""
+        row = ctypes.c_int64(0)
+        self._check(self._lib.tls_debug_prefix(self._h, None, 0, ctypes.byref(row)))
+        out = numpy.empty((int(n_periods), int(row.value)), dtype=numpy.float64)
+        self._check(self._lib.tls_debug_prefix(self._h, _dp(out), out.size, ctypes.byref(row)))
         return out
 
     def phase_cycles(self):

@@ -313,7 +313,7 @@ hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
     return hipGetLastError();
 }
 
-int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* debug_folded = nullptr) {
+int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* debug_folded = nullptr, double* debug_prefix = nullptr) {
     if (count_work)
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
     tlsdev::SearchArgs a;
@@ -331,7 +331,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_phase.ptr, 0, tlsdev::kPhases * sizeof(unsigned long long), ctx->stream));
         a.phase_cycles = ctx->d_phase.ptr;
     }
-    a.debug_folded = debug_folded;
+    a.debug_folded = debug_folded; a.debug_prefix = debug_prefix;
     a.check = nullptr; a.lds_bytes = (long long)ctx->lds_bytes;
 #ifdef TLS_DEBUG_CHECKS
     if (!ctx->d_check.ptr) {
@@ -816,6 +816,26 @@ int tls_debug_folded(tls_ctx* ctx, double* out, int64_t capacity) {
     DevBuf<double> d_out;
     TLS_HIP(ctx, d_out.reserve((size_t)need));
     int rc = enqueue(ctx, false, false, d_out.ptr);
+    if (rc) { d_out.release(); return rc; }
+    ctx->executed = true;
+    TLS_HIP(ctx, hipMemcpyAsync(out, d_out.ptr, (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    d_out.release();
+    return TLS_OK;
+}
+
+int tls_debug_prefix(tls_ctx* ctx, double* out, int64_t capacity, int64_t* row_length) {
+    if (!ctx || !row_length) return fail(ctx, TLS_E_ARG, "bad argument");
+    if (!ctx->prepared) return fail(ctx, TLS_E_STATE, "tls_debug_prefix before tls_prepare");
+    *row_length = ctx->M + 1;
+    if (!out) return TLS_OK;   // size query
+    const int64_t need = ctx->n_periods * (ctx->M + 1);
+    if (capacity < need) return fail(ctx, TLS_E_ARG, "tls_debug_prefix: out holds fewer than n_periods * row_length doubles");
+    if (need == 0) return TLS_OK;
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<double> d_out;
+    TLS_HIP(ctx, d_out.reserve((size_t)need));
+    int rc = enqueue(ctx, false, false, nullptr, d_out.ptr);
     if (rc) { d_out.release(); return rc; }
     ctx->executed = true;
     TLS_HIP(ctx, hipMemcpyAsync(out, d_out.ptr, (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));

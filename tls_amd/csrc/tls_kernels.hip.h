@@ -442,6 +442,7 @@ struct SearchArgs {
     int sort3;                  // tiled variant, one light curve: fold_sort_cumsum_tiled
     unsigned long long* sort3_scratch;   // [blocks][sort3_scratch_doubles(n)] pass-1 output of that path
     double* debug_folded;                // test entry (tls_debug_folded): [n_periods][n] folded flux of every period, or nullptr
+    double* debug_prefix;                // test entry (tls_debug_prefix): [n_periods][M + 1] prefix sum C of every period, or nullptr
     int n_curves;               // >= 1; curve c reads y + c*n (w + c*n), writes out_* + c*n_periods
     const double* curve_S0;     // [n_curves] S0 per curve (n_curves > 1; else S0 / w0 below)
     const double* curve_w0;     // [n_curves]
@@ -2565,6 +2566,10 @@ tls_search_kernel(const SearchArgs a) {
         // sentinels (possible for widths below kR) still sees a huge positive sum.
         for (int k = tid; k < region_pad; k += nt) regB[M + 1 + k] = (double)(k + 1) * 1.0e300;
         __syncthreads();
+        if (a.debug_prefix && curve == 0) {   // test entry: C as the predicate will read it (helpers.py:72)
+            for (int k = tid; k <= M; k += nt) a.debug_prefix[(long long)p * (M + 1) + k] = regB[k];
+            __syncthreads();
+        }
         pc.mark(5);
         // e = 1 - f in place (uniform weights) or e*w (general weights); the tiled variant has done
         // it chunk by chunk above
