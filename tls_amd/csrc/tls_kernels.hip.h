@@ -1620,7 +1620,10 @@ __device__ __forceinline__ unsigned int lds_address(T* p) {
 //   lds: at least sort2_lds_bytes(n) bytes.  Returns false (all threads alike) when a coarse bin
 //   overflows its LDS window (phases piled up, e.g. a period commensurate with the cadence): the
 //   caller then falls back to fold_and_sort.
-constexpr int kSort2Chunk = 10240;    // points bucketed per pass-1 round
+#ifndef TLS_SORT2_CHUNK
+#define TLS_SORT2_CHUNK 10240
+#endif
+constexpr int kSort2Chunk = TLS_SORT2_CHUNK;    // points bucketed per pass-1 round
 constexpr int kSort2BinCap = 384;     // points one wavefront can sort in its LDS window
 #ifndef TLS_SORT2_FINE
 #define TLS_SORT2_FINE 384
@@ -1946,6 +1949,18 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 // and which loops were hit changed with unrelated edits elsewhere in the kernel).
 // The arguments arrive in vector registers: the uniform ones are moved back to scalars, the LDS pointer to
 // its address space.  Keeps its own phase clock.
+// One block of the exact prefix sum as a real function for the slab rounds (own register allocation: inlined
+// into the slab kernel its 16 elements per thread are spilled around every phase).  f and C in LDS, in place
+// (C[k+1] over f[k]); addresses as 32-bit LDS addresses.
+__device__ __noinline__ double exact_cumsum_round_call(unsigned int buf_addr, int len, double carry, unsigned int cs_addr,
+                                                       global_ptr<unsigned long long> dbg) {
+    typedef __attribute__((address_space(3))) double* lds_d;
+    typedef __attribute__((address_space(3))) Cumsum2Scratch* lds_c;
+    double* buf = (double*)(lds_d)(uintptr_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)buf_addr);
+    Cumsum2Scratch* cs = (Cumsum2Scratch*)(lds_c)(uintptr_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)cs_addr);
+    return exact_cumsum_block_inline<16, true>(buf + 1, buf, 0, uniform_i32(len), uniform_f64(carry), cs, from_global_arg(dbg));
+}
+
 template <bool HAS_W>
 __device__ __noinline__ bool fold_and_sort_tiled_call(global_ptr<const double> t, int n, double period,
                                                       global_ptr<unsigned long long> g_rec, global_ptr<unsigned int> perm,
@@ -2549,8 +2564,8 @@ tls_search_kernel(const SearchArgs a) {
                 lds_barrier();
                 pc.mark(26);
                 if (len <= 16 * nt) {
-                    carry = exact_cumsum_block_inline<16, true>(buf + 1, buf, 0, len, carry,
-                                                                reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
+                    carry = exact_cumsum_round_call(lds_address(buf), len, carry, lds_address(cumsum_scratch),
+                                                    (global_ptr<unsigned long long>)a.phase_cycles);
                 } else {   // fewer than 1024 threads: several blocks per round
                     carry = exact_cumsum<true>(buf + 1, buf, len, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles, carry);
                 }
