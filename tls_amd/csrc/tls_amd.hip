@@ -786,9 +786,9 @@ int tls_spectra(tls_ctx* ctx, const double* chi2, int64_t n, int64_t kernel, dou
     a.sde = ctx->d_spec.ptr + 3 * nn; a.n = (int)n; a.kernel = (int)kernel; a.detrend = n > 2 * kernel ? 1 : 0;
     hipLaunchKernelGGL(tlsdev::tls_spectra_head, dim3(1), dim3(1024), 0, ctx->stream, a);
     if (a.detrend) {
-        const int n_med = (int)(n - kernel + 1), threads = 256;
-        const size_t lds = (size_t)(threads + kernel) * 8;
-        hipLaunchKernelGGL(tlsdev::tls_spectra_median, dim3((unsigned)((n_med + threads - 1) / threads)), dim3(threads), lds,
+        const int n_med = (int)(n - kernel + 1), threads = 256, per = tlsdev::kMedianWindows;
+        const size_t lds = (size_t)(2 * per + kernel) * 8;
+        hipLaunchKernelGGL(tlsdev::tls_spectra_median, dim3((unsigned)((n_med + per - 1) / per)), dim3(threads), lds,
                            ctx->stream, a);
         hipLaunchKernelGGL(tlsdev::tls_spectra_tail, dim3(1), dim3(1024), 0, ctx->stream, a);
     }

@@ -3448,30 +3448,34 @@ __global__ void __launch_bounds__(1024) tls_spectra_head(const SpectraArgs a) {
     if (tid == 0) { a.sde[0] = sde_raw; if (!a.detrend) a.sde[1] = sde_raw; }
 }
 
-// one window per thread: the median of an odd window is its element of rank kernel/2
+// kMedianWindows windows per workgroup; the (window, candidate) pairs are spread over the threads: a candidate is
+// the median of its (odd) window iff exactly kernel/2 elements precede it in (value, position) order.  (One
+// window per thread walked up to kernel^2 elements serially: 0.28 ms for 9679 periods, on 38 CUs.)
+constexpr int kMedianWindows = 16;
 __global__ void __launch_bounds__(256) tls_spectra_median(const SpectraArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* w = reinterpret_cast<double*>(smem);
     const int tid = threadIdx.x, nt = blockDim.x, n = a.n, k = a.kernel;
-    const int n_med = n - k + 1, first = blockIdx.x * nt;
-    const int staged = (first + nt < n_med ? nt : n_med - first) + k - 1;
+    const int n_med = n - k + 1, first = blockIdx.x * kMedianWindows;
+    const int windows = first + kMedianWindows < n_med ? kMedianWindows : n_med - first;
+    const int staged = windows + k - 1;
+    double* w = reinterpret_cast<double*>(smem);            // [kMedianWindows + kernel - 1]
+    double* med = w + (kMedianWindows + k - 1);               // [kMedianWindows]
     for (int j = tid; j < staged; j += nt) w[j] = a.power_raw[first + j];
     __syncthreads();
-    const int i = first + tid;
-    if (i >= n_med) return;
-    const double* x = w + tid;
-    double med = x[0];
-    for (int j = 0; j < k; ++j) {
+    for (int pair = tid; pair < windows * k; pair += nt) {
+        const int i = pair / k, j = pair - i * k;
+        const double* x = w + i;
         const double xj = x[j];
         int rank = 0;
         for (int l = 0; l < k; ++l) rank += (x[l] < xj || (x[l] == xj && l < j)) ? 1 : 0;
-        if (rank == k / 2) { med = xj; break; }
+        if (rank == k / 2) med[i] = xj;   // exactly one candidate of a window has this rank
     }
+    __syncthreads();
     // helpers.py:100-108: the medians sit in the middle, the first/last one pads the edges
     const int missing = n - n_med, front = (int)((double)missing * 0.5);
-    a.power[front + i] = a.power_raw[front + i] - med;                                         // stats.py:120
-    if (i == 0) for (int j = 0; j < front; ++j) a.power[j] = a.power_raw[j] - med;
-    if (i == n_med - 1) for (int j = front + n_med; j < n; ++j) a.power[j] = a.power_raw[j] - med;
+    for (int i = tid; i < windows; i += nt) a.power[front + first + i] = a.power_raw[front + first + i] - med[i];   // stats.py:120
+    if (first == 0) for (int j = tid; j < front; j += nt) a.power[j] = a.power_raw[j] - med[0];
+    if (first + windows == n_med) for (int j = front + n_med + tid; j < n; j += nt) a.power[j] = a.power_raw[j] - med[windows - 1];
 }
 
 __global__ void __launch_bounds__(1024) tls_spectra_tail(const SpectraArgs a) {
