@@ -3,9 +3,11 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config k2_90d]
 
-N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
-(one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Rank 0
-prints ONE JSON line.
+N > 1 runs one process per GPU: either under `python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or started
+plainly as `python bench.py --gpus N`, in which case it spawns its N rank processes itself
+(tls_amd/launch.py, the counterpart of the reference's Pool, main.py:140-163).  Rank 0 prints ONE
+JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already
 resident in HBM: the full period x duration x T0 grid search of BASELINE.json's config 2 (90 d,
@@ -42,7 +44,7 @@ import numpy
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from tls_amd import _lib, rendezvous, shard, synthetic  # noqa: E402
+from tls_amd import _lib, launch, rendezvous, shard, synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6   # SURVEY.md section 7 (vector fp64, no MFMA on this path)
@@ -156,10 +158,7 @@ class Harness(object):
 
     def __init__(self, args):
         self.rank, self.world, local_rank, addr, port = rendezvous.env_layout()
-        if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                         "(--nproc-per-node %d)" % (args.gpus, args.gpus))
+        if self.world != args.gpus:   # a launcher's WORLD_SIZE wins over the flag
             args.gpus = self.world
         n_dev = _lib.device_count()
         self.ctx = _lib.Context(local_rank % max(n_dev, 1))
@@ -358,6 +357,12 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="1-GPU runs: go through the RCCL code path with a one-rank communicator")
     args = ap.parse_args()
+
+    # Started plainly (`python bench.py --gpus N`, no launcher): become the launcher.  N rank
+    # processes of this same command line, one per GPU, with the environment contract of
+    # torch.distributed.run (tls_amd/launch.py); rank 0's JSON line is this process's output.
+    if args.gpus > 1 and not launch.launched_by_a_launcher():
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     h = Harness(args)
     ctx, rank, world = h.ctx, h.rank, h.world
