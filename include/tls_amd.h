@@ -97,7 +97,10 @@ int tls_search_batch(tls_ctx *ctx, const double *t, const double *y, const doubl
                      int64_t *out_row, double *out_depth);
 
 /* ---- staged search: same result, inputs resident in HBM between the stages ------ */
-/* prepare: validate, build the device-side work list, upload everything. */
+/* prepare: validate, build the device-side work list, upload everything (one pinned staging buffer, one
+ * asynchronous copy; the call does not wait for the device).  A call with the same t, periods, template and
+ * parameters as the plan the context already holds (compared byte for byte) only replaces the flux: that is
+ * what a survey and repeated power() calls do, and it costs two passes over y and one upload. */
 int tls_prepare(tls_ctx *ctx, const double *t, const double *y, const double *dy, int64_t n,
                 const double *periods, int64_t n_periods, const tls_template *tmpl,
                 const tls_params *params);
@@ -127,6 +130,10 @@ int tls_debug_folded(tls_ctx *ctx, double *out, int64_t capacity);
  * (helpers.py:72 numpy.cumsum order, core.py:126 patch), M = n + widest window; *row_length = M + 1 (out may be
  * NULL to query it), out holds n_periods * row_length doubles. */
 int tls_debug_prefix(tls_ctx *ctx, double *out, int64_t capacity, int64_t *row_length);
+/* developer instrumentation: runs the prepared search once more and returns the shader cycles the workgroup that
+ * searched period p spent on it (one entry per period of the plan, in `periods` order): the per-period cost the
+ * shard cost model of tls_amd/shard.py is fitted to (tools/gpu_cost_model.py). */
+int tls_debug_period_cycles(tls_ctx *ctx, uint64_t *cycles, int64_t capacity);
 /* developer instrumentation: the debug build (make -C tls_amd/csrc debug) tests every hand-computed
  * bound of the search kernel on the device and counts violations per check (names in
  * tls_amd/_lib.py::check_counts); returns 1 from a checked build, 0 (all counts zero) otherwise. */
@@ -173,6 +180,13 @@ int tls_spectra(tls_ctx *ctx, const double *chi2, int64_t n, int64_t kernel, dou
 int tls_grid_cells(const double *t, int64_t n, const double *periods, int64_t n_periods,
                    const tls_template *tmpl, const tls_params *params,
                    int64_t *cells_per_period);
+/* The two data-independent cost features of every period the shard cost model uses (tls_amd/shard.py): its trial
+ * cells (as tls_grid_cells) and its expected template taps -- per in-range duration: trial positions x template
+ * length x the fraction of white-noise windows of scatter `sigma` whose mean depth exceeds transit_depth_min
+ * (core.py:58), the cells the sliding chi^2 of core.py:59-74 is evaluated for (sigma <= 0: all of them). */
+int tls_period_costs(const double *t, int64_t n, const double *periods, int64_t n_periods,
+                     const tls_template *tmpl, const tls_params *params, double sigma,
+                     int64_t *cells_per_period, double *taps_per_period);
 
 /* ---- multi-GPU: period grid sharded over ranks, one RCCL all-gather at the end --- */
 /* rank 0 creates the 128-byte id and hands it to the other ranks by any host channel */

@@ -109,6 +109,11 @@ def test_power_gpu_equals_power_with_oracle_search(monkeypatch, oracle_lib, seed
     for key in pins.SCALARS:
         numpy.testing.assert_allclose(float(got[key]), float(want[key]), rtol=1e-9, atol=1e-12, err_msg=key)
     for key in pins.ARRAYS:
+        # The spectra are (SR - mean SR) / std SR with std SR ~ 1e-3: a 1e-12 relative difference of chi^2 -- the
+        # LDS-resident kernel's fast prefix-sum mode moves the depth scale of a cell by <= 2^-52 * N (DESIGN.md
+        # section 3) -- arrives 1e3 times larger.  chi^2 itself is held to 1e-9 here and to 1e-9 against the oracle
+        # on every configuration (tests/test_gpu_parity.py).
+        atol = 2e-9 if key in ("power", "power_raw", "SR") else 1e-11
         numpy.testing.assert_allclose(numpy.asarray(got[key], dtype=float), numpy.asarray(want[key], dtype=float),
-                                      rtol=1e-9, atol=1e-11, err_msg=key)
+                                      rtol=1e-9, atol=atol, err_msg=key)
     assert int(numpy.argmin(got.chi2)) == int(numpy.argmin(want.chi2))

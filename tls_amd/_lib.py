@@ -5,7 +5,6 @@ raised as RuntimeError with the library's message.  No torch, no fallback: if th
 shared library is missing, or no GPU is usable, the error surfaces here.
 """
 import ctypes
-import hashlib
 import os
 
 import numpy
@@ -18,7 +17,7 @@ LIB_PATH = os.environ.get("TLS_AMD_LIB") or os.path.join(_HERE, "libtls_amd.so")
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
     "tls_device_name", "tls_search", "tls_search_batch", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_period_cycles",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
     "tls_comm_barrier", "tls_comm_max",
@@ -110,10 +109,14 @@ def load():
     lib.tls_debug_folded.argtypes = [vp, _c_double_p, i64]
     lib.tls_debug_prefix.restype = ci
     lib.tls_debug_prefix.argtypes = [vp, _c_double_p, i64, ctypes.POINTER(ctypes.c_int64)]
+    lib.tls_debug_period_cycles.restype = ci
+    lib.tls_debug_period_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), i64]
     lib.tls_debug_cumsum.restype = ci
     lib.tls_debug_cumsum.argtypes = [vp, _c_double_p, i64, _c_double_p, ci]
     lib.tls_grid_cells.restype = ci
     lib.tls_grid_cells.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, _c_int64_p]
+    lib.tls_period_costs.restype = ci
+    lib.tls_period_costs.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, dbl, _c_int64_p, _c_double_p]
     lib.tls_comm_unique_id.restype = ci
     lib.tls_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.tls_comm_init.restype = ci
@@ -138,11 +141,6 @@ def load():
     lib.tls_comm_max.argtypes = [vp, _c_double_p]
     _lib = lib
     return lib
-
-
-def _digest(a):
-    """128-bit content digest of an array: the key under which a prepared device plan is reused."""
-    return hashlib.blake2b(memoryview(numpy.ascontiguousarray(a)).cast("B"), digest_size=16).digest()
 
 
 def _f8(a):
@@ -172,7 +170,6 @@ class Context(object):
                                + self._lib.tls_last_error(None).decode())
         self.device = int(device)
         self._n_periods = 0
-        self._plan_key = None     # what the device currently holds a prepared plan for (see search)
 
     # -- plumbing
     def close(self):
@@ -211,29 +208,9 @@ class Context(object):
         """chi2, row, depth (and counters dict) for every period, in `periods` order.
 
         Consecutive searches on the same time stamps, period list, template table and parameters
-        (a survey, or repeated power() calls) reuse the prepared plan: only the flux and the
-        weights are replaced (tls_update_flux), the host planning and the uploads are skipped."""
-        t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)
-        key = (len(t), _digest(t), len(periods), _digest(periods),
-               _digest(_f8(table.values)), _digest(_i8(table.offset)), _digest(_i8(table.length)),
-               _digest(_i8(table.width)), _digest(_f8(table.overshoot)),
-               tuple(sorted((k, float(v)) for k, v in params.items())),
-               os.environ.get("TLS_PRUNE"), os.environ.get("TLS_PRUNE_MIN_LIVE"), os.environ.get("TLS_SORT2"),
-               os.environ.get("TLS_SORT3"))
-        reused = False
-        if key == self._plan_key and len(y) == len(t) == len(dy):
-            try:
-                self.update_flux(y, dy)
-                reused = True
-            except RuntimeError as exc:
-                # uniform dy after per-point dy (or the reverse): the prepared plan differs after all.
-                # Anything else (a HIP error) is not ours to swallow.
-                if "weight structure" not in str(exc):
-                    raise
-                reused = False
-        if not reused:
-            self.prepare(t, y, dy, periods, table, params)
-            self._plan_key = key
+        (a survey, or repeated power() calls) reuse the prepared plan: tls_prepare recognises them
+        (byte comparison inside the library) and only replaces the flux and the weights."""
+        self.prepare(t, y, dy, periods, table, params)
         self.execute(count_work=count_work)
         return self.fetch(with_counters=True)
 
@@ -246,7 +223,6 @@ class Context(object):
         dy_batch = numpy.ascontiguousarray(dy_batch, dtype=numpy.float64)
         if y_batch.ndim != 2 or y_batch.shape != dy_batch.shape or y_batch.shape[1] != len(t):
             raise ValueError("y_batch and dy_batch must both have shape [n_curves, len(t)]")
-        self._plan_key = None
         arrays, tm, pr = self._pack(table, params)
         n_c, n_p = y_batch.shape[0], len(periods)
         chi2 = numpy.empty((n_c, n_p), dtype=numpy.float64)
@@ -259,7 +235,6 @@ class Context(object):
         return chi2, row, depth
 
     def prepare(self, t, y, dy, periods, table, params):
-        self._plan_key = None
         t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)
         if not (t.ndim == y.ndim == dy.ndim == 1 and len(t) == len(y) == len(dy)):
             raise ValueError("t, y, dy must be 1-dimensional and of equal length")
@@ -319,14 +294,23 @@ class Context(object):
     def phase_cycles(self):
         """Developer instrumentation: per-phase shader-cycle sums of the last
         execute(phase_clock=True)."""
-        arr = (ctypes.c_uint64 * 32)()
-        self._check(self._lib.tls_debug_phase_cycles(self._h, arr, 32))
+        arr = (ctypes.c_uint64 * 40)()
+        self._check(self._lib.tls_debug_phase_cycles(self._h, arr, 40))
         names = ("fold_count", "scan", "scatter", "rank", "gather_patch", "cumsum", "batch_prefix",
                  "chi2", "e_convert", "predicate_strided", "cumsum_blocks", "cumsum_fallbacks",
                  "tile_staging", "predicate_dense", "cs_A", "cs_B1", "cs_B2", "cs_scan", "cs_D", "cs_E",
                  "tile_wait", "chi2_wait", "prune_e2", "prune_bounds", "prune_incumbent", "select_relist",
-                 "slab_copy_in", "slab_copy_out", "part_fold", "part_scan", "part_lds", "part_store")
+                 "slab_copy_in", "slab_copy_out", "part_fold", "part_scan", "part_lds", "part_store",
+                 "stat_live_units", "stat_kept_units", "stat_singles", "stat_batches", "stat_pruned_periods",
+                 "stat_exact_retries", "stat_38", "stat_39")
         return dict(zip(names, [int(v) for v in arr]))
+
+    def period_cycles(self):
+        """Developer instrumentation: shader cycles per period of the prepared plan (one more search)."""
+        out = numpy.zeros(self._n_periods, dtype=numpy.uint64)
+        self._check(self._lib.tls_debug_period_cycles(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                                      len(out)))
+        return out
 
     def check_counts(self):
         """(checked_build, {check name: violations}) -- device-side bound checks of the debug build."""
@@ -448,6 +432,21 @@ def grid_cells(t, periods, table, params):
     if rc != 0:
         raise RuntimeError("tls_amd error %d: %s" % (rc, lib.tls_last_error(None).decode()))
     return out
+
+
+def period_costs(t, periods, table, params, sigma):
+    """(trial cells, expected template taps) of every period: the features of the shard cost model
+    (host-only planning call, needs no GPU)."""
+    lib = load()
+    t, periods = _f8(t), _f8(periods)
+    arrays, tm, pr = Context._pack(table, params)
+    cells = numpy.zeros(len(periods), dtype=numpy.int64)
+    taps = numpy.zeros(len(periods), dtype=numpy.float64)
+    rc = lib.tls_period_costs(_dp(t), len(t), _dp(periods), len(periods), ctypes.byref(tm), ctypes.byref(pr),
+                              float(sigma), _ip(cells), _dp(taps))
+    if rc != 0:
+        raise RuntimeError("tls_amd error %d: %s" % (rc, lib.tls_last_error(None).decode()))
+    return cells, taps
 
 
 def device_count():

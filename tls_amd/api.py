@@ -20,7 +20,7 @@ from .results import transitleastsquaresresults
 from .stats import (FAP, all_transit_times, calculate_fill_factor, calculate_stretch,
                     calculate_transit_duration_in_days, count_stats, final_T0_fit,
                     intransit_stats, model_lightcurve, period_uncertainty, rp_rs_from_depth,
-                    snr_stats)
+                    snr_stats, _intransit_fluxes)
 from .template import TemplateTable, fractional_transit, get_cache
 from .validate import validate_args, validate_inputs
 
@@ -164,16 +164,18 @@ class transitleastsquares(object):
         model_lightcurve_model, model_lightcurve_time = model_lightcurve(
             transit_times, period, self.t, model_transit_single)
 
+        # (the in-transit flux of every epoch and the out-of-transit flux feed several statistics)
+        chunks = _intransit_fluxes(self.t, self.y, transit_times, transit_duration_in_days)
+        flux_ootr = self.y[~transit_mask(self.t, period, 2 * duration, T0)]
         (depth_mean_odd, depth_mean_even, depth_mean_odd_std, depth_mean_even_std,
          all_flux_intransit_odd, all_flux_intransit_even, per_transit_count, transit_depths,
          transit_depths_uncertainties) = intransit_stats(
-            self.t, self.y, transit_times, transit_duration_in_days)
+            self.t, self.y, transit_times, transit_duration_in_days, chunks=chunks)
         all_flux_intransit = numpy.concatenate([all_flux_intransit_odd, all_flux_intransit_even])
         snr_per_transit, snr_pink_per_transit = snr_stats(
             t=self.t, y=self.y, period=period, duration=duration, T0=T0,
             transit_times=transit_times, transit_duration_in_days=transit_duration_in_days,
-            per_transit_count=per_transit_count)
-        flux_ootr = self.y[~transit_mask(self.t, period, 2 * duration, T0)]
+            per_transit_count=per_transit_count, chunks=chunks, flux_ootr=flux_ootr)
         depth_mean = numpy.mean(all_flux_intransit)
         depth_mean_std = numpy.std(all_flux_intransit) / numpy.sum(per_transit_count) ** (0.5)
         snr = ((1 - depth_mean) / numpy.std(flux_ootr)) * len(all_flux_intransit) ** (0.5)

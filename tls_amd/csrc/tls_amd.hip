@@ -15,8 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tls_amd.h"
@@ -64,6 +66,28 @@ struct DevBuf {
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
+// a typed window into the context's one plan allocation (d_plan): same `.ptr` as a DevBuf, not owned
+template <typename T>
+struct View {
+    T* ptr = nullptr;
+};
+
+// what a prepared plan was built from: a second tls_prepare with the same time stamps, period list, template table,
+// parameters and developer switches only replaces the flux (the search call of a survey, or of repeated power()
+// calls).  Compared byte for byte (memcmp runs at ~10 GB/s; a cfg2 key is 120 KB).
+struct PlanLayout {   // byte offsets of the plan arrays inside d_plan / h_stage (256-byte aligned)
+    size_t t = 0, y = 0, w = 0, periods = 0, order = 0, rows = 0, widths = 0, screens = 0, q = 0, q2 = 0, total = 0;
+};
+
+struct PlanKey {
+    bool valid = false;
+    int64_t n = 0, n_periods = 0, n_rows = 0;
+    std::vector<double> t, periods, values, overshoot;
+    std::vector<int64_t> offset, length, width;
+    tls_params params = {0, 0, 0, 0, 0, 0};
+    std::string env;
+};
+
 }  // namespace
 
 struct tls_ctx {
@@ -75,12 +99,27 @@ struct tls_ctx {
     int n_cu = 0;
 
     // device-resident plan
-    DevBuf<double> d_t, d_y, d_w, d_periods, d_q, d_q2, d_chi2, d_depth, d_scratch, d_pack, d_gather, d_scalar, d_stage;
-    DevBuf<long long> d_row;
-    DevBuf<int> d_order;
-    DevBuf<tlsdev::PeriodRows> d_rows;
-    DevBuf<tlsdev::WidthEntry> d_widths;
-    DevBuf<unsigned long long> d_counters, d_phase, d_check;
+    // ONE allocation holds every plan array (views below); it is filled from ONE pinned staging buffer by ONE
+    // asynchronous copy, and tls_prepare does not wait for it
+    DevBuf<unsigned char> d_plan;
+    View<double> d_t, d_y, d_w, d_periods, d_q, d_q2;
+    View<int> d_order;
+    View<tlsdev::PeriodRows> d_rows;
+    View<tlsdev::WidthEntry> d_widths;
+    View<tlsdev::RowScreen> d_screens;
+    unsigned char* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned: the plan (tls_prepare) / the flux (tls_update_flux)
+    hipEvent_t ev_stage = nullptr; bool stage_pending = false;  // its last upload
+    // results: [chi2 | row | depth | counters[4]] in one allocation, fetched by one copy into pinned memory
+    DevBuf<double> d_out;
+    View<double> d_chi2, d_depth;
+    View<long long> d_row;
+    View<unsigned long long> d_counters;
+    double* h_out = nullptr; size_t h_out_cap = 0;
+    PlanKey key;
+    PlanLayout layout;
+    int64_t plan_reuses = 0;   // tls_prepare calls answered from the held plan
+    DevBuf<double> d_scratch, d_pack, d_gather, d_scalar, d_stage;
+    DevBuf<unsigned long long> d_phase, d_check;
     DevBuf<unsigned int> d_queue, d_squeue, d_lists, d_perm;   // d_squeue: the search kernel's self-rewinding queue
     DevBuf<double> d_curve_S0, d_curve_w0;   // survey batches
     // survey batches: two slots of device + pinned host buffers, a second stream for the transfers
@@ -116,6 +155,7 @@ struct tls_ctx {
     int threads = 512, blocks = 0;
     size_t lds_bytes = 0;
     double S0 = 0, w0 = 1, depth_min = 0;
+    double y_abs_max = 1.0;   // largest |flux| of the light curve(s) of the next launch: bounds the prefix sum (fast mode's eps)
     tls_counters plan_counters = {0, 0, 0, 0, 0};
     bool counted = false;
 
@@ -130,6 +170,9 @@ struct tls_ctx {
 };
 
 namespace {
+
+int update_flux_impl(tls_ctx* ctx, const double* y, const double* dy);
+constexpr int kWeightsDiffer = 1;
 
 int fail(tls_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg; else g_create_error = msg;
@@ -150,6 +193,61 @@ int fail(tls_ctx* ctx, int code, const std::string& msg) {
             return fail(ctx, TLS_E_RCCL, std::string(#call) + ": " + ncclGetErrorString(r_)); \
     } while (0)
 
+// the pinned staging buffer, at least `bytes` long and no longer read by an upload in flight
+int stage_reserve(tls_ctx* ctx, size_t bytes) {
+    if (!ctx->ev_stage) TLS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming));
+    if (ctx->stage_pending) { TLS_HIP(ctx, hipEventSynchronize(ctx->ev_stage)); ctx->stage_pending = false; }
+    if (ctx->h_stage_cap < bytes) {
+        if (ctx->h_stage) TLS_HIP(ctx, hipHostFree(ctx->h_stage));
+        ctx->h_stage = nullptr; ctx->h_stage_cap = 0;
+        const size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+        TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), cap, hipHostMallocDefault));
+        ctx->h_stage_cap = cap;
+    }
+    return TLS_OK;
+}
+
+std::string plan_env() {   // developer switches that change the plan
+    std::string e;
+    for (const char* name : {"TLS_PRUNE", "TLS_PRUNE_MIN_LIVE", "TLS_SORT2", "TLS_SORT3", "TLS_THREADS", "TLS_BLOCKS", "TLS_STAGE_C"}) {
+        const char* v = std::getenv(name);
+        e += v ? v : "-";
+        e += '|';
+    }
+    return e;
+}
+
+size_t template_values(const tls_template* tmpl) {
+    int64_t total = 0;
+    for (int64_t r = 0; r < tmpl->n_rows; ++r) total = std::max(total, tmpl->offset[r] + std::max<int64_t>(tmpl->length[r], 0));
+    return (size_t)std::max<int64_t>(total, 0);
+}
+
+bool key_matches(const PlanKey& k, const double* t, int64_t n, const double* periods, int64_t n_periods,
+                 const tls_template* tmpl, const tls_params* params) {
+    if (!k.valid || k.n != n || k.n_periods != n_periods || k.n_rows != tmpl->n_rows) return false;
+    if (std::memcmp(&k.params, params, sizeof(tls_params)) != 0) return false;
+    const size_t rows = (size_t)tmpl->n_rows;
+    if (std::memcmp(k.offset.data(), tmpl->offset, rows * 8) || std::memcmp(k.length.data(), tmpl->length, rows * 8) ||
+        std::memcmp(k.width.data(), tmpl->width, rows * 8) || std::memcmp(k.overshoot.data(), tmpl->overshoot, rows * 8))
+        return false;
+    if (k.values.size() != template_values(tmpl) || std::memcmp(k.values.data(), tmpl->values, k.values.size() * 8)) return false;
+    if (std::memcmp(k.t.data(), t, (size_t)n * 8) || std::memcmp(k.periods.data(), periods, (size_t)n_periods * 8)) return false;
+    return k.env == plan_env();
+}
+
+void key_store(PlanKey& k, const double* t, int64_t n, const double* periods, int64_t n_periods,
+               const tls_template* tmpl, const tls_params* params) {
+    k.n = n; k.n_periods = n_periods; k.n_rows = tmpl->n_rows; k.params = *params;
+    k.t.assign(t, t + n); k.periods.assign(periods, periods + n_periods);
+    const size_t rows = (size_t)tmpl->n_rows;
+    k.offset.assign(tmpl->offset, tmpl->offset + rows); k.length.assign(tmpl->length, tmpl->length + rows);
+    k.width.assign(tmpl->width, tmpl->width + rows); k.overshoot.assign(tmpl->overshoot, tmpl->overshoot + rows);
+    k.values.assign(tmpl->values, tmpl->values + template_values(tmpl));
+    k.env = plan_env();
+    k.valid = true;
+}
+
 template <typename T>
 int upload(tls_ctx* ctx, DevBuf<T>& buf, const T* host, size_t count) {
     TLS_HIP(ctx, buf.reserve(count));
@@ -160,7 +258,12 @@ int upload(tls_ctx* ctx, DevBuf<T>& buf, const T* host, size_t count) {
 
 // weights and the period-independent constant S0 = sum (1-y)^2 / dy^2
 void weights_from(const double* y, const double* dy, int64_t n, bool& uniform, double& w0,
-                  std::vector<double>& w, double& S0) {
+                  std::vector<double>& w, double& S0, double* y_abs_max = nullptr) {
+    if (y_abs_max) {
+        double m = 0.0;
+        for (int64_t i = 0; i < n; ++i) m = std::max(m, std::fabs(y[i]));
+        *y_abs_max = std::max(*y_abs_max, m);
+    }
     uniform = true;
     for (int64_t i = 1; i < n; ++i)
         if (dy[i] != dy[0]) { uniform = false; break; }
@@ -246,6 +349,93 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
     return TLS_OK;
 }
 
+// Piecewise-constant images of the template rows for the pruning bound (tlsdev::window_bound).  All rows are the
+// same transit shape resampled to their width (transit.py:98-160), so the segment boundaries are chosen ONCE, as
+// fractions of the row length, on the widest row: the kSeg-segment partition with the smallest sum of squared
+// deviations from the segment means (dynamic programme over <= 96 groups of taps).  Levels, telescoped
+// differences and the squared remainder are then exact sums over each row's own taps (long double, remainder
+// rounded up): the bound is rigorous for ANY boundaries, good ones only make it tight.
+void build_screens(const std::vector<tlsdev::WidthEntry>& widths, const std::vector<double>& q,
+                   std::vector<tlsdev::RowScreen>& screens) {
+    constexpr int K = tlsdev::kSeg;
+    screens.assign(widths.size(), tlsdev::RowScreen());
+    for (auto& sc : screens) { std::memset(&sc, 0, sizeof sc); }
+    if (widths.empty()) return;
+    double frac[K + 1];
+    {
+        const auto& we = widths.back();
+        const int L = we.q_len, G = std::min(L, 96);
+        const double* qr = q.data() + we.q_offset;
+        std::vector<long double> s1((size_t)G + 1, 0.0L), s2((size_t)G + 1, 0.0L);
+        std::vector<int> edge((size_t)G + 1);
+        for (int g = 0; g <= G; ++g) edge[(size_t)g] = (int)((long long)g * L / G);
+        for (int g = 0; g < G; ++g) {
+            long double a1 = 0, a2 = 0;
+            for (int j = edge[(size_t)g]; j < edge[(size_t)g + 1]; ++j) { a1 += qr[j]; a2 += (long double)qr[j] * qr[j]; }
+            s1[(size_t)g + 1] = s1[(size_t)g] + a1; s2[(size_t)g + 1] = s2[(size_t)g] + a2;
+        }
+        auto sse = [&](int a, int b) -> double {
+            const long double m = (long double)(edge[(size_t)b] - edge[(size_t)a]);
+            const long double d1 = s1[(size_t)b] - s1[(size_t)a];
+            return (double)((s2[(size_t)b] - s2[(size_t)a]) - d1 * d1 / m);
+        };
+        const int Ke = std::min(K, G);
+        std::vector<double> cost((size_t)(Ke + 1) * (G + 1), 1e300);
+        std::vector<int> arg((size_t)(Ke + 1) * (G + 1), 0);
+        cost[0] = 0.0;
+        for (int k = 1; k <= Ke; ++k)
+            for (int j = k; j <= G; ++j) {
+                double best = 1e300; int bi = k - 1;
+                for (int i = k - 1; i < j; ++i) {
+                    const double c = cost[(size_t)(k - 1) * (G + 1) + i] + sse(i, j);
+                    if (c < best) { best = c; bi = i; }
+                }
+                cost[(size_t)k * (G + 1) + j] = best; arg[(size_t)k * (G + 1) + j] = bi;
+            }
+        int at = G;
+        for (int k = K; k >= 0; --k) frac[k] = 1.0;
+        for (int k = Ke; k >= 1; --k) { frac[k] = (double)edge[(size_t)at] / L; at = arg[(size_t)k * (G + 1) + at]; }
+        frac[0] = 0.0;
+        for (int k = Ke + 1; k <= K; ++k) frac[k] = 1.0;
+    }
+    for (size_t w = 0; w < widths.size(); ++w) {
+        const auto& we = widths[w];
+        tlsdev::RowScreen& sc = screens[w];
+        const int L = we.q_len;
+        if (!we.prunable || L < tlsdev::kScreenMinLen || L < 2 * K) continue;
+        const double* qr = q.data() + we.q_offset;
+        int b[K + 1];
+        b[0] = 0;
+        for (int k = 1; k < K; ++k) b[k] = std::max(b[k - 1] + 1, (int)std::lround(frac[k] * L));
+        b[K] = L;
+        for (int k = K - 1; k >= 1; --k) b[k] = std::min(b[k], b[k + 1] - 1);
+        long double lev[K], r2 = 0.0L, sq = 0.0L;
+        for (int k = 0; k < K; ++k) {
+            long double a1 = 0.0L;
+            for (int j = b[k]; j < b[k + 1]; ++j) a1 += qr[j];
+            lev[k] = a1 / (long double)(b[k + 1] - b[k]);
+        }
+        // the device works with the levels rounded to double: remainder and sum are those of the ROUNDED levels
+        double levd[K];
+        for (int k = 0; k < K; ++k) levd[k] = (double)lev[k];
+        long double dsum = 0.0L;   // sum of the differences q - q~: zero for exact means, ~1e-17 L after rounding
+        for (int k = 0; k < K; ++k)
+            for (int j = b[k]; j < b[k + 1]; ++j) {
+                const long double dq = (long double)qr[j] - (long double)levd[k];
+                r2 += dq * dq; dsum += dq; sq += (long double)levd[k];
+            }
+        for (int k = 0; k <= K; ++k) sc.b[k] = b[k];
+        sc.g[0] = -levd[0];
+        for (int k = 1; k < K; ++k) sc.g[k] = levd[k - 1] - levd[k];
+        sc.g[K] = levd[K - 1];
+        // (g_k is the rounded difference of two doubles: the telescoped sum then equals sum_j q~'_j e_j for levels
+        // q~' within 1 ulp of levd -- absorbed by inflating the remainder; |dsum| * mean enters the same way)
+        sc.sq = (double)sq;
+        sc.r2 = (double)(r2 * (1.0L + 1e-9L)) + 1e-24 + 1e-12 * (double)fabsl(dsum);
+        sc.valid = 1;
+    }
+}
+
 // Pruning pays when most trial cells pass the depth predicate (core.py:58), i.e. when the noise of
 // a window mean, sigma/sqrt(d), is large against transit_depth_min.  Expected passing fraction of a
 // flat, white light curve, averaged over the trial widths; the pruning kernel is used above 0.25
@@ -274,24 +464,111 @@ double flux_scatter(const double* y, int64_t n) {
     return (double)std::sqrt((double)(v / (long double)n));
 }
 
-// In-range width window of one period (core.py:143-156) and its trial-cell count.
-int64_t period_window(const std::vector<tlsdev::WidthEntry>& widths, const tls_params* params, double P,
-                      double length, int64_t n, int64_t M, int& lo_out, int& hi_out, int64_t* pairs) {
-    const double duration_max = t14(params->R_star_max, params->M_star_max, P, false);
-    const double duration_min = t14(params->R_star_min, params->M_star_min, P, true);
-    const double naive = length / P;
-    const double correction = (naive + 1) / naive;
-    const double lo = std::floor(duration_min * (double)n);
-    const double hi = std::ceil(duration_max * (double)n * correction);
-    lo_out = (int)std::max(-2.0e9, std::min(2.0e9, lo));
-    hi_out = (int)std::max(-2.0e9, std::min(2.0e9, hi));
-    int64_t c = 0;
-    for (const auto& we : widths)
-        if (we.width >= lo_out && we.width <= hi_out) {
-            c += (M - we.width) / we.xth + 1;
-            if (pairs) *pairs += 1;
+// In-range width window of every period (core.py:143-156) and its trial-cell count.
+// The same for every period of a grid (what tls_prepare and tls_grid_cells need): the in-range rows [k_lo, k_hi)
+// of the ascending width table by binary search, the dense rows [k_lo, k_x), and the trial-cell count from a
+// prefix sum over the table -- per period two pow() calls (t14, kept in the reference's operation order) and a few
+// dozen instructions instead of a walk over all widths.  Long grids are cut into slices for a few host threads
+// (a Kepler-size grid of 182 388 periods: 21 ms on one core).  Returns false on a non-positive or non-finite period.
+struct GridPlan {
+    int64_t cells = 0, pairs = 0;
+};
+bool plan_periods(const std::vector<tlsdev::WidthEntry>& widths, const tls_params* params, const double* periods,
+                  int64_t n_periods, double length, int64_t n, int64_t M, tlsdev::PeriodRows* prow, int64_t* cost,
+                  GridPlan* total) {
+    const int nw = (int)widths.size();
+    std::vector<int> wd((size_t)nw);
+    std::vector<int64_t> prefix((size_t)nw + 1, 0);
+    int first_strided = nw;   // xth = int(width * margin) never decreases with the width (core.py:50-55)
+    for (int k = 0; k < nw; ++k) {
+        wd[(size_t)k] = widths[(size_t)k].width;
+        prefix[(size_t)k + 1] = prefix[(size_t)k] + ((M - widths[(size_t)k].width) / widths[(size_t)k].xth + 1);
+        if (widths[(size_t)k].xth != 1 && first_strided == nw) first_strided = k;
+    }
+    for (int k = first_strided; k < nw; ++k)
+        if (widths[(size_t)k].xth == 1) first_strided = -1;   // not monotone (cannot happen): per-row walk below
+    auto slice = [&](int64_t p0, int64_t p1, GridPlan* out, bool* ok) {
+        GridPlan g;
+        for (int64_t p = p0; p < p1; ++p) {
+            const double P = periods[p];
+            if (!(P > 0) || !std::isfinite(P)) { *ok = false; return; }
+            const double duration_max = t14(params->R_star_max, params->M_star_max, P, false);
+            const double duration_min = t14(params->R_star_min, params->M_star_min, P, true);
+            const double naive = length / P;
+            const double correction = (naive + 1) / naive;
+            const double lo = std::floor(duration_min * (double)n);
+            const double hi = std::ceil(duration_max * (double)n * correction);
+            const int dlo = (int)std::max(-2.0e9, std::min(2.0e9, lo));
+            const int dhi = (int)std::max(-2.0e9, std::min(2.0e9, hi));
+            const int k_lo = (int)(std::lower_bound(wd.begin(), wd.end(), dlo) - wd.begin());
+            const int k_hi = std::max(k_lo, (int)(std::upper_bound(wd.begin(), wd.end(), dhi) - wd.begin()));
+            int k_x = std::min(k_hi, std::max(k_lo, first_strided));
+            if (first_strided < 0) {
+                k_x = k_lo;
+                for (int k = k_lo; k < k_hi; ++k) if (widths[(size_t)k].xth == 1) k_x = k + 1;
+            }
+            const int64_t c = prefix[(size_t)k_hi] - prefix[(size_t)k_lo];
+            if (prow) { prow[p].k_lo = k_lo; prow[p].k_hi = k_hi; prow[p].k_x = k_x; prow[p].pad = 0; }
+            if (cost) cost[p] = c;
+            g.cells += c; g.pairs += k_hi - k_lo;
         }
-    return c;
+        *out = g;
+    };
+    unsigned n_threads = 1;
+    if (n_periods >= 4096) {
+        n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
+        n_threads = (unsigned)std::min<int64_t>(n_threads, n_periods / 2048);
+        if (const char* env = std::getenv("TLS_PLAN_THREADS")) n_threads = (unsigned)std::max(1, std::min(64, std::atoi(env)));
+    }
+    std::vector<GridPlan> part(n_threads);
+    std::vector<char> ok(n_threads, 1);
+    if (n_threads <= 1) {
+        bool good = true;
+        slice(0, n_periods, &part[0], &good);
+        ok[0] = good;
+    } else {
+        std::vector<std::thread> pool;
+        std::vector<bool*> flags;
+        std::unique_ptr<bool[]> good(new bool[n_threads]);
+        for (unsigned i = 0; i < n_threads; ++i) {
+            good[i] = true;
+            const int64_t p0 = n_periods * i / n_threads, p1 = n_periods * (i + 1) / n_threads;
+            pool.emplace_back(slice, p0, p1, &part[i], &good[i]);
+        }
+        for (auto& th : pool) th.join();
+        for (unsigned i = 0; i < n_threads; ++i) ok[i] = good[i];
+    }
+    for (unsigned i = 0; i < n_threads; ++i) {
+        if (!ok[i]) return false;
+        total->cells += part[i].cells; total->pairs += part[i].pairs;
+    }
+    return true;
+}
+
+// work order of the period queue: most expensive first (longest-processing-time first), ties in grid order --
+// a stable LSD radix sort of the 32-bit key (max cost - cost), three passes of 11 bits
+void order_by_cost(const std::vector<int64_t>& cost, std::vector<int>& order) {
+    const size_t np = cost.size();
+    order.resize(np);
+    int64_t cmax = 0;
+    for (size_t p = 0; p < np; ++p) cmax = std::max(cmax, cost[p]);
+    if (cmax >= (1LL << 33)) {   // (absurdly long series: comparison sort)
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+        return;
+    }
+    std::vector<unsigned long long> key(np), tmp(np);
+    for (size_t p = 0; p < np; ++p) key[p] = ((unsigned long long)(cmax - cost[p]) << 31) | (unsigned long long)p;   // p < 2^31
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = 31 + 11 * pass;
+        if (pass > 0 && (cmax >> (11 * pass)) == 0) break;
+        size_t hist[2049] = {0};
+        for (size_t p = 0; p < np; ++p) ++hist[((key[p] >> shift) & 2047u) + 1];
+        for (int b = 0; b < 2048; ++b) hist[b + 1] += hist[b];
+        for (size_t p = 0; p < np; ++p) tmp[hist[(key[p] >> shift) & 2047u]++] = key[p];
+        key.swap(tmp);
+    }
+    for (size_t p = 0; p < np; ++p) order[p] = (int)(key[p] & 0x7fffffffull);
 }
 
 template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false>
@@ -313,7 +590,8 @@ hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
     return hipGetLastError();
 }
 
-int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* debug_folded = nullptr, double* debug_prefix = nullptr) {
+int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* debug_folded = nullptr, double* debug_prefix = nullptr,
+            unsigned long long* period_cycles = nullptr) {
     if (count_work)
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_counters.ptr, 0, 3 * sizeof(unsigned long long), ctx->stream));
     tlsdev::SearchArgs a;
@@ -321,6 +599,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.w = ctx->uniform_w ? nullptr : (ctx->over_w ? ctx->over_w : ctx->d_w.ptr);
     a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.rows = ctx->d_rows.ptr;
     a.widths = ctx->d_widths.ptr; a.q = ctx->d_q.ptr; a.q2 = ctx->uniform_w ? nullptr : ctx->d_q2.ptr;
+    a.screens = ctx->d_screens.ptr;
     a.out_chi2 = ctx->over_chi2 ? ctx->over_chi2 : ctx->d_chi2.ptr;
     a.out_row = ctx->over_row ? ctx->over_row : ctx->d_row.ptr;
     a.out_depth = ctx->over_depth ? ctx->over_depth : ctx->d_depth.ptr;
@@ -331,7 +610,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_phase.ptr, 0, tlsdev::kPhases * sizeof(unsigned long long), ctx->stream));
         a.phase_cycles = ctx->d_phase.ptr;
     }
-    a.debug_folded = debug_folded; a.debug_prefix = debug_prefix;
+    a.debug_folded = debug_folded; a.debug_prefix = debug_prefix; a.period_cycles = period_cycles;
     a.check = nullptr; a.lds_bytes = (long long)ctx->lds_bytes;
 #ifdef TLS_DEBUG_CHECKS
     if (!ctx->d_check.ptr) {
@@ -344,9 +623,19 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.scratch = ctx->d_scratch.ptr;
     a.scratch_stride = (long long)(ctx->uniform_w ? 2 : 3) * ((ctx->M + 1 + ctx->region_pad + 1) & ~1);   // even regions (kernel: RS)
     a.region_pad = ctx->region_pad;
-    a.chunk_lists = ctx->d_lists.ptr; a.list_stride = 2 * (long long)ctx->list_stride; a.list_cap = (long long)ctx->list_stride;
+    a.chunk_lists = ctx->d_lists.ptr; a.list_stride = 3 * (long long)ctx->list_stride; a.list_cap = (long long)ctx->list_stride;
     a.prune_min_live = ctx->prune_min_live; a.p2_shift = ctx->p2_shift; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
+    {
+        // the sequential cumsum C of the reference (helpers.py:72) rounds by at most half an ulp of its running value
+        // per step, and C <= (n + W) * max|flux|: the two constants below follow from that (tls_kernels.hip.h,
+        // depth_pass and window_bound); both carry a factor 2 of margin
+        const double c_max = (double)ctx->M * ctx->y_abs_max;
+        a.eps_fast = 2.0 * (1.1102230246251565e-16 * c_max) + 1e-15;
+        a.slack_unit = 2.5e-16 * c_max;
+        const char* env = std::getenv("TLS_EXACT_PREFIX");
+        a.exact_prefix = (env && std::atoi(env) != 0) ? 1 : 0;
+    }
     a.sort2 = ctx->sort2 ? 1 : 0;
     a.sort3 = ctx->sort3 ? 1 : 0; a.sort3_scratch = ctx->d_sort3.ptr;
     a.n_curves = ctx->batch_curves;
@@ -430,11 +719,13 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->d_t.release(); ctx->d_y.release(); ctx->d_w.release(); ctx->d_periods.release(); ctx->d_q.release();
-    ctx->d_chi2.release(); ctx->d_depth.release(); ctx->d_scratch.release(); ctx->d_pack.release();
-    ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release(); ctx->d_row.release(); ctx->d_order.release();
-    ctx->d_rows.release(); ctx->d_widths.release(); ctx->d_counters.release();
-    ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_q2.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
+    ctx->d_plan.release(); ctx->d_out.release();
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    if (ctx->ev_stage) (void)hipEventDestroy(ctx->ev_stage);
+    ctx->d_scratch.release(); ctx->d_pack.release();
+    ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release();
+    ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     for (auto& sl : ctx->slot) {
         sl.d_y.release(); sl.d_w.release(); sl.d_S0.release(); sl.d_w0.release(); sl.d_chi2.release(); sl.d_depth.release(); sl.d_row.release();
@@ -463,6 +754,16 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         return fail(ctx, TLS_E_ARG, "empty template table");
     TLS_HIP(ctx, hipSetDevice(ctx->device));
 
+    // The same time stamps, periods, template and parameters as the plan this context already holds (a survey, or
+    // repeated power() calls): only the flux is new.  tls_prepare then costs two passes over y and one upload.
+    if (ctx->key.valid && key_matches(ctx->key, t, n, periods, n_periods, tmpl, params)) {
+        const int rcu = update_flux_impl(ctx, y, dy);
+        if (rcu == TLS_OK) { ctx->prepared = true; ++ctx->plan_reuses; return TLS_OK; }
+        if (rcu != kWeightsDiffer) return rcu;
+        // uniform dy after per-point dy (or the reverse): a different kernel variant and layout -- plan again
+    }
+    ctx->key.valid = false;
+
     std::vector<tlsdev::WidthEntry> widths;
     std::vector<double> q;
     { int rcw = build_widths(ctx, tmpl, params, n, widths, &q); if (rcw) return rcw; }
@@ -475,37 +776,24 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     // per-period duration window (core.py:143-156) and cost
     double t_min = t[0], t_max = t[0];
     for (int64_t i = 1; i < n; ++i) { t_min = std::min(t_min, t[i]); t_max = std::max(t_max, t[i]); }
-    std::vector<int> order((size_t)n_periods);
+    std::vector<int> order;
     std::vector<tlsdev::PeriodRows> prow((size_t)n_periods);
     std::vector<int64_t> cost((size_t)n_periods);
     tls_counters pc = {0, 0, 0, 0, 0};
-    const double length = t_max - t_min;
-    for (int64_t p = 0; p < n_periods; ++p) {
-        const double P = periods[p];
-        if (!(P > 0) || !std::isfinite(P)) return fail(ctx, TLS_E_ARG, "periods must be positive and finite");
-        int dlo, dhi;
-        const int64_t c = period_window(widths, params, P, length, n, M, dlo, dhi, &pc.pd_pairs);
-        // the in-range rows of the ascending width table; rows below k_x have T0 stride 1
-        tlsdev::PeriodRows& pr = prow[(size_t)p];
-        const int nw = (int)widths.size();
-        pr.k_lo = 0;
-        while (pr.k_lo < nw && widths[(size_t)pr.k_lo].width < dlo) ++pr.k_lo;
-        pr.k_hi = pr.k_x = pr.k_lo;
-        while (pr.k_hi < nw && widths[(size_t)pr.k_hi].width <= dhi) {
-            if (widths[(size_t)pr.k_hi].xth == 1) pr.k_x = pr.k_hi + 1;
-            ++pr.k_hi;
-        }
-        pr.pad = 0;
-        cost[(size_t)p] = c;
-        pc.grid_cells += c;
+    {
+        GridPlan gp;
+        if (!plan_periods(widths, params, periods, n_periods, t_max - t_min, n, M, prow.data(), cost.data(), &gp))
+            return fail(ctx, TLS_E_ARG, "periods must be positive and finite");
+        pc.grid_cells = gp.cells; pc.pd_pairs = gp.pairs;
     }
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+    order_by_cost(cost, order);
 
     // weights
     std::vector<double> w;
     bool uniform; double w0, S0;
-    weights_from(y, dy, n, uniform, w0, w, S0);
+    double y_abs_max = 0.0;
+    weights_from(y, dy, n, uniform, w0, w, S0, &y_abs_max);
+    ctx->y_abs_max = y_abs_max;
 
     // launch geometry
     const size_t regions = uniform ? 2 : 3;
@@ -642,8 +930,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         list_cap += (size_t)we.n_chunks;
     }
     ctx->list_stride = (list_cap + 63) / 64 * 64;
-    // two arrays per workgroup: the live units and (pruning) the bound of each
-    TLS_HIP(ctx, ctx->d_lists.reserve((size_t)ctx->blocks * 2 * ctx->list_stride));
+    // three arrays per workgroup: the live units, (pruning) the bound of each, and the units the bound keeps
+    TLS_HIP(ctx, ctx->d_lists.reserve((size_t)ctx->blocks * 3 * ctx->list_stride));
     if (const char* env = std::getenv("TLS_PRUNE_MIN_LIVE")) ctx->prune_min_live = std::atoll(env);
     ctx->p2_shift = 4;  // block length of the coarse prefix sum of e^2: at most kP2MaxBlocks blocks
     while ((((size_t)M + ((size_t)1 << ctx->p2_shift) - 1) >> ctx->p2_shift) > (size_t)tlsdev::kP2MaxBlocks) ++ctx->p2_shift;
@@ -655,52 +943,101 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->prune_kernel = uniform && pruning_pays(widths, flux_scatter(y, n), params->transit_depth_min, ctx->resident);
     ctx->plan_counters = pc;
 
-    int rc;
-    if ((rc = upload(ctx, ctx->d_t, t, (size_t)n))) return rc;
-    if ((rc = upload(ctx, ctx->d_y, y, (size_t)n))) return rc;
-    if (!uniform && (rc = upload(ctx, ctx->d_w, w.data(), (size_t)n))) return rc;
-    if ((rc = upload(ctx, ctx->d_periods, periods, (size_t)n_periods))) return rc;
-    if ((rc = upload(ctx, ctx->d_order, order.data(), (size_t)n_periods))) return rc;
-    if ((rc = upload(ctx, ctx->d_rows, prow.data(), (size_t)n_periods))) return rc;
-    if ((rc = upload(ctx, ctx->d_widths, widths.data(), widths.size()))) return rc;
-    if ((rc = upload(ctx, ctx->d_q, q.data(), q.size()))) return rc;
-    std::vector<double> q2;
-    if (!uniform) {
-        q2.resize(q.size());
-        for (size_t j = 0; j < q.size(); ++j) q2[j] = q[j] * q[j];
-        if ((rc = upload(ctx, ctx->d_q2, q2.data(), q2.size()))) return rc;
+    // ONE pinned staging buffer, ONE device allocation, ONE asynchronous copy; nothing is waited for here (the
+    // staging buffer is reused only after its event)
+    std::vector<tlsdev::RowScreen> screens;
+    build_screens(widths, q, screens);
+    {
+        PlanLayout& L = ctx->layout;
+        size_t off = 0;
+        auto place = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 255) / 256 * 256; return at; };
+        const size_t nn = (size_t)n, np = (size_t)n_periods, nw = widths.size(), nq = q.size();
+        L.t = place(nn * 8); L.y = place(nn * 8); L.w = place(uniform ? 0 : nn * 8);
+        L.periods = place(np * 8); L.order = place(np * sizeof(int)); L.rows = place(np * sizeof(tlsdev::PeriodRows));
+        L.widths = place(nw * sizeof(tlsdev::WidthEntry)); L.screens = place(nw * sizeof(tlsdev::RowScreen));
+        L.q = place(nq * 8); L.q2 = place(uniform ? 0 : nq * 8);
+        L.total = off;
+        int rcs = stage_reserve(ctx, L.total);
+        if (rcs) return rcs;
+        TLS_HIP(ctx, ctx->d_plan.reserve(L.total));
+        unsigned char* h = ctx->h_stage;
+        std::memcpy(h + L.t, t, nn * 8);
+        std::memcpy(h + L.y, y, nn * 8);
+        if (!uniform) std::memcpy(h + L.w, w.data(), nn * 8);
+        if (np) {
+            std::memcpy(h + L.periods, periods, np * 8);
+            std::memcpy(h + L.order, order.data(), np * sizeof(int));
+            std::memcpy(h + L.rows, prow.data(), np * sizeof(tlsdev::PeriodRows));
+        }
+        std::memcpy(h + L.widths, widths.data(), nw * sizeof(tlsdev::WidthEntry));
+        std::memcpy(h + L.screens, screens.data(), nw * sizeof(tlsdev::RowScreen));
+        std::memcpy(h + L.q, q.data(), nq * 8);
+        if (!uniform) {
+            double* q2 = reinterpret_cast<double*>(h + L.q2);
+            for (size_t j = 0; j < nq; ++j) q2[j] = q[j] * q[j];
+        }
+        unsigned char* d = ctx->d_plan.ptr;
+        ctx->d_t.ptr = reinterpret_cast<double*>(d + L.t); ctx->d_y.ptr = reinterpret_cast<double*>(d + L.y);
+        ctx->d_w.ptr = reinterpret_cast<double*>(d + L.w); ctx->d_periods.ptr = reinterpret_cast<double*>(d + L.periods);
+        ctx->d_order.ptr = reinterpret_cast<int*>(d + L.order); ctx->d_rows.ptr = reinterpret_cast<tlsdev::PeriodRows*>(d + L.rows);
+        ctx->d_widths.ptr = reinterpret_cast<tlsdev::WidthEntry*>(d + L.widths);
+        ctx->d_screens.ptr = reinterpret_cast<tlsdev::RowScreen*>(d + L.screens);
+        ctx->d_q.ptr = reinterpret_cast<double*>(d + L.q); ctx->d_q2.ptr = reinterpret_cast<double*>(d + L.q2);
+        TLS_HIP(ctx, hipMemcpyAsync(d, h, L.total, hipMemcpyHostToDevice, ctx->stream));
+        TLS_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+        ctx->stage_pending = true;
+        // results [chi2 | row | depth | counters[4]]
+        TLS_HIP(ctx, ctx->d_out.reserve(3 * np + 4));
+        ctx->d_chi2.ptr = ctx->d_out.ptr; ctx->d_row.ptr = reinterpret_cast<long long*>(ctx->d_out.ptr + np);
+        ctx->d_depth.ptr = ctx->d_out.ptr + 2 * np;
+        ctx->d_counters.ptr = reinterpret_cast<unsigned long long*>(ctx->d_out.ptr + 3 * np);
     }
-    TLS_HIP(ctx, ctx->d_chi2.reserve((size_t)n_periods));
-    TLS_HIP(ctx, ctx->d_row.reserve((size_t)n_periods));
-    TLS_HIP(ctx, ctx->d_depth.reserve((size_t)n_periods));
-    TLS_HIP(ctx, ctx->d_counters.reserve(3));
     TLS_HIP(ctx, ctx->d_queue.reserve(1));
-    TLS_HIP(ctx, ctx->d_squeue.reserve(2));
-    TLS_HIP(ctx, hipMemsetAsync(ctx->d_squeue.ptr, 0, 2 * sizeof(unsigned int), ctx->stream));  // the kernel rewinds it itself
-    // the host staging vectors die at return: wait for the copies
-    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->d_squeue.ptr) {   // zero once per context: the kernel rewinds its queue itself
+        TLS_HIP(ctx, ctx->d_squeue.reserve(2));
+        TLS_HIP(ctx, hipMemsetAsync(ctx->d_squeue.ptr, 0, 2 * sizeof(unsigned int), ctx->stream));
+    }
+    key_store(ctx->key, t, n, periods, n_periods, tmpl, params);
     ctx->prepared = true;
     return TLS_OK;
 }
+
+namespace {
+// the flux (and weights) of a prepared plan replaced; kWeightsDiffer when the new dy changes the weight structure
+int update_flux_impl(tls_ctx* ctx, const double* y, const double* dy) {
+    std::vector<double> w;
+    bool uniform; double w0, S0;
+    double y_abs_max = 0.0;
+    weights_from(y, dy, ctx->n, uniform, w0, w, S0, &y_abs_max);
+    if (uniform != ctx->uniform_w) return kWeightsDiffer;
+    ctx->w0 = w0; ctx->S0 = S0; ctx->y_abs_max = y_abs_max;
+    ctx->prune_kernel = uniform && pruning_pays(ctx->host_widths, flux_scatter(y, ctx->n), ctx->depth_min, ctx->resident);
+    const PlanLayout& L = ctx->layout;
+    const size_t nn = (size_t)ctx->n;
+    int rcs = stage_reserve(ctx, L.total);   // (waits for the previous upload out of the staging buffer)
+    if (rcs) return rcs;
+    std::memcpy(ctx->h_stage + L.y, y, nn * 8);
+    TLS_HIP(ctx, hipMemcpyAsync(ctx->d_y.ptr, ctx->h_stage + L.y, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!uniform) {
+        std::memcpy(ctx->h_stage + L.w, w.data(), nn * 8);
+        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_w.ptr, ctx->h_stage + L.w, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    TLS_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+    ctx->stage_pending = true;
+    ctx->executed = false;
+    return TLS_OK;
+}
+}  // namespace
 
 int tls_update_flux(tls_ctx* ctx, const double* y, const double* dy) {
     if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
     if (!ctx->prepared) return fail(ctx, TLS_E_STATE, "tls_update_flux before tls_prepare");
     if (!y || !dy) return fail(ctx, TLS_E_ARG, "null argument");
     TLS_HIP(ctx, hipSetDevice(ctx->device));
-    std::vector<double> w;
-    bool uniform; double w0, S0;
-    weights_from(y, dy, ctx->n, uniform, w0, w, S0);
-    if (uniform != ctx->uniform_w)
+    const int rc = update_flux_impl(ctx, y, dy);
+    if (rc == kWeightsDiffer)
         return fail(ctx, TLS_E_STATE, "weight structure (uniform / per-point dy) differs from the prepared search");
-    ctx->w0 = w0; ctx->S0 = S0;
-    ctx->prune_kernel = uniform && pruning_pays(ctx->host_widths, flux_scatter(y, ctx->n), ctx->depth_min, ctx->resident);
-    int rc;
-    if ((rc = upload(ctx, ctx->d_y, y, (size_t)ctx->n))) return rc;
-    if (!uniform && (rc = upload(ctx, ctx->d_w, w.data(), (size_t)ctx->n))) return rc;
-    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->executed = false;
-    return TLS_OK;
+    return rc;
 }
 
 int tls_execute(tls_ctx* ctx, int count_work) {
@@ -844,6 +1181,27 @@ int tls_debug_prefix(tls_ctx* ctx, double* out, int64_t capacity, int64_t* row_l
     return TLS_OK;
 }
 
+int tls_debug_period_cycles(tls_ctx* ctx, uint64_t* cycles, int64_t capacity) {
+    if (!ctx || !cycles) return fail(ctx, TLS_E_ARG, "bad argument");
+    if (!ctx->prepared) return fail(ctx, TLS_E_STATE, "tls_debug_period_cycles before tls_prepare");
+    if (capacity < ctx->n_periods) return fail(ctx, TLS_E_ARG, "tls_debug_period_cycles: out holds fewer than n_periods entries");
+    if (ctx->n_periods == 0) return TLS_OK;
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<unsigned long long> d_out;
+    TLS_HIP(ctx, d_out.reserve((size_t)ctx->n_periods));
+    hipError_t e = hipMemsetAsync(d_out.ptr, 0, (size_t)ctx->n_periods * 8, ctx->stream);
+    int rc = e == hipSuccess ? enqueue(ctx, false, false, nullptr, nullptr, d_out.ptr) : fail(ctx, TLS_E_HIP, hipGetErrorString(e));
+    if (rc == TLS_OK) {
+        e = hipMemcpyAsync(cycles, d_out.ptr, (size_t)ctx->n_periods * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, TLS_E_HIP, hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    d_out.release();
+    return rc;
+}
+
 int tls_debug_cumsum(tls_ctx* ctx, const double* f, int64_t count, double* out, int threads) {
     if (!ctx || !f || !out || count < 0 || count > 100000000) return fail(ctx, TLS_E_ARG, "bad argument");
     if (threads < 64 || threads > 1024 || threads % 64) return fail(ctx, TLS_E_ARG, "threads must be a multiple of 64 in [64, 1024]");
@@ -937,15 +1295,25 @@ int tls_fetch(tls_ctx* ctx, double* out_chi2, int64_t* out_row, double* out_dept
     TLS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t np = (size_t)ctx->n_periods;
     static_assert(sizeof(long long) == sizeof(int64_t), "int64 layout");
-    if (np) {
-        TLS_HIP(ctx, hipMemcpyAsync(out_chi2, ctx->d_chi2.ptr, np * 8, hipMemcpyDeviceToHost, ctx->stream));
-        TLS_HIP(ctx, hipMemcpyAsync(out_row, ctx->d_row.ptr, np * 8, hipMemcpyDeviceToHost, ctx->stream));
-        TLS_HIP(ctx, hipMemcpyAsync(out_depth, ctx->d_depth.ptr, np * 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
     unsigned long long dev_counts[3] = {0, 0, 0};
-    if (counters && ctx->counted && np)
-        TLS_HIP(ctx, hipMemcpyAsync(dev_counts, ctx->d_counters.ptr, sizeof dev_counts, hipMemcpyDeviceToHost, ctx->stream));
-    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (np) {
+        // [chi2 | row | depth | counters] leave the device as ONE copy into pinned memory
+        const size_t words = 3 * np + 4;
+        if (ctx->h_out_cap < words) {
+            if (ctx->h_out) TLS_HIP(ctx, hipHostFree(ctx->h_out));
+            ctx->h_out = nullptr; ctx->h_out_cap = 0;
+            TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_out), (words + words / 4) * 8, hipHostMallocDefault));
+            ctx->h_out_cap = words + words / 4;
+        }
+        TLS_HIP(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out.ptr, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(out_chi2, ctx->h_out, np * 8);
+        std::memcpy(out_row, ctx->h_out + np, np * 8);
+        std::memcpy(out_depth, ctx->h_out + 2 * np, np * 8);
+        std::memcpy(dev_counts, ctx->h_out + 3 * np, sizeof dev_counts);
+    } else {
+        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (counters) {
         *counters = ctx->plan_counters;
         counters->evaluated_cells = ctx->counted ? (int64_t)dev_counts[0] : -1;
@@ -1061,9 +1429,10 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         double* h_S0 = sl.h_in + (size_t)group * nn * (uni ? 1 : 2);
         double* h_w0 = h_S0 + group;
         double sigma_sum = 0.0;
+        double group_y_max = 0.0;
         for (int64_t c = 0; c < gc; ++c) {
             bool uniform; double w0, S0;
-            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0);
+            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0, &group_y_max);
             if (uniform != uni) { rc = fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy"); break; }
             h_S0[c] = S0; h_w0[c] = w0;
             std::memcpy(h_y + (size_t)c * nn, y + (c0 + c) * n, nn * 8);
@@ -1077,7 +1446,7 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         TLS_HIP(ctx, hipMemcpyAsync(sl.d_w0.ptr, h_w0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->copy_stream));
         TLS_HIP(ctx, hipEventRecord(sl.ev_in, ctx->copy_stream));
         TLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ev_in, 0));
-        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0];
+        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = group_y_max;
         ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident);
         ctx->batch_curves = (int)gc;
         ctx->over_y = sl.d_y.ptr; ctx->over_w = uni ? nullptr : sl.d_w.ptr; ctx->over_S0 = sl.d_S0.ptr; ctx->over_w0 = sl.d_w0.ptr;
@@ -1118,10 +1487,46 @@ int tls_grid_cells(const double* t, int64_t n, const double* periods, int64_t n_
     if (W % 2 != 0) W += 1;
     double t_min = t[0], t_max = t[0];
     for (int64_t i = 1; i < n; ++i) { t_min = std::min(t_min, t[i]); t_max = std::max(t_max, t[i]); }
-    for (int64_t p = 0; p < n_periods; ++p) {
-        int lo, hi;
-        cells_per_period[p] = period_window(widths, params, periods[p], t_max - t_min, n, n + W, lo, hi, nullptr);
+    GridPlan gp;
+    if (!plan_periods(widths, params, periods, n_periods, t_max - t_min, n, n + W, nullptr, cells_per_period, &gp)) {
+        g_create_error = "tls_grid_cells: periods must be positive and finite";
+        return TLS_E_ARG;
     }
+    return TLS_OK;
+}
+
+int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t n_periods, const tls_template* tmpl,
+                     const tls_params* params, double sigma, int64_t* cells_per_period, double* taps_per_period) {
+    if (!t || !periods || !cells_per_period || !taps_per_period || n < 3 || n_periods < 0) {
+        g_create_error = "tls_period_costs: invalid argument";
+        return TLS_E_ARG;
+    }
+    std::vector<tlsdev::WidthEntry> widths;
+    int rc = build_widths(nullptr, tmpl, params, n, widths, nullptr);
+    if (rc) return rc;
+    int64_t W = widths.back().width;
+    if (W % 2 != 0) W += 1;
+    const int64_t M = n + W;
+    double t_min = t[0], t_max = t[0];
+    for (int64_t i = 1; i < n; ++i) { t_min = std::min(t_min, t[i]); t_max = std::max(t_max, t[i]); }
+    std::vector<tlsdev::PeriodRows> prow((size_t)n_periods);
+    GridPlan gp;
+    if (!plan_periods(widths, params, periods, n_periods, t_max - t_min, n, M, prow.data(), cells_per_period, &gp)) {
+        g_create_error = "tls_period_costs: periods must be positive and finite";
+        return TLS_E_ARG;
+    }
+    // expected template taps of a row: trial positions x taps x the fraction of windows of white noise whose mean
+    // exceeds transit_depth_min (core.py:58): Q(depth_min * sqrt(d) / sigma)
+    std::vector<double> prefix(widths.size() + 1, 0.0);
+    for (size_t k = 0; k < widths.size(); ++k) {
+        const auto& we = widths[k];
+        const double n_pos = (double)((M - we.width) / we.xth + 1);
+        double frac = 1.0;
+        if (sigma > 0) frac = 0.5 * std::erfc(params->transit_depth_min * std::sqrt((double)we.width) / sigma / std::sqrt(2.0));
+        prefix[k + 1] = prefix[k] + n_pos * (double)we.q_len * frac;
+    }
+    for (int64_t p = 0; p < n_periods; ++p)
+        taps_per_period[p] = prefix[(size_t)prow[(size_t)p].k_hi] - prefix[(size_t)prow[(size_t)p].k_lo];
     return TLS_OK;
 }
 

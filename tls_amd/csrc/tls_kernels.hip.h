@@ -90,7 +90,7 @@ enum CheckCode {
 
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;  // up to 1024 threads per workgroup
-constexpr int kPhases = 32;    // phase-clock slots (tls_amd/_lib.py names them)
+constexpr int kPhases = 40;    // phase-clock slots 0..31 and work statistics 32..39 (tls_amd/_lib.py names them)
 #ifndef TLS_KR
 #define TLS_KR 5
 #endif
@@ -415,6 +415,25 @@ struct PeriodRows {
     int pad;   // slab variant: tile length of this period (0: SearchArgs::tile_len)
 };
 
+// Piecewise-constant image of a template row for the pruning bound (window_bound): the row's taps
+// q_0..q_{L-1} are replaced by kSeg levels (the means of q over [b_k, b_{k+1})), so that the dot product
+// with the folded series needs kSeg + 1 look-ups in the prefix sum C instead of L taps:
+//     sum_j q~_j e_{i+j} = sq - sum_k g_k C[i + b_k],     e = 1 - f,
+// (telescoped: g_0 = -q~_0, g_k = q~_{k-1} - q~_k, g_kSeg = q~_{kSeg-1}; sq = sum_j q~_j), and what the levels
+// miss is bounded by Cauchy-Schwarz with r2 = sum_j (q_j - q~_j)^2.  Host-built (build_widths).
+constexpr int kSeg = 8;
+constexpr int kScreenMinLen = 32;   // shorter rows: the exact dot product costs about as much as the screen
+struct RowScreen {
+    int b[kSeg + 1];      // segment boundaries, b[0] = 0 < ... < b[kSeg] = q_len
+    int valid;            // the screen may be used for this row
+    int pad_[2];
+    double g[kSeg + 1];   // telescoped level differences
+    double sq;            // sum_j q~_j
+    double r2;            // sum_j (q_j - q~_j)^2, rounded up
+    double pad2_;
+};
+typedef const __attribute__((address_space(4))) RowScreen* const_screen_ptr;
+
 struct SearchArgs {
     const double* t;        // [n]
     const double* y;        // [n]
@@ -425,6 +444,7 @@ struct SearchArgs {
     const WidthEntry* widths;
     const double* q;        // template rows q_j = 1 - signal_j, zero padded front and back
     const double* q2;       // q_j^2, same layout (general weights only)
+    const RowScreen* screens;   // [n_widths] piecewise-constant rows of the pruning bound (pruning variant)
     double* out_chi2;       // [n_periods]
     long long* out_row;     // [n_periods]
     double* out_depth;      // [n_periods]
@@ -443,6 +463,7 @@ struct SearchArgs {
     unsigned long long* sort3_scratch;   // [blocks][sort3_scratch_doubles(n)] pass-1 output of that path
     double* debug_folded;                // test entry (tls_debug_folded): [n_periods][n] folded flux of every period, or nullptr
     double* debug_prefix;                // test entry (tls_debug_prefix): [n_periods][M + 1] prefix sum C of every period, or nullptr
+    unsigned long long* period_cycles;   // developer entry (tls_debug_period_cycles): [n_periods] shader cycles per period, or nullptr
     int n_curves;               // >= 1; curve c reads y + c*n (w + c*n), writes out_* + c*n_periods
     const double* curve_S0;     // [n_curves] S0 per curve (n_curves > 1; else S0 / w0 below)
     const double* curve_w0;     // [n_curves]
@@ -451,6 +472,9 @@ struct SearchArgs {
     long long prune_min_live;   // prune a period (tile) only when at least this many units are live
     int p2_shift;               // log2 of the block length of the coarse prefix sum of e^2 (pruning bound)
     double depth_min;
+    double eps_fast;            // fast mode: half-width of the undecided band around depth_min (depth_pass)
+    double slack_unit;          // pruning: rounding allowance of window_bound per sample of a window
+    int exact_prefix;           // != 0: every period in exact mode (developer switch TLS_EXACT_PREFIX=1, debug entries)
     double S0;
     double w0;
     int n, W, M;            // points, patch length, n + W
@@ -1361,6 +1385,37 @@ __device__ __forceinline__ double exact_cumsum(const double* f, double* C, int c
     return s0;
 }
 
+// Fast mode of the LDS-resident kernel: fe[k] = e_k = 1 - f[k] in place and X[0] = 0, X[k+1] = X[k] + e_k as a plain
+// parallel prefix sum (any association: the values are ~1e-4..1e-2, their sums carry ~1e-18 of rounding).  With
+// per-point weights the samples become e*w afterwards; X is the sum of the unweighted e.  One LDS-only barrier.
+template <bool UNIFORM_W>
+__device__ __forceinline__ void prefix_sum_of_e(double* fe, const double* w, double* X, int M, double* wtot) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int nt = blockDim.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    int per = (M + nt - 1) / nt;
+    if ((per & 1) == 0) per += 1;    // odd stride: the 8-byte LDS accesses of a wave hit 32 bank pairs
+    const int lo = tid * per < M ? tid * per : M;
+    const int hi = lo + per < M ? lo + per : M;
+    double local = 0.0;
+    for (int k = lo; k < hi; ++k) { const double e = 1.0 - fe[k]; fe[k] = e; local += e; }
+    const double incl = wave_inclusive_sum(local);
+    if (lane == kWave - 1) wtot[wave] = incl;
+    lds_barrier();
+    double run = 0.0;
+    for (int v = 0; v < wave; ++v) run += wtot[v];
+    run += incl - local;
+    for (int k = lo; k < hi; ++k) {
+        X[k] = run;
+        const double e = fe[k];
+        run += e;
+        if constexpr (!UNIFORM_W) fe[k] = e * w[k];
+    }
+    if (hi == M && lo < hi) X[M] = run;
+}
+
 // Depth predicate of one trial cell (core.py:58): mean = 1 - (C[i+d]-C[i])/d > depth_min.
 // The quotient is replaced by a multiplication (the two differ by < 3e-16); only a result
 // within 1e-15 of the threshold is re-decided with the exact quotient, so the decision is
@@ -1371,6 +1426,29 @@ __device__ __forceinline__ int depth_class(double dC, double inv_d, double dmin)
 }
 __device__ __forceinline__ bool depth_exact(double dC, double dd, double dmin) {
     return (1.0 - dC / dd) > dmin;
+}
+
+// The kernels keep the prefix sum in the form  X[k] = k - C[k]  (the running sum of e = 1 - f): a window's
+// X[i+d] - X[i] = d - (C[i+d] - C[i]) is d times its mean depth.  Two ways to fill X:
+//   exact mode  C is the sequential fp64 cumsum, bit for bit numpy.cumsum (exact_cumsum), and X[k] = k - C[k]
+//               is an EXACT subtraction (both are multiples of ulp(C) and the result is small), as is
+//               dd - dX = C[i+d] - C[i]: the reference expression 1 - (C[i+d]-C[i])/d is evaluated on its own bits.
+//   fast mode   (LDS-resident series) X is a plain parallel prefix sum of e = 1 - f.  It differs from k - C by
+//               the rounding the sequential cumsum has collected, at most half an ulp of the total per step, i.e.
+//               |dX/d - mean_reference| <= 2^-53 * C_max + O(1e-16) =: eps/2 for EVERY window.  A window whose
+//               mean is farther than eps from transit_depth_min is decided exactly as the reference decides it;
+//               one inside the band (about one period in fifty at N = 4320) is not decided at all: the thread
+//               raises `undecided`, and the workgroup searches that period again in exact mode.
+// So the set of evaluated cells is the reference's in both modes; what fast mode changes is the depth scale of
+// a cell by <= eps (~1e-12 absolute on a mean of ~1e-5..1e-2, i.e. <= ~1e-10 relative on chi^2; typically 1e-12).
+__device__ __forceinline__ bool depth_pass(double dX, double inv_d, double dd, double dmin, double eps,
+                                           bool exact_mode, bool& undecided) {
+    const double m_fast = dX * inv_d;
+    if (m_fast > dmin + eps) return true;
+    if (!(m_fast >= dmin - eps)) return false;
+    if (exact_mode) return (1.0 - (dd - dX) / dd) > dmin;   // dd - dX == C[i+d] - C[i], exactly
+    undecided = true;
+    return false;
 }
 
 // Per-row (= per in-range trial duration) bookkeeping of one period, in the LDS header.
@@ -1391,11 +1469,11 @@ struct RowTables {
 // over-estimating) prefix sum.  A cell whose bound is below a statistic that some evaluated cell
 // has already reached cannot win (strict '<', core.py:70-74): skipping it leaves the result
 // unchanged.  All roundings go upwards (the float steps are inflated by 1e-6).
-__device__ __forceinline__ float cell_bound(double dC_min, double dC_max, double dd, double inv_d, double ov,
+__device__ __forceinline__ float cell_bound(double dX_max, double dX_min, double dd, double inv_d, double ov,
                                             double k_mono, double var_q, double e2) {
-    const double m_hi = fma(-dC_min, inv_d, 1.0);
-    if (!(m_hi > 0.0)) return -INFINITY;
-    const double m_lo = fmax(fma(-dC_max, inv_d, 1.0), 0.0);
+    const double m_hi = dX_max * inv_d * (1.0 + 1e-9) + 1e-15;
+    if (!(dX_max > 0.0)) return -INFINITY;
+    const double m_lo = fmax(dX_min * inv_d * (1.0 - 1e-9) - 1e-15, 0.0);
     const double V = fmax(fma(-dd * m_lo, m_lo, e2), 0.0) * (1.0 + 1e-6) + 1e-9 * e2;
     const float f = sqrtf((float)(var_q * V)) * (1.0f + 1e-6f);
     const double U = 4.0 * ov * m_hi * fma(m_hi, k_mono, (double)f);
@@ -1410,21 +1488,104 @@ __device__ __forceinline__ double coarse_e2(const double* P2, int lo, int hi, in
     return P2[b_hi] - P2[b_lo];
 }
 
+// Tight bound of ONE window (uniform weights): the template row is replaced by its piecewise-constant image
+// (RowScreen), whose dot product B~ = sum_k g_k X[i + b_k] with e comes from kSeg + 1 values of X, and the remainder is
+// bounded by Cauchy-Schwarz:  sum_j (q_j - q~_j) e_j = sum_j (q_j - q~_j)(e_j - m)  (the levels are segment
+// means, so the differences sum to zero)  <=  sqrt(r2 * V),  V = sum (e_j - m)^2 = sum e_j^2 - d m^2.  Hence
+//     -stat = rs (2B - rs A) <= U = rs (2 (B~ + sqrt(r2 V) + slack) - rs A),     rs = 2 m ov > 0.
+// The cell_bound above is the one-segment case of this; with eight segments the remainder is ~20x smaller and
+// at 50 ppm four out of five template taps of a search are never multiplied.  `slack` covers the rounding of C
+// (sequential sum: at most half an ulp of the total per step, over the d steps of a window) and of the
+// telescoped sum; sum e^2 comes from the coarse prefix sum (rounded outwards), all other roundings go upwards.
+// Windows that fail the depth predicate (core.py:58) -- among them those past the end of the T0 grid, which read
+// the sentinels behind C -- return -inf.
+__device__ __forceinline__ float window_bound(const double* x, int i, int d, double dd, double inv_d, double ov, double A,
+                                              const_screen_ptr s, const double* P2, int shift, int n_blocks,
+                                              double dmin, double eps, bool exact_mode, bool& undecided, double slack) {
+    const double x0 = x[i], xK = x[i + d];
+    double xm[kSeg - 1];
+#pragma unroll
+    for (int k = 1; k < kSeg; ++k) xm[k - 1] = x[i + s->b[k]];
+    const double dX = xK - x0;
+    const bool pass = depth_pass(dX, inv_d, dd, dmin, eps, exact_mode, undecided);
+    double Bt = s->g[0] * x0;
+#pragma unroll
+    for (int k = 1; k < kSeg; ++k) Bt = fma(s->g[k], xm[k - 1], Bt);
+    Bt = fma(s->g[kSeg], xK, Bt);
+    const double m = dX * inv_d;
+    const double e2 = coarse_e2(P2, i, i + d, shift, n_blocks);
+    const double m_lo = fmax(m, 0.0) * (1.0 - 1e-12);
+    const double V = fmax(fma(-dd * m_lo, m_lo, e2), 0.0) * (1.0 + 1e-6) + 1e-9 * e2;
+    const float f = sqrtf((float)(s->r2 * V)) * (1.0f + 1e-6f) + 1e-30f;
+    const double Bub = Bt + (double)f + slack;
+    const double rs = 2.0 * (m * ov);
+    const double U = rs * (2.0 * Bub - rs * A);
+    float uf = (float)(U + 1e-6 * fabs(U) + 1e-300);
+    uf += fabsf(uf) * 1e-6f;
+    return pass ? uf : -INFINITY;
+}
+
+// The same for a UNIT of n_win windows xth samples apart (the kR windows of a chunk): per window only the
+// piecewise-constant dot product B~ and the window sum dX; square root, variance and statistic once, for
+//     B_up = max_r B~_r + sqrt(r2 V) + slack,   V from the shallowest passing window and sum e^2 over the whole unit,
+//     U = max over rs in [rs(shallowest), rs(deepest)] of rs (2 B_up - rs A)     (a parabola in rs: vertex or end point)
+// which is >= window_bound of every window of the unit.  A quarter of the instructions of n_win window_bounds.
+__device__ __forceinline__ float unit_bound(const double* x, int b, int n_win, int xth, int d, double dd, double inv_d, double ov,
+                                            double A, const_screen_ptr s, const double* P2, int shift, int n_blocks,
+                                            double dmin, double eps, bool exact_mode, bool& undecided, double slack) {
+    double B_max = -INFINITY, dX_max = -INFINITY, dX_min = INFINITY;
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+        if (r < n_win) {
+            const int i = b + r * xth;
+            const double x0 = x[i], xK = x[i + d];
+            double xm[kSeg - 1];
+#pragma unroll
+            for (int k = 1; k < kSeg; ++k) xm[k - 1] = x[i + s->b[k]];
+            const double dX = xK - x0;
+            double Bt = s->g[0] * x0;
+#pragma unroll
+            for (int k = 1; k < kSeg; ++k) Bt = fma(s->g[k], xm[k - 1], Bt);
+            Bt = fma(s->g[kSeg], xK, Bt);
+            if (depth_pass(dX, inv_d, dd, dmin, eps, exact_mode, undecided)) {
+                B_max = fmax(B_max, Bt); dX_max = fmax(dX_max, dX); dX_min = fmin(dX_min, dX);
+            }
+        }
+    }
+    if (!(dX_max > -INFINITY)) return -INFINITY;   // no window of the unit passes the depth predicate
+    // (the depth the evaluation uses, 1 - (d - dX)/d, carries ~1e-16 of absolute rounding, 1e-11 of a 1e-5 depth)
+    const double m_hi = dX_max * inv_d * (1.0 + 1e-9) + 1e-15;
+    const double m_lo = fmax(dX_min * inv_d * (1.0 - 1e-9) - 1e-15, 0.0);
+    const double e2 = coarse_e2(P2, b, b + (n_win - 1) * xth + d, shift, n_blocks);
+    const double V = fmax(fma(-dd * m_lo, m_lo, e2), 0.0) * (1.0 + 1e-6) + 1e-9 * e2;
+    const float f = sqrtf((float)(s->r2 * V)) * (1.0f + 1e-6f) + 1e-30f;
+    const double B_up = B_max + (double)f + slack;
+    const double rs_lo = 2.0 * (m_lo * ov), rs_hi = 2.0 * (m_hi * ov);
+    const double rs = fmin(fmax(B_up / A, rs_lo), rs_hi);
+    const double U = rs * (2.0 * B_up - rs * A);
+    float uf = (float)(U + 1e-6 * fabs(U) + 1e-300);
+    uf += fabsf(uf) * 1e-6f;
+    return uf;
+}
+
 // Candidate evaluation shared by all dot-product variants: given the dot products of one
 // T0 position, apply the predicate, form the statistic and keep the lane's best.  Positions
 // past the end of the T0 grid read the +huge sentinels behind C and fail the predicate.
-__device__ __forceinline__ void consider(Best& best, double c_lo, double c_hi, int i, double inv_d,
-                                         double dd, double dmin, double overshoot, double A, double B,
-                                         int k, unsigned long long& n_eval) {
-    const double dC = c_hi - c_lo;
-    const int cls = depth_class(dC, inv_d, dmin);
-    if (cls == 0 || (cls < 0 && !depth_exact(dC, dd, dmin))) return;
+struct DepthRule {   // how the depth predicate is decided in this period (depth_pass)
+    double dmin, eps;
+    bool exact_mode;
+};
+__device__ __forceinline__ void consider(Best& best, double x_lo, double x_hi, int i, double inv_d,
+                                         double dd, const DepthRule& rule, double overshoot, double A, double B,
+                                         int k, unsigned long long& n_eval, bool& undecided) {
+    const double dX = x_hi - x_lo;
+    if (!depth_pass(dX, inv_d, dd, rule.dmin, rule.eps, rule.exact_mode, undecided)) return;
     n_eval += 1;
     // cheap estimate first; the exact quotient only for cells that can beat the lane's best
-    const double rs_f = 2.0 * (fma(-dC, inv_d, 1.0) * overshoot);
+    const double rs_f = 2.0 * ((dX * inv_d) * overshoot);
     const double stat_f = rs_f * (rs_f * A - 2.0 * B);
     if (!(stat_f <= best.stat + 1e-9 * fabs(best.stat))) return;
-    const double mean = 1.0 - dC / dd;          // helpers.py:73 + core.py:167, exact
+    const double mean = 1.0 - (dd - dX) / dd;   // helpers.py:73 + core.py:167; dd - dX is C[i+d] - C[i] (exact mode: its bits)
     const double td = mean * overshoot;          // core.py:61
     const double rs = 2.0 * td;                  // 1/(SIGNAL_DEPTH/td), core.py:62-63
     Best c;
@@ -2050,6 +2211,23 @@ __device__ __forceinline__ void block_exclusive_scan8(unsigned int* cnt, int nb,
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));   // one partitioned point: {key << 32 | index, flux bits}
 
 // dst[0..count) (slab, HBM) = src[0..count) (LDS): 16-byte stores wherever the destination allows
+// the same for a piece of the prefix sum C on its way into the slab, stored as X[k] = k - C[k] (an exact subtraction:
+// see depth_pass); src[j] is C[k0 + j]
+__device__ __forceinline__ void copy_out_stream_x(double* dst, const double* src, int count, int tid, int k0) {
+    const int nt = blockDim.x;
+    const int head = (int)((reinterpret_cast<unsigned long long>(dst) >> 3) & 1ull);   // 1: dst starts on an odd element
+    if (tid == 0 && head && count > 0) stream_store(dst, (double)k0 - src[0]);
+    const int pairs = (count - head) / 2;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2* d2 = reinterpret_cast<f64x2*>(dst + head);
+    const double* s1 = src + head;
+    const int kb = k0 + head;
+    for (int q = tid; q < pairs; q += nt) {
+        f64x2 v; v.x = (double)(kb + 2 * q) - s1[2 * q]; v.y = (double)(kb + 2 * q + 1) - s1[2 * q + 1];
+        stream_store(d2 + q, v);
+    }
+    if (tid == 0 && head + 2 * pairs < count) stream_store(dst + count - 1, (double)(k0 + count - 1) - src[count - 1]);
+}
 __device__ __forceinline__ void copy_out_stream(double* dst, const double* src, int count, int tid) {
     const int nt = blockDim.x;
     const int head = (int)((reinterpret_cast<unsigned long long>(dst) >> 3) & 1ull);   // 1: dst starts on an odd element
@@ -2423,14 +2601,26 @@ tls_search_kernel(const SearchArgs a) {
     const const_rows_ptr rows_c = (const_rows_ptr)a.rows;
     const const_f64_ptr q_all = (const_f64_ptr)a.q;
     const const_f64_ptr q2_all = (const_f64_ptr)a.q2;
+    const const_screen_ptr screens_c = (const_screen_ptr)a.screens;
     const double dmin = a.depth_min;
 
+    bool retry_exact = false;   // the period just searched in fast mode left a window undecided: again, in exact mode
+    int work = 0;
     for (;;) {
         // ---- fetch the next period from the queue ----------------------------------
-        if (tid == 0) s_work[0] = (int)atomicAdd(a.queue, 1u);
-        __syncthreads();
-        const int work = __builtin_amdgcn_readfirstlane(s_work[0]);
-        __syncthreads();
+        if (!retry_exact) {
+            if (tid == 0) { s_work[0] = (int)atomicAdd(a.queue, 1u); s_work[1] = 0; s_work[2] = 0; }
+            __syncthreads();
+            work = __builtin_amdgcn_readfirstlane(s_work[0]);
+            __syncthreads();
+        } else if (tid == 0) {
+            s_work[1] = 0; s_work[2] = 0;   // (published by the barriers of the sort, long before any thread may raise them again)
+        }
+        int flag_slot = 1;   // the "undecided" flag of the attempt in flight: s_work[1] and s_work[2] take turns
+        // exact mode: X = k - numpy.cumsum, bit for bit; fast mode: X = plain prefix sum of 1 - f (depth_pass)
+        const bool period_exact = !RESIDENT || retry_exact || a.exact_prefix != 0 || a.debug_prefix != nullptr;
+        retry_exact = false;
+        bool curve_exact = false;   // batches: this light curve again in exact mode (the permutation is kept: no new sort)
         if (work >= a.n_periods) {
             // the last workgroup to leave rewinds the queue for the next launch (no memset between
             // two searches of a prepared plan); queue[1] counts the workgroups that are done
@@ -2443,6 +2633,8 @@ tls_search_kernel(const SearchArgs a) {
         const int p = a.order[work];
         TLS_CHECK(a, p >= 0 && p < a.n_periods, kChkWorkItem);
         const double period = a.periods[p];
+        long long t_period = 0;
+        if (a.period_cycles && tid == 0) t_period = clock64();
         PhaseClock pc;
         pc.start(a.phase_cycles);
 
@@ -2483,6 +2675,11 @@ tls_search_kernel(const SearchArgs a) {
             __syncthreads();
         }
         for (int curve = 0; curve < a.n_curves; ++curve) {
+        const bool exact_mode = period_exact || curve_exact;
+        curve_exact = false;
+        DepthRule rule;
+        rule.dmin = a.depth_min; rule.eps = exact_mode ? 1e-15 : a.eps_fast; rule.exact_mode = exact_mode;
+        bool undecided = false;
         const double* y_c = a.y + (long long)curve * n;
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  kG
         // elements per step: their global reads (L2 latency) are in flight together -- the compiler
@@ -2532,13 +2729,18 @@ tls_search_kernel(const SearchArgs a) {
         const int n_rows = k_hi - k_lo;
         TLS_CHECK(a, 0 <= k_lo && k_lo <= k_x && k_x <= k_hi && k_hi <= a.n_widths, kChkWorkItem);
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
-        // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup
+        // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup -- or, in fast mode,
+        // e = 1 - f and its plain prefix sum X in one pass (depth_pass explains why that decides the same cells)
         if constexpr (RESIDENT) {
+            if (!exact_mode) {
+                prefix_sum_of_e<UNIFORM_W>(regA, regW, regB, M, reinterpret_cast<double*>(cumsum_scratch));
+            } else {
 #if TLS_CUMSUM2
             exact_cumsum<false, true, true>(regA, regB, M, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
 #else
             exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
 #endif
+            }
         } else if (!fused) {
             // the series is in the HBM slab: the scan runs through LDS, 16 K elements a round, in place
             // (C[k+1] over f[k]); the patch (core.py:126: the first W samples again) is an index mapping
@@ -2570,29 +2772,37 @@ tls_search_kernel(const SearchArgs a) {
                     carry = exact_cumsum<true>(buf + 1, buf, len, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles, carry);
                 }
                 pc.mark(5);
-                copy_out_stream(regB + c0, buf, len + 1, tid);
+                copy_out_stream_x(regB + c0, buf, len + 1, tid, c0);   // the slab keeps X[k] = k - C[k]
                 lds_barrier();
                 pc.mark(27);
             }
+        } else {
+            // (the fused sort path has left C in the slab)
+            __syncthreads();
+            for (int k = tid; k <= M; k += nt) regB[k] = (double)k - regB[k];
         }
-        // sentinels behind C: a window that would start past the end of the T0 grid sees an
-        // absurdly deep "mean" and fails the depth predicate without any bounds test.  The
-        // sentinels RISE (k * 1e300 at index M + k) so that a window whose both ends lie in the
-        // sentinels (possible for widths below kR) still sees a huge positive sum.
-        for (int k = tid; k < region_pad; k += nt) regB[M + 1 + k] = (double)(k + 1) * 1.0e300;
+        // sentinels behind X: a window that would start past the end of the T0 grid sees an
+        // absurdly negative "depth" and fails the depth predicate without any bounds test.  The
+        // sentinels FALL (-k * 1e300 at index M + k) so that a window whose both ends lie in the
+        // sentinels (possible for widths below kR) still sees a huge negative sum.
+        for (int k = tid; k < region_pad; k += nt) regB[M + 1 + k] = -(double)(k + 1) * 1.0e300;
         __syncthreads();
-        if (a.debug_prefix && curve == 0) {   // test entry: C as the predicate will read it (helpers.py:72)
-            for (int k = tid; k <= M; k += nt) a.debug_prefix[(long long)p * (M + 1) + k] = regB[k];
+        if (a.debug_prefix && curve == 0) {   // test entry: C as numpy.cumsum gives it (helpers.py:72); exact mode is forced
+            if constexpr (RESIDENT) { for (int k = tid; k <= M; k += nt) a.debug_prefix[(long long)p * (M + 1) + k] = regB[k]; }
+            else { for (int k = tid; k <= M; k += nt) a.debug_prefix[(long long)p * (M + 1) + k] = (double)k - regB[k]; }
             __syncthreads();
         }
         pc.mark(5);
-        // e = 1 - f in place (uniform weights) or e*w (general weights); the tiled variant has done
-        // it chunk by chunk above
+        // exact mode, resident: regB holds C -- now X[k] = k - C[k] (an exact subtraction); e = 1 - f in place (uniform
+        // weights) or e*w (general weights).  Fast mode has done both; the tiled variant chunk by chunk above.
         if constexpr (RESIDENT) {
-            for (int k = tid; k < M; k += nt) {
-                double e = 1.0 - regA[k];
-                if constexpr (!UNIFORM_W) e *= regW[k];
-                regA[k] = e;
+            if (exact_mode) {
+                for (int k = tid; k <= M; k += nt) regB[k] = (double)k - regB[k];
+                for (int k = tid; k < M; k += nt) {
+                    double e = 1.0 - regA[k];
+                    if constexpr (!UNIFORM_W) e *= regW[k];
+                    regA[k] = e;
+                }
             }
         }
         __syncthreads();
@@ -2636,7 +2846,7 @@ tls_search_kernel(const SearchArgs a) {
                         stage_samples<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M);
                         copy_in_flight4(tile_c, regB + p_lo, valid);
                     }
-                    for (int k = valid + tid; k < staged; k += nt) tile_c[k] = (double)(p_lo + k - M) * 1.0e300;
+                    for (int k = valid + tid; k < staged; k += nt) tile_c[k] = -(double)(p_lo + k - M) * 1.0e300;
                 }
                 e_base = tile_e - p_lo;
                 w_base = tile_w - p_lo;
@@ -2654,7 +2864,7 @@ tls_search_kernel(const SearchArgs a) {
                     } else {
                         copy_in_flight4(tile_e, regB + p_lo, valid);
                     }
-                    for (int k = valid + tid; k < staged; k += nt) tile_e[k] = (double)(p_lo + k - M) * 1.0e300;
+                    for (int k = valid + tid; k < staged; k += nt) tile_e[k] = -(double)(p_lo + k - M) * 1.0e300;
                 }
                 c_base = tile_e - p_lo;
             }
@@ -2704,15 +2914,17 @@ tls_search_kernel(const SearchArgs a) {
                     for (int j = 0; j < kRowBatch; ++j) {
                         double m = c_hi[j][0] - c_lo[0];
 #pragma unroll
-                        for (int r = 1; r < kR; ++r) m = fmin(m, c_hi[j][r] - c_lo[r]);
-                        dC[j] = m;
+                        for (int r = 1; r < kR; ++r) m = fmax(m, c_hi[j][r] - c_lo[r]);
+                        dC[j] = m;   // the chunk's largest X[i+d] - X[i]: its deepest window
                     }
 #pragma unroll
                     for (int j = 0; j < kRowBatch; ++j) {
                         if (k + j < k_x) {
-                            const int cls = depth_class(dC[j], inv[j], dmin);
-                            bool live = cls > 0;
-                            if (cls < 0) live = depth_exact(dC[j], (double)dv[j], dmin);  // rare: on the threshold
+                            // (a lane past the row's units reads sentinels or foreign cells: it is masked below and
+                            // must not raise `undecided`)
+                            bool und_j = false;
+                            const bool live = depth_pass(dC[j], inv[j], (double)dv[j], dmin, rule.eps, exact_mode, und_j);
+                            undecided |= und_j && unit < unit_hi;
                             if (n_dense <= kWave) {
                                 const unsigned long long mask = __ballot(live && unit < unit_hi);
                                 if (lane == k + j - k_lo) row_mask = mask;
@@ -2771,10 +2983,10 @@ tls_search_kernel(const SearchArgs a) {
                     for (int r = 0; r < kR; ++r) { c_lo[r] = c0[r * xth]; c_hi[r] = c0[r * xth + d]; }
                     double dC = c_hi[0] - c_lo[0];
 #pragma unroll
-                    for (int r = 1; r < kR; ++r) dC = fmin(dC, c_hi[r] - c_lo[r]);
-                    const int cls = depth_class(dC, inv_d, dmin);
-                    bool live = cls > 0;
-                    if (cls < 0) live = depth_exact(dC, (double)d, dmin);
+                    for (int r = 1; r < kR; ++r) dC = fmax(dC, c_hi[r] - c_lo[r]);
+                    bool und_u = false;
+                    bool live = depth_pass(dC, inv_d, (double)d, dmin, rule.eps, exact_mode, und_u);
+                    undecided |= und_u && unit < unit_hi;
                     live = live && unit < unit_hi;
                     const unsigned long long mask = __ballot(live);
                     if (live) list[n_listed + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
@@ -2791,8 +3003,7 @@ tls_search_kernel(const SearchArgs a) {
                         double dC;
                         if (oversize) dC = regB[i + d] - regB[i];
                         else dC = c_base[i + d] - c_base[i];
-                        const int cls = depth_class(dC, inv_d, dmin);
-                        live = cls > 0 || (cls < 0 && depth_exact(dC, (double)d, dmin));
+                        live = depth_pass(dC, inv_d, (double)d, dmin, rule.eps, exact_mode, undecided);
                     }
                     const unsigned long long mask = __ballot(live);
                     if (live) list[n_listed + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
@@ -2838,6 +3049,9 @@ tls_search_kernel(const SearchArgs a) {
         // decided per period (and tile) from the number of live units.
         double T = -INFINITY;
         bool prune_now = false;
+        // rounding allowance of window_bound per sample of a window: the sequential prefix sum is off by at most
+        // half an ulp of its total per step
+        [[maybe_unused]] const double slack_unit = a.slack_unit;
         int p2_blocks = 0;
         float* const ulist = reinterpret_cast<float*>(chunk_list + a.list_cap);   // bound of every live unit
         if (prune_on) {
@@ -2847,13 +3061,47 @@ tls_search_kernel(const SearchArgs a) {
             total_live = (unsigned int)__builtin_amdgcn_readfirstlane((int)total_live);  // uniform: keep it scalar
             prune_now = (long long)total_live >= a.prune_min_live;
         }
+        if (a.phase_cycles && tid == 0) {   // developer statistics beside the phase clocks
+            unsigned int total_live = 0;
+            for (int row = 0; row < n_rows; ++row) total_live += rt.live[row];
+            atomicAdd(&a.phase_cycles[32], (unsigned long long)total_live);
+            if (prune_now) atomicAdd(&a.phase_cycles[36], 1ull);
+        }
+        unsigned int* active_list = chunk_list;   // the lists phase 3b reads (the pruning pass writes a second set)
+        int n_groups = 0;
         if (prune_now) {
+            // (0) the live units of all rows in groups of 64, numbered row by row (batch_start[row] = first group
+            // of the row): the passes below hand GROUPS to the waves, so that a row with 600 live units and a
+            // row with 6 cost the workgroup what they cost, not what the slowest wave's rows add up to
+            if (wave == 0) {
+                unsigned int carry = 0;
+                for (int r0 = 0; r0 < n_rows; r0 += kWave) {
+                    const int row = r0 + lane;
+                    const unsigned int mine = row < n_rows ? (rt.live[row] + kWave - 1) / kWave : 0u;
+                    const unsigned int incl = wave_inclusive_sum_u32(mine);
+                    if (row < n_rows) rt.batch_start[row] = carry + incl - mine;
+                    carry += (unsigned int)lane_value((int)incl, kWave - 1);
+                }
+                if (lane == 0) rt.batch_start[n_rows] = carry;
+            }
             // (1) coarse prefix sum of e^2: P2[b] = sum of e_k^2 over k < b * 2^p2_shift
             if (!p2_ready) {   // once per period, by the first tile that prunes
                 p2_ready = true;
                 const int sh = a.p2_shift, G = 1 << sh;
                 p2_blocks = (M + G - 1) >> sh;
-                if (G <= kWave) {   // short blocks: one thread each
+                if (RESIDENT && G >= 8) {
+                    // eight consecutive samples per thread, G/8 neighbouring lanes per block
+                    const int per_blk = G >> 3;   // lanes per block: 2, 4 or 8 (G = 16, 32, 64)
+#pragma unroll 1
+                    for (int c0 = 0; c0 < M; c0 += 8 * nt) {
+                        const int k0 = c0 + 8 * tid;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const double ev = k0 + j < M ? regA[k0 + j] : 0.0; acc = fma(ev, ev, acc); }
+                        for (int dlt = 1; dlt < per_blk; dlt <<= 1) acc += __shfl_xor(acc, dlt, kWave);
+                        if ((lane & (per_blk - 1)) == 0 && k0 < M) P2[(k0 >> sh) + 1] = acc;
+                    }
+                } else if (G <= kWave) {   // short blocks: one thread each
 #pragma unroll 1
                     for (int b = tid; b < p2_blocks; b += nt) {
                         const int hi = (b + 1) * G < M ? (b + 1) * G : M;
@@ -2888,74 +3136,77 @@ tls_search_kernel(const SearchArgs a) {
                     double local = 0.0;
 #pragma unroll 1
                     for (int b = lo; b < hi; ++b) local += P2[b + 1];
-                    double incl = local;
-#pragma unroll
-                    for (int dlt = 1; dlt < kWave; dlt <<= 1) {
-                        const double o = __shfl_up(incl, dlt, kWave);
-                        if (lane >= dlt) incl += o;
-                    }
+                    const double incl = wave_inclusive_sum(local);
                     double run = incl - local;
 #pragma unroll 1
                     for (int b = lo; b < hi; ++b) { run += P2[b + 1]; P2[b + 1] = run; }
                     if (lane == 0) P2[0] = 0.0;
                 }
-                __syncthreads();
             }
+            __syncthreads();
             p2_blocks = (M + (1 << a.p2_shift) - 1) >> a.p2_shift;
+            n_groups = __builtin_amdgcn_readfirstlane((int)rt.batch_start[n_rows]);
             pc.mark(22);
-            // (2) the bound of every live unit; each wave remembers its most promising one
+            // (2) the bound of every live unit, group by group; each wave remembers its most promising one
             float cand_u = -INFINITY;
             int cand_k = 0x7fffffff, cand_unit = 0;
-            for (int row = wave; row < n_rows; row += nw) {
-                const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
-                const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
-                const int xth = widths_c[k].xth, tiled = widths_c[k].tiled, d = widths_c[k].width;
-                const int list_base = widths_c[k].list_base, prunable = widths_c[k].prunable;
-                const double inv_d = widths_c[k].inv_d, dd = (double)d;
-                const double ov = widths_c[k].overshoot, k_mono = widths_c[k].k_mono, var_q = widths_c[k].var_q;
-                const int reach = tiled ? (kR - 1) * xth + d : d;   // samples covered by the windows of a unit
-                const int step = tiled ? kR * xth : xth;            // samples between two units
-                // kGroups groups of 64 entries per step: their list reads (HBM/L2 latency) and LDS
-                // reads are in flight together
-                constexpr int kGroups = 4;
+            {
+                int row = 0;
 #pragma unroll 1
-                for (int base = 0; base < n_live; base += kGroups * kWave) {
-                    int unit[kGroups];
-#pragma unroll
-                    for (int j = 0; j < kGroups; ++j) {
-                        const int idx = base + j * kWave + lane;
-                        unit[j] = idx < n_live ? (int)chunk_list[list_base + idx] : 0;
-                    }
-                    float u[kGroups];
-#pragma unroll
-                    for (int j = 0; j < kGroups; ++j) {
-                        const int b = unit[j] * step;
-                        double dC_min, dC_max;
-                        if (!RESIDENT && widths_c[k].oversize) dC_min = regB[b + d] - regB[b];   // (no pointer select, see phase 3a)
-                        else dC_min = c_base[b + d] - c_base[b];
-                        dC_max = dC_min;
+                for (int g = wave; g < n_groups; g += nw) {
+                    while (g >= __builtin_amdgcn_readfirstlane((int)rt.batch_start[row + 1])) ++row;
+                    const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
+                    const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
+                    const int xth = widths_c[k].xth, tiled = widths_c[k].tiled, d = widths_c[k].width;
+                    const int list_base = widths_c[k].list_base, prunable = widths_c[k].prunable;
+                    const double inv_d = widths_c[k].inv_d, dd = (double)d;
+                    const double ov = widths_c[k].overshoot, k_mono = widths_c[k].k_mono, var_q = widths_c[k].var_q;
+                    const double sum_q2 = widths_c[k].sum_q2;
+                    const const_screen_ptr scr = screens_c + k;
+                    const bool screened = RESIDENT && prunable && scr->valid != 0;
+                    const double slack = slack_unit * (double)(d + 64);
+                    const int reach = tiled ? (kR - 1) * xth + d : d;   // samples covered by the windows of a unit
+                    const int step = tiled ? kR * xth : xth;            // samples between two units
+                    const int idx = (g - (int)rt.batch_start[row]) * kWave + lane;
+                    const bool valid = idx < n_live;
+                    const int unit = valid ? (int)chunk_list[list_base + idx] : 0;
+                    const int b = unit * step;
+                    float u = INFINITY;   // rows without a valid bound are always evaluated
+                    if (screened) {
+                        // tight bound, window by window; the unit keeps its best window's
+                        // (an undecided window is listed again by phase 3b or the re-listing, which raise the flag)
+                        bool und_b = false;
+                        u = unit_bound(c_base, b, tiled ? kR : 1, xth, d, dd, inv_d, ov, sum_q2, scr, P2, a.p2_shift, p2_blocks,
+                                       dmin, rule.eps, exact_mode, und_b, slack);
+                        undecided |= und_b && valid;
+                    } else if (prunable) {
+                        // (every window of a live unit goes through depth_pass here as it does in phase 3b of the plain
+                        // kernel: the two variants must send the SAME periods through exact mode to agree bit for bit)
+                        bool und_c = false;
+                        double dX_max, dX_min;
+                        if (!RESIDENT && widths_c[k].oversize) dX_max = regB[b + d] - regB[b];   // (no pointer select, see phase 3a)
+                        else dX_max = c_base[b + d] - c_base[b];
+                        dX_min = dX_max;
+                        (void)depth_pass(dX_max, inv_d, dd, dmin, rule.eps, exact_mode, und_c);
                         if (tiled) {
 #pragma unroll
                             for (int r = 1; r < kR; ++r) {
-                                const double dC = c_base[b + r * xth + d] - c_base[b + r * xth];
-                                dC_min = fmin(dC_min, dC); dC_max = fmax(dC_max, dC);
+                                const double dX = c_base[b + r * xth + d] - c_base[b + r * xth];
+                                (void)depth_pass(dX, inv_d, dd, dmin, rule.eps, exact_mode, und_c);
+                                dX_min = fmin(dX_min, dX); dX_max = fmax(dX_max, dX);
                             }
                         }
-                        u[j] = INFINITY;   // rows without a valid bound are always evaluated
-                        if (prunable)
-                            u[j] = cell_bound(dC_min, dC_max, dd, inv_d, ov, k_mono, var_q,
-                                              coarse_e2(P2, b, b + reach, a.p2_shift, p2_blocks));
+                        undecided |= und_c && valid;
+                        u = cell_bound(dX_max, dX_min, dd, inv_d, ov, k_mono, var_q,
+                                       coarse_e2(P2, b, b + reach, a.p2_shift, p2_blocks));
                     }
-#pragma unroll
-                    for (int j = 0; j < kGroups; ++j) {
-                        const int idx = base + j * kWave + lane;
-                        if (idx < n_live) {
-                            if (prunable && u[j] > cand_u) { cand_u = u[j]; cand_k = k; cand_unit = unit[j]; }
-                            ulist[list_base + idx] = u[j];
-                        }
+                    if (valid) {
+                        if (prunable && u > cand_u) { cand_u = u; cand_k = k; cand_unit = unit; }
+                        ulist[list_base + idx] = u;
                     }
                 }
             }
+            for (int row = tid; row < n_rows; row += nt) rt.singles[row] = 0;   // (5a)'s counters; published by (4)'s barrier
             pc.mark(23);
             // (3) each wave evaluates its candidate exactly (lanes over the template taps)
 #pragma unroll
@@ -3001,7 +3252,7 @@ tls_search_kernel(const SearchArgs a) {
                 if (lane < n_win) {
                     const int i = i0 + lane * xth;
                     unsigned long long ignored = 0;
-                    consider(trial, c_base[i], c_base[i + d], i, inv_d, (double)d, dmin, overshoot, sum_q2, Bmine, ck, ignored);
+                    consider(trial, c_base[i], c_base[i + d], i, inv_d, (double)d, rule, overshoot, sum_q2, Bmine, ck, ignored, undecided);
                 }
             }
             // (4) T = the best statistic any evaluated cell has reached (this and earlier tiles)
@@ -3017,7 +3268,38 @@ tls_search_kernel(const SearchArgs a) {
             T = lane_value(-g, 0);                     // uniform (scalar registers); -inf while nothing has been evaluated
             pc.mark(24);
         }
-        // Per row: (5) keep the units whose bound reaches T, then re-list SPARSE rows.  A handful of
+        if (prune_now) {
+            // (5a) keep the units whose bound reaches T: group by group again, compacted into the workgroup's SECOND
+            // set of lists (the slots of a row handed out by an LDS atomic per group; the order inside a list is
+            // irrelevant).  The first set is still being read by the other waves, so nothing is compacted in place.
+            unsigned int* const kept_list = chunk_list + 2 * a.list_cap;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int row = 0;
+#pragma unroll 1
+            for (int g = wave; g < n_groups; g += nw) {
+                while (g >= __builtin_amdgcn_readfirstlane((int)rt.batch_start[row + 1])) ++row;
+                const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
+                const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
+                const int list_base = widths_c[k].list_base;
+                const int idx = (g - (int)rt.batch_start[row]) * kWave + lane;
+                const bool valid = idx < n_live;
+                const unsigned int unit = valid ? chunk_list[list_base + idx] : 0u;
+                const float u = valid ? ulist[list_base + idx] : -INFINITY;
+                const bool sel = (double)u >= T;   // invalid lanes hold -inf
+                const unsigned long long mask = __ballot(sel);
+                if (mask) {
+                    unsigned int base = 0;
+                    if (lane == 0) base = atomicAdd(&rt.singles[row], (unsigned int)__popcll(mask));
+                    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                    if (sel) kept_list[list_base + base + (unsigned int)__popcll(mask & below)] = unit;
+                }
+            }
+            __syncthreads();
+            for (int r2 = tid; r2 < n_rows; r2 += nt) { rt.live[r2] = rt.singles[r2]; rt.singles[r2] = 0; }
+            active_list = kept_list;
+            __syncthreads();
+        }
+        // Per row: (5b) re-list SPARSE rows.  A handful of
         // live chunks would still occupy a whole 64-lane batch with kR FMAs per tap, so such rows
         // are listed position by position (only positions that pass the predicate and the bound)
         // behind their chunk entries; phase 3b then runs them one window per lane, which costs a
@@ -3029,34 +3311,9 @@ tls_search_kernel(const SearchArgs a) {
             const int d = widths_c[k].width, list_base = widths_c[k].list_base;
             const double inv_d = widths_c[k].inv_d, dd = (double)d;
             const bool bound_row = prune_now && widths_c[k].prunable;
+            const bool screened_row = bound_row && screens_c[k].valid != 0;
             const double ov = widths_c[k].overshoot, k_mono = widths_c[k].k_mono, var_q = widths_c[k].var_q;
-            unsigned int* list = chunk_list + list_base;
-            if (bound_row && n_live > 0) {
-                // compaction in place: a 64-entry group is read before anything at or behind it is written
-                int n_sel = 0;
-                constexpr int kGroups = 4;   // reads of several groups in flight together
-#pragma unroll 1
-                for (int base = 0; base < n_live; base += kGroups * kWave) {
-                    unsigned int unit[kGroups];
-                    float u[kGroups];
-#pragma unroll
-                    for (int j = 0; j < kGroups; ++j) {
-                        const int idx = base + j * kWave + lane;
-                        const bool valid = idx < n_live;
-                        unit[j] = valid ? list[idx] : 0u;
-                        u[j] = valid ? ulist[list_base + idx] : -INFINITY;
-                    }
-#pragma unroll
-                    for (int j = 0; j < kGroups; ++j) {
-                        const bool sel = (double)u[j] >= T;   // invalid lanes hold -inf
-                        const unsigned long long mask = __ballot(sel);
-                        if (sel) list[n_sel + __popcll(mask & ((1ull << lane) - 1ull))] = unit[j];
-                        n_sel += __popcll(mask);
-                    }
-                }
-                n_live = n_sel;
-                __threadfence_block();   // the re-listing below reads entries other lanes have just moved
-            }
+            unsigned int* list = active_list + list_base;
             unsigned int count = 0;
             if (tiled && n_live > 0 && n_live <= kSparseRow && n_units >= (kR + 1) * kSparseRow) {
 #pragma unroll 1
@@ -3067,12 +3324,17 @@ tls_search_kernel(const SearchArgs a) {
                     if (idx < n_live * kR) {
                         u = (int)list[idx / kR] * kR + idx % kR;   // T0 position index
                         const int i = u * xth;
-                        const double dC = c_base[i + d] - c_base[i];   // past the grid: sentinel
-                        const int cls = depth_class(dC, inv_d, dmin);
-                        pass = cls > 0 || (cls < 0 && depth_exact(dC, dd, dmin));
-                        if (bound_row && pass)
-                            pass = (double)cell_bound(dC, dC, dd, inv_d, ov, k_mono, var_q,
-                                                      coarse_e2(P2, i, i + d, a.p2_shift, p2_blocks)) >= T;
+                        const double dX = c_base[i + d] - c_base[i];   // past the grid: sentinel
+                        pass = depth_pass(dX, inv_d, dd, dmin, rule.eps, exact_mode, undecided);
+                        if (bound_row && pass) {
+                            if (RESIDENT && screened_row)
+                                pass = (double)window_bound(c_base, i, d, dd, inv_d, ov, widths_c[k].sum_q2, screens_c + k, P2,
+                                                            a.p2_shift, p2_blocks, dmin, rule.eps, exact_mode, undecided,
+                                                            slack_unit * (double)(d + 64)) >= T;
+                            else
+                                pass = (double)cell_bound(dX, dX, dd, inv_d, ov, k_mono, var_q,
+                                                          coarse_e2(P2, i, i + d, a.p2_shift, p2_blocks)) >= T;
+                        }
                     }
                     const unsigned long long mask = __ballot(pass);
                     if (pass) list[n_live + count + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)u;
@@ -3104,6 +3366,13 @@ tls_search_kernel(const SearchArgs a) {
                 carry += __shfl(incl, kWave - 1, kWave);
             }
             if (lane == 0) { rt.batch_start[n_rows] = carry; *rt.next_batch = 0; }
+            if (a.phase_cycles && lane == 0) {
+                unsigned int kept = 0, singles = 0;
+                for (int row = 0; row < n_rows; ++row) { kept += rt.live[row]; singles += rt.singles[row]; }
+                atomicAdd(&a.phase_cycles[33], (unsigned long long)kept);
+                atomicAdd(&a.phase_cycles[34], (unsigned long long)singles);
+                atomicAdd(&a.phase_cycles[35], (unsigned long long)carry);
+            }
         }
         __syncthreads();
         pc.mark(6);
@@ -3135,7 +3404,7 @@ tls_search_kernel(const SearchArgs a) {
                 const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
                 const bool have = slot < (unsigned int)(n_singles ? n_singles : n_live);
                 // re-listed rows keep their positions behind the chunk entries
-                const int unit = have ? (int)chunk_list[list_base + (n_singles ? n_live : 0) + slot] : 0;
+                const int unit = have ? (int)active_list[list_base + (n_singles ? n_live : 0) + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
                 const unsigned long long evals_before = n_eval;
                 if (a.counters) {   // what the loops below issue per lane, padding and idle lanes included
@@ -3182,7 +3451,7 @@ tls_search_kernel(const SearchArgs a) {
                         for (int r = 0; r < kR; ++r) { cl[r] = c_base[b + r * xth]; ch[r] = c_base[b + r * xth + d]; }
 #pragma unroll
                         for (int r = 0; r < kR; ++r)
-                            consider(best, cl[r], ch[r], b + r * xth, inv_d, dd, dmin, overshoot, Av[r], Bv[r], k, n_eval);
+                            consider(best, cl[r], ch[r], b + r * xth, inv_d, dd, rule, overshoot, Av[r], Bv[r], k, n_eval, undecided);
                     }
                 } else {
                     // wide T0 strides and re-listed sparse rows: one window per lane
@@ -3214,7 +3483,7 @@ tls_search_kernel(const SearchArgs a) {
                         }
                         if (have) {
                             const int i = unit * xth;
-                            consider(best, regB[i], regB[i + d], i, inv_d, dd, dmin, overshoot, myA, myB, k, n_eval);
+                            consider(best, regB[i], regB[i + d], i, inv_d, dd, rule, overshoot, myA, myB, k, n_eval, undecided);
                         }
                         n_steps += (n_eval - evals_before) * (unsigned long long)L;
                         continue;
@@ -3250,14 +3519,28 @@ tls_search_kernel(const SearchArgs a) {
                             for (int u = 0; u < kU; ++u) { B0 = fma(qs[u], x[u], B0); A0 = fma(ps[u], z[u], A0); }
                         }
                     }
-                    if (have) consider(best, c_base[i], c_base[i + d], i, inv_d, dd, dmin, overshoot, A0 + A1, B0 + B1, k, n_eval);
+                    if (have) consider(best, c_base[i], c_base[i + d], i, inv_d, dd, rule, overshoot, A0 + A1, B0 + B1, k, n_eval, undecided);
                 }
                 n_steps += (n_eval - evals_before) * (unsigned long long)L;
             }
         }
         pc.mark(7);
         }  // position tiles
+        // fast mode: a window too close to transit_depth_min for the plain prefix sum to decide (depth_pass) sends the
+        // whole period through exact mode; nothing of this attempt is written or counted
+        // (an LDS flag, not __syncthreads_or: the library routine brings static LDS of its own, and the slab variant's
+        // launches already ask for all 160 KB)
+        if (undecided) s_work[flag_slot] = 1;
         __syncthreads();
+        const int any_undecided = __builtin_amdgcn_readfirstlane(s_work[flag_slot]);
+        if (tid == 0) s_work[3 - flag_slot] = 0;   // the next attempt's flag: nobody touches it before several barriers from now
+        flag_slot = 3 - flag_slot;
+        if (any_undecided != 0 && !exact_mode) {
+            if (a.phase_cycles && tid == 0) atomicAdd(&a.phase_cycles[37], 1ull);
+            if (a.n_curves > 1) { curve_exact = true; --curve; continue; }   // this curve again; the others are not touched
+            retry_exact = true;   // one light curve: its permutation is gone (the prefix sum took its place) -- sort again
+            break;
+        }
         pc.mark(21);
 
         // ---- phase 4: argmin over the workgroup --------------------------------------
@@ -3307,6 +3590,8 @@ tls_search_kernel(const SearchArgs a) {
         }
         __syncthreads();
         }  // light curves of the batch
+        if (a.period_cycles && tid == 0) atomicAdd(&a.period_cycles[p], (unsigned long long)(clock64() - t_period));
+        // (a retry re-enters the period loop with the same work item)
     }
 }
 

@@ -35,6 +35,24 @@ def partition_by_cost(costs, n_ranks):
     return numpy.asarray(bounds, dtype=numpy.int64)
 
 
+# Time model of one period for the placement of the block boundaries: a * N + b * cells + c * taps (N points: fold,
+# sort and prefix sum are O(N) per period whatever its duration window; cells: the depth predicate; taps: the
+# sliding chi^2 of the cells that pass it).  Coefficients in shader cycles, fitted to tls_debug_period_cycles on an
+# MI355X by tools/gpu_cost_model.py (profiles/r03_cost_model_fit.json); only their ratios matter here.  Balancing
+# cells alone leaves the blocks of short periods -- many cheap periods, each with the full fixed cost -- 1.4-1.6x
+# slower than the blocks of long ones at 8 ranks.
+COST_MODEL = {
+    # variant: (a per point, b per trial cell, c per expected template tap)
+    "resident": (20.0, 0.6, 0.08),
+    "slab": (30.0, 0.5, 0.05),
+}
+
+
+def period_time_model(n_points, cells, taps, resident):
+    a, b, c = COST_MODEL["resident" if resident else "slab"]
+    return a * float(n_points) + b * numpy.asarray(cells, dtype=numpy.float64) + c * numpy.asarray(taps, dtype=numpy.float64)
+
+
 def assemble(gathered, bounds, count_per_rank):
     """Undo the padding of an all-gather: `gathered` has n_ranks blocks of
     count_per_rank entries; block r carries bounds[r+1]-bounds[r] valid ones."""

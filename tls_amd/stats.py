@@ -67,18 +67,50 @@ def rp_rs_from_depth(depth, law, params):
     return (depth * factor) ** (1 / 2)
 
 
+def _window_sums(cols):
+    """Sum over the window axis of `cols` (a list of equally long vectors: element j of every window),
+    in the association numpy's own reduction uses on a contiguous window (pairwise summation: eight
+    interleaved partial sums per block of at most 128, blocks halved recursively), so that the result
+    equals numpy.sum(window) bit for bit for every window at once."""
+    n = len(cols)
+    if n < 8:
+        total = cols[0].copy()
+        for c in cols[1:]:
+            total += c
+        return total
+    if n <= 128:
+        r = [cols[j].copy() for j in range(8)]
+        full = n - n % 8
+        for i in range(8, full, 8):
+            for j in range(8):
+                r[j] += cols[i + j]
+        total = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for i in range(full, n):
+            total += cols[i]
+        return total
+    half = n // 2
+    half -= half % 8
+    return _window_sums(cols[:half]) + _window_sums(cols[half:])
+
+
 def pink_noise(data, width):
     """Mean over all windows of `width` points of std(window)/sqrt(width)
-    (reference stats.py:72-77).  Window statistics in one vectorised call; the
-    running total is accumulated left to right like the reference's loop."""
-    data = numpy.asarray(data, dtype=float)
+    (reference stats.py:72-77).  The two passes of numpy.std run as `width` shifted vector
+    operations over all windows at once, summed in numpy's own order (_window_sums), and the
+    running total is accumulated left to right like the reference's loop: bit-identical to it,
+    at a tenth of the cost of numpy.std over the short axis of a sliding-window view."""
+    data = numpy.ascontiguousarray(data, dtype=float)
+    width = int(width)
     n_windows = len(data) - width + 1
-    windows = numpy.lib.stride_tricks.sliding_window_view(data, width)
-    terms = numpy.std(windows, axis=1) / width ** 0.5
-    total = 0
-    for v in terms.tolist():
-        total += v
-    return total / n_windows
+    if width < 1 or n_windows < 1:
+        raise ValueError("window longer than the data")   # (the reference divides by zero here)
+    cols = [data[j:j + n_windows] for j in range(width)]
+    mean = _window_sums(cols) / width
+    dev = [c - mean for c in cols]
+    for v in dev:
+        v *= v
+    terms = numpy.sqrt(_window_sums(dev) / width) / width ** 0.5
+    return numpy.cumsum(terms)[-1] / n_windows
 
 
 def period_uncertainty(periods, power):
@@ -182,12 +214,37 @@ def _points_between(t, lo, hi):
     return numpy.where(numpy.logical_and(t > lo, t < hi))
 
 
+def _is_ascending(t):
+    return bool(numpy.all(t[1:] >= t[:-1]))
+
+
+def _open_interval_slices(t, lo, hi):
+    """[start, stop) index ranges of the points with lo < t < hi for arrays of bounds, for
+    ASCENDING t (two binary searches per interval instead of two passes over the series).
+    NaN bounds give empty ranges, like the reference's comparisons."""
+    lo, hi = numpy.asarray(lo, dtype=float), numpy.asarray(hi, dtype=float)
+    start = numpy.searchsorted(t, lo, side="right")
+    stop = numpy.searchsorted(t, hi, side="left")
+    bad = numpy.isnan(lo) | numpy.isnan(hi)
+    stop = numpy.where(bad, start, numpy.maximum(stop, start))
+    return start, stop
+
+
 def count_stats(t, y, transit_times, transit_duration_in_days):
     """Numbers of points in transit and in equally long windows right before and
     after, over epochs fully inside the data (reference stats.py:304-342)."""
-    n_in = n_after = n_before = 0
     d = transit_duration_in_days
     t_first, t_last = numpy.min(t), numpy.max(t)   # (the builtins walk the array element by element)
+    if _is_ascending(t):
+        mid = numpy.asarray(transit_times, dtype=float)
+        edges = [mid - 1.5 * d, mid - 0.5 * d, mid + 0.5 * d, mid + 1.5 * d]
+        inside = numpy.logical_and(edges[0] > t_first, edges[3] < t_last)
+        counts = []
+        for a, b in ((0, 1), (1, 2), (2, 3)):
+            start, stop = _open_interval_slices(t, edges[a], edges[b])
+            counts.append(int(numpy.sum((stop - start)[inside])))
+        return counts[1], counts[2], counts[0]
+    n_in = n_after = n_before = 0
     for mid in transit_times:
         edges = (mid - 1.5 * d, mid - 0.5 * d, mid + 0.5 * d, mid + 1.5 * d)
         if edges[0] > t_first and edges[3] < t_last:
@@ -201,34 +258,50 @@ def _mean_and_err(values):
     return numpy.mean(values), numpy.std(values) / numpy.sum(len(values)) ** (0.5)
 
 
-def intransit_stats(t, y, transit_times, transit_duration_in_days):
+def _intransit_fluxes(t, y, transit_times, transit_duration_in_days):
+    """The in-transit flux of every epoch (mid - d/2 < t < mid + d/2), as a list of arrays."""
+    mid = numpy.asarray(transit_times, dtype=float)
+    lo = mid - 0.5 * transit_duration_in_days
+    hi = mid + 0.5 * transit_duration_in_days
+    if _is_ascending(t):
+        start, stop = _open_interval_slices(t, lo, hi)
+        return [y[a:b] for a, b in zip(start.tolist(), stop.tolist())]
+    out = []
+    for a, b in zip(lo, hi):
+        out.append(y[:0] if (numpy.isnan(a) or numpy.isnan(b)) else y[_points_between(t, a, b)])
+    return out
+
+
+def _segment_means_and_stds(chunks):
+    """(size, mean, population std) of every chunk in one go: two-pass like numpy.std, NaN for
+    empty chunks."""
+    sizes = numpy.array([len(c) for c in chunks], dtype=numpy.int64)
+    means = numpy.full(len(chunks), numpy.nan)
+    stds = numpy.full(len(chunks), numpy.nan)
+    filled = numpy.nonzero(sizes)[0]
+    if len(filled):
+        flat = numpy.concatenate([chunks[i] for i in filled])
+        cnt = sizes[filled]
+        starts = numpy.concatenate([[0], numpy.cumsum(cnt)[:-1]])
+        m = numpy.add.reduceat(flat, starts) / cnt
+        dev = flat - numpy.repeat(m, cnt)
+        means[filled] = m
+        stds[filled] = numpy.sqrt(numpy.add.reduceat(dev * dev, starts) / cnt)
+    return sizes, means, stds
+
+
+def intransit_stats(t, y, transit_times, transit_duration_in_days, chunks=None):
     """Per-epoch in-transit flux statistics and the odd/even split
     (reference stats.py:345-416; even = epochs 0, 2, 4, ...)."""
-    n_epochs = len(transit_times)
-    flux_odd = numpy.array([])
-    flux_even = numpy.array([])
-    per_transit_count = numpy.zeros([n_epochs])
-    transit_depths = numpy.zeros([n_epochs])
-    transit_depths_uncertainties = numpy.zeros([n_epochs])
-    for i, mid in enumerate(transit_times):
-        lo = mid - 0.5 * transit_duration_in_days
-        hi = mid + 0.5 * transit_duration_in_days
-        if numpy.isnan(lo) or numpy.isnan(hi):
-            inside = y[:0]
-        else:
-            inside = y[_points_between(t, lo, hi)]
-        n_inside = numpy.size(inside)
-        per_transit_count[i] = n_inside
-        if n_inside > 0:
-            transit_depths[i] = numpy.mean(inside)
-            transit_depths_uncertainties[i] = numpy.std(inside) / numpy.sqrt(n_inside)
-        else:
-            transit_depths[i] = numpy.nan
-            transit_depths_uncertainties[i] = numpy.nan
-        if i % 2 == 0:
-            flux_even = numpy.append(flux_even, inside)
-        else:
-            flux_odd = numpy.append(flux_odd, inside)
+    if chunks is None:
+        chunks = _intransit_fluxes(t, y, transit_times, transit_duration_in_days)
+    sizes, transit_depths, stds = _segment_means_and_stds(chunks)
+    per_transit_count = sizes.astype(float)
+    with numpy.errstate(invalid="ignore", divide="ignore"):
+        transit_depths_uncertainties = stds / numpy.sqrt(per_transit_count)
+    empty = numpy.zeros(0)
+    flux_even = numpy.concatenate([empty] + chunks[0::2])
+    flux_odd = numpy.concatenate([empty] + chunks[1::2])
     mean_odd, err_odd = _mean_and_err(flux_odd) if len(flux_odd) > 0 else (numpy.nan, numpy.nan)
     mean_even, err_even = (_mean_and_err(flux_even) if len(flux_even) > 0
                            else (numpy.nan, numpy.nan))
@@ -237,34 +310,22 @@ def intransit_stats(t, y, transit_times, transit_duration_in_days):
 
 
 def snr_stats(t, y, period, duration, T0, transit_times, transit_duration_in_days,
-              per_transit_count):
+              per_transit_count, chunks=None, flux_ootr=None):
     """Per-epoch white-noise and pink-noise SNR (reference stats.py:419-469)."""
-    n_epochs = len(transit_times)
-    snr_per_transit = numpy.zeros([n_epochs])
-    snr_pink_per_transit = numpy.zeros([n_epochs])
-    flux_ootr = y[~transit_mask(t, period, 2 * duration, T0)]
+    if flux_ootr is None:
+        flux_ootr = y[~transit_mask(t, period, 2 * duration, T0)]
     try:
         pinknoise = pink_noise(flux_ootr, int(numpy.mean(per_transit_count)))
     except Exception:
         pinknoise = numpy.nan
     std = numpy.std(flux_ootr) if len(flux_ootr) > 0 else numpy.nan
-    for i, mid in enumerate(transit_times):
-        lo = mid - 0.5 * transit_duration_in_days
-        hi = mid + 0.5 * transit_duration_in_days
-        if numpy.isnan(lo) or numpy.isnan(hi):
-            inside = y[:0]
-        else:
-            inside = y[_points_between(t, lo, hi)]
-        n_inside = numpy.size(inside)
-        mean_flux = numpy.mean(inside) if n_inside > 0 else numpy.nan
-        try:
-            snr_pink_per_transit[i] = (1 - mean_flux) / pinknoise
-            if n_inside > 0 and not numpy.isnan(std):
-                snr_per_transit[i] = (1 - mean_flux) / (std / n_inside ** 0.5)
-            else:
-                snr_per_transit[i] = 0
-                snr_pink_per_transit[i] = 0
-        except Exception:
-            snr_per_transit[i] = 0
-            snr_pink_per_transit[i] = 0
+    if chunks is None:
+        chunks = _intransit_fluxes(t, y, transit_times, transit_duration_in_days)
+    sizes, mean_flux, _ = _segment_means_and_stds(chunks)
+    with numpy.errstate(invalid="ignore", divide="ignore"):
+        snr_pink = (1 - mean_flux) / pinknoise
+        snr_white = (1 - mean_flux) / (std / numpy.sqrt(sizes.astype(float)))
+    usable = numpy.logical_and(sizes > 0, not numpy.isnan(std))
+    snr_per_transit = numpy.where(usable, snr_white, 0.0)
+    snr_pink_per_transit = numpy.where(usable, snr_pink, 0.0)
     return snr_per_transit, snr_pink_per_transit

@@ -19,6 +19,7 @@ from .interp import interp1d
 
 
 _CURVES = {}  # shape parameters -> (t, flux, first in-transit sample): the model is the costly part
+_SHAPES = {}  # (samples, shape parameters) -> the resampled in-transit shape (power() asks for the same few per call)
 
 
 def _supersampled_curve(per, rp, a, inc, ecc, w, u, limb_dark):
@@ -42,14 +43,23 @@ def reference_transit(samples, per, rp, a, inc, ecc, w, u, limb_dark):
     """In-transit part of the template planet's light curve, resampled to
     `samples` points and rescaled to depth 1 (0 = bottom, 1 = out of transit).
     Reference transit.py:8-42."""
-    t, flux, first = _supersampled_curve(per, rp, a, inc, ecc, w, u, limb_dark)
-    # the slice is one sample longer on the egress side (transit.py:29-30)
-    in_flux = flux[first: -first + 1]
-    in_time = t[first: -first + 1]
-    x_new = numpy.linspace(t[first], t[-first - 1], samples)
-    down = interp1d(x_new, in_time)(in_flux)
-    lo = numpy.min(down)
-    return (lo - down) / (lo - 1)
+    key = (int(samples), float(per), float(rp), float(a), float(inc), float(ecc), float(w),
+           tuple(float(x) for x in u), str(limb_dark))
+    hit = _SHAPES.get(key)
+    if hit is None:
+        t, flux, first = _supersampled_curve(per, rp, a, inc, ecc, w, u, limb_dark)
+        # the slice is one sample longer on the egress side (transit.py:29-30)
+        in_flux = flux[first: -first + 1]
+        in_time = t[first: -first + 1]
+        x_new = numpy.linspace(t[first], t[-first - 1], samples)
+        down = interp1d(x_new, in_time)(in_flux)
+        lo = numpy.min(down)
+        hit = (lo - down) / (lo - 1)
+        hit.setflags(write=False)   # shared between calls
+        if len(_SHAPES) >= 32:
+            _SHAPES.pop(next(iter(_SHAPES)))
+        _SHAPES[key] = hit
+    return hit
 
 
 def fractional_transit(duration, maxwidth, depth, samples, per, rp, a, inc, ecc, w, u,

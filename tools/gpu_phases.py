@@ -22,8 +22,10 @@ for case in cases:
     ctx.execute(phase_clock=True)
     ph = ctx.phase_cycles()
     blocks, fails = ph.pop("cumsum_blocks"), ph.pop("cumsum_fallbacks")
+    stats = {k: ph.pop(k) for k in list(ph) if k.startswith("stat_")}
     tot = sum(ph.values())
     info = ctx.plan_info()
     print(case, "%.3f ms" % ms, "cells/s %.3e" % (info["grid_cells"] / ms * 1e3),
           "cyc/period/wg %.0f" % (tot / len(periods)), "cumsum blocks %d fallbacks %d |" % (blocks, fails),
-          " ".join("%s=%.1f" % (k, 100.0 * v / tot) for k, v in ph.items() if v >= 0.004 * tot), flush=True)
+          " ".join("%s=%.1f" % (k, 100.0 * v / tot) for k, v in ph.items() if v >= 0.004 * tot),
+          "| per period:", " ".join("%s=%.1f" % (k[5:], v / len(periods)) for k, v in stats.items() if v), flush=True)
