@@ -3151,10 +3151,23 @@ tls_search_kernel(const SearchArgs a) {
             float cand_u = -INFINITY;
             int cand_k = 0x7fffffff, cand_unit = 0;
             {
-                int row = 0;
+                // (the list entry of the NEXT group is requested before this group's bound is formed: the lists live in
+                // global memory, and an L2 round trip per group, one after the other, was most of this pass)
+                int row = 0, row_next = 0, unit_next = 0;
+                if (wave < n_groups) {
+                    while (wave >= __builtin_amdgcn_readfirstlane((int)rt.batch_start[row_next + 1])) ++row_next;
+                    const int idx0 = (wave - (int)rt.batch_start[row_next]) * kWave + lane;
+                    if (idx0 < (int)rt.live[row_next]) unit_next = (int)chunk_list[widths_c[k_lo + row_next].list_base + idx0];
+                }
 #pragma unroll 1
                 for (int g = wave; g < n_groups; g += nw) {
-                    while (g >= __builtin_amdgcn_readfirstlane((int)rt.batch_start[row + 1])) ++row;
+                    row = row_next;
+                    const int unit_now = unit_next;
+                    if (g + nw < n_groups) {
+                        while (g + nw >= __builtin_amdgcn_readfirstlane((int)rt.batch_start[row_next + 1])) ++row_next;
+                        const int idx1 = (g + nw - (int)rt.batch_start[row_next]) * kWave + lane;
+                        unit_next = idx1 < (int)rt.live[row_next] ? (int)chunk_list[widths_c[k_lo + row_next].list_base + idx1] : 0;
+                    }
                     const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
                     const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
                     const int xth = widths_c[k].xth, tiled = widths_c[k].tiled, d = widths_c[k].width;
@@ -3169,7 +3182,7 @@ tls_search_kernel(const SearchArgs a) {
                     const int step = tiled ? kR * xth : xth;            // samples between two units
                     const int idx = (g - (int)rt.batch_start[row]) * kWave + lane;
                     const bool valid = idx < n_live;
-                    const int unit = valid ? (int)chunk_list[list_base + idx] : 0;
+                    const int unit = valid ? unit_now : 0;
                     const int b = unit * step;
                     float u = INFINITY;   // rows without a valid bound are always evaluated
                     if (screened) {
@@ -3274,17 +3287,37 @@ tls_search_kernel(const SearchArgs a) {
             // irrelevant).  The first set is still being read by the other waves, so nothing is compacted in place.
             unsigned int* const kept_list = chunk_list + 2 * a.list_cap;
             const unsigned long long below = (1ull << lane) - 1ull;
-            int row = 0;
+            // (all of a wave's entries are requested before the first is used: up to kAhead groups in flight)
+            constexpr int kAhead = 4;
 #pragma unroll 1
-            for (int g = wave; g < n_groups; g += nw) {
-                while (g >= __builtin_amdgcn_readfirstlane((int)rt.batch_start[row + 1])) ++row;
+            for (int g0 = wave; g0 < n_groups; g0 += kAhead * nw) {
+            unsigned int unit_a[kAhead];
+            float u_a[kAhead];
+            int row_a[kAhead];
+            {
+                int row = 0;
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) {
+                    const int g = g0 + j * nw;
+                    unit_a[j] = 0u; u_a[j] = -INFINITY; row_a[j] = 0;
+                    if (g < n_groups) {
+                        while (g >= __builtin_amdgcn_readfirstlane((int)rt.batch_start[row + 1])) ++row;
+                        row_a[j] = row;
+                        const int list_base = widths_c[k_lo + row].list_base;
+                        const int idx = (g - (int)rt.batch_start[row]) * kWave + lane;
+                        if (idx < (int)rt.live[row]) { unit_a[j] = chunk_list[list_base + idx]; u_a[j] = ulist[list_base + idx]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                const int g = g0 + j * nw;
+                if (g >= n_groups) break;
+                const int row = __builtin_amdgcn_readfirstlane(row_a[j]);
                 const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
-                const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
                 const int list_base = widths_c[k].list_base;
-                const int idx = (g - (int)rt.batch_start[row]) * kWave + lane;
-                const bool valid = idx < n_live;
-                const unsigned int unit = valid ? chunk_list[list_base + idx] : 0u;
-                const float u = valid ? ulist[list_base + idx] : -INFINITY;
+                const unsigned int unit = unit_a[j];
+                const float u = u_a[j];
                 const bool sel = (double)u >= T;   // invalid lanes hold -inf
                 const unsigned long long mask = __ballot(sel);
                 if (mask) {
@@ -3293,6 +3326,7 @@ tls_search_kernel(const SearchArgs a) {
                     base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
                     if (sel) kept_list[list_base + base + (unsigned int)__popcll(mask & below)] = unit;
                 }
+            }
             }
             __syncthreads();
             for (int r2 = tid; r2 < n_rows; r2 += nt) { rt.live[r2] = rt.singles[r2]; rt.singles[r2] = 0; }
