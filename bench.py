@@ -215,6 +215,7 @@ class Harness(object):
         elapsed = time.perf_counter() - t0
         kernel_ms, launches = ctx.kernel_timing(reset=True)
         kernel_ms = kernel_ms / max(launches, 1)
+        self.own_kernel_ms = kernel_ms
         if self.world > 1:
             elapsed = self.reduce_max(elapsed)
             kernel_ms = self.reduce_max(kernel_ms)
@@ -252,14 +253,14 @@ def run_survey(h, args, inp):
     return elapsed, kernel_ms
 
 
-def run_shard(h, args, config):
+def run_shard(h, args, config, steps=None):
     """Period-shard layout: ONE light curve per step, its period grid block-partitioned by cumulative
     trial-cell cost (tls_amd/shard.py), one all-gather per light curve."""
     ctx = h.ctx
     t, flux, kw = synthetic.config(config, seed=0)
     inp = synthetic.search_inputs(t, flux, **kw)
     job = shard.ShardedSearch(h.rank, h.world)
-    lo, hi = job.plan(inp["t"], inp["periods"], inp["table"], inp["params"])
+    lo, hi = job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"])
     ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"][lo:hi], inp["table"], inp["params"])
     c = job.count_per_rank
 
@@ -273,7 +274,9 @@ def run_shard(h, args, config):
             cc, rr, dd = ctx.fetch()
             h.channel.allgather_bytes(cc.tobytes() + rr.tobytes() + dd.tobytes())
 
-    elapsed, kernel_ms = h.timed(step, lambda: None, args.steps, args.warmup)
+    n_steps = args.steps if steps is None else steps
+    elapsed, kernel_ms = h.timed(step, lambda: None, n_steps, min(args.warmup, n_steps))
+    own_kernel_ms = [h.own_kernel_ms]
     argmin = None
     if h.collective == "rccl":
         g = ctx.comm_fetch_gathered(c, h.world)
@@ -281,12 +284,23 @@ def run_shard(h, args, config):
         assert len(chi2) == len(inp["periods"])
         argmin = int(numpy.argmin(chi2))
     cells = numpy.array([numpy.sum(job.costs[job.bounds[r]:job.bounds[r + 1]]) for r in range(h.world)], dtype=float)
+    model = numpy.array([numpy.sum(job.times[job.bounds[r]:job.bounds[r + 1]]) for r in range(h.world)], dtype=float)
     total = float(numpy.sum(job.costs))
+    # measured balance: every rank's own kernel time per step (HIP events), gathered over the host channel
+    kernel_ms_ranks = None
+    if h.channel is not None:
+        import struct
+        parts = h.channel.allgather_bytes(struct.pack("<d", own_kernel_ms[0]))
+        kernel_ms_ranks = [struct.unpack("<d", b)[0] for b in parts]
     return {"config": config, "points": len(inp["t"]), "periods": len(inp["periods"]), "trial_cells": total,
-            "value": total * args.steps / elapsed, "unit": "trial cells/s", "scaling": "strong",
-            "ms_per_step": 1e3 * elapsed / args.steps, "kernel_ms_max_rank": kernel_ms,
+            "value": total * n_steps / elapsed, "unit": "trial cells/s", "scaling": "strong", "steps": n_steps,
+            "ms_per_step": 1e3 * elapsed / n_steps, "kernel_ms_max_rank": kernel_ms,
             "cells_per_rank_max": float(cells.max()), "cells_per_rank_mean": float(cells.mean()),
-            "imbalance_max_over_mean": float(cells.max() / cells.mean()),
+            "cells_imbalance_max_over_mean": float(cells.max() / cells.mean()),
+            "modelled_time_imbalance_max_over_mean": float(model.max() / model.mean()),
+            "kernel_ms_per_rank": kernel_ms_ranks,
+            "measured_time_imbalance_max_over_mean": (float(max(kernel_ms_ranks) / (sum(kernel_ms_ranks) / len(kernel_ms_ranks)))
+                                                      if kernel_ms_ranks else None),
             "periods_per_rank": [int(job.bounds[r + 1] - job.bounds[r]) for r in range(h.world)],
             "argmin_period_index": argmin}
 
@@ -314,6 +328,37 @@ def large_config(ctx, name, reps):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo,
                          "traffic": traffic, "traffic_source": source}}
+
+
+def shard_balance(ctx, name, n_blocks=8, reps=3):
+    """The period-shard layout measured on ONE GPU: the grid cut into `n_blocks` contiguous blocks by the time
+    model (tls_amd/shard.py), every block searched alone -- what each of `n_blocks` ranks would run -- and its kernel
+    time taken with HIP events.  max/mean of those times is the balance an 8-GPU run would see (the all-gather of
+    24 B per period aside); the same for blocks placed by trial cells alone is what round 2 shipped."""
+    t, flux, kw = synthetic.config(name, seed=0)
+    inp = synthetic.search_inputs(t, flux, **kw)
+    out = {"config": name, "blocks": n_blocks, "periods": len(inp["periods"])}
+    whole_ms = None
+    for label in ("time_model", "cells_only"):
+        job = shard.ShardedSearch(0, n_blocks)
+        job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"])
+        bounds = job.bounds if label == "time_model" else shard.partition_by_cost(job.costs, n_blocks)
+        ms = []
+        for r in range(n_blocks):
+            ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"][bounds[r]:bounds[r + 1]], inp["table"], inp["params"])
+            ctx.execute()
+            ctx.synchronize()
+            ms.append(ctx.execute_timed(reps))
+        out[label] = {"periods_per_block": [int(bounds[r + 1] - bounds[r]) for r in range(n_blocks)],
+                      "kernel_ms_per_block": ms, "max_over_mean": max(ms) / (sum(ms) / len(ms)),
+                      "slowest_block_ms": max(ms)}
+    ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+    ctx.execute()
+    ctx.synchronize()
+    whole_ms = ctx.execute_timed(reps)
+    out["whole_grid_kernel_ms"] = whole_ms
+    out["speedup_if_ranks_ran_the_blocks"] = whole_ms / out["time_model"]["slowest_block_ms"]
+    return out
 
 
 def survey_1024(ctx, n_curves):
@@ -378,8 +423,9 @@ def main():
     shard_out = None
     if world > 1 and args.mode in ("both", "shard"):
         shard_out = [run_shard(h, args, args.config)]
-        if args.config != "tess_27d":
-            shard_out.append(run_shard(h, args, "tess_27d"))
+        for other_cfg in ("tess_27d", "kepler_4yr"):   # BASELINE config 4, and config 3: the one grid with room to scale
+            if args.config != other_cfg:
+                shard_out.append(run_shard(h, args, other_cfg, steps=max(1, min(args.steps, 3)) if other_cfg == "kepler_4yr" else None))
         if elapsed is None:   # --mode shard: the first shard run is the headline
             elapsed = shard_out[0]["ms_per_step"] * 1e-3 * args.steps
             kernel_ms = shard_out[0]["kernel_ms_max_rank"]
@@ -396,16 +442,26 @@ def main():
         # buffers out: planning + H2D + kernel + D2H (tls_search), best of 5
         one_shot = None
         if extras:
-            best = float("inf")
-            for _ in range(5):
+            # cold: the context holds the plan of ANOTHER period grid, so tls_prepare plans from scratch (duration
+            # windows, work order, template rows, one pinned upload).  warm: the same time stamps / grid / template
+            # as the call before (a survey, repeated power() calls): the library recognises the plan and only the
+            # flux travels.  Both: host buffers in, host buffers out.
+            def one_call(per):
                 t1 = time.perf_counter()
-                ctx.prepare(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
+                ctx.prepare(inp["t"], inp["y"], inp["dy"], per, inp["table"], inp["params"])
                 ctx.execute()
                 ctx.fetch()
-                best = min(best, time.perf_counter() - t1)
-            one_shot = {"ms": 1e3 * best, "trial_cells_per_s": info["grid_cells"] / best,
-                        "what": "tls_prepare + tls_execute + tls_fetch from host buffers (= tls_search): host "
-                                "planning, H2D, kernel, D2H"}
+                return time.perf_counter() - t1
+            cold = warm = float("inf")
+            for _ in range(5):
+                one_call(periods[:-1])          # evicts the plan
+                cold = min(cold, one_call(periods))
+                warm = min(warm, one_call(periods))
+            one_shot = {"ms": 1e3 * warm, "trial_cells_per_s": info["grid_cells"] / warm,
+                        "cold_ms": 1e3 * cold, "cold_trial_cells_per_s": info["grid_cells"] / cold,
+                        "what": "tls_prepare + tls_execute + tls_fetch from host buffers (= tls_search): H2D, kernel, "
+                                "D2H; `ms` with the plan of the previous call reused inside the library (same t, "
+                                "periods, template: a survey), `cold_ms` with host planning from scratch"}
 
         # the same grid at 500 ppm noise, where 55 % of the cells pass the depth predicate instead of 11 %
         noisy = None
@@ -444,6 +500,12 @@ def main():
                 other["survey_1024"] = survey_1024(ctx, args.survey_curves)
             except Exception as exc:
                 other["survey_1024"] = {"error": str(exc)[:300]}
+            other["shard_balance"] = []
+            for name in ("k2_90d", "tess_27d", "kepler_4yr"):
+                try:
+                    other["shard_balance"].append(shard_balance(ctx, name, 8, 2 if name == "kepler_4yr" else 5))
+                except Exception as exc:
+                    other["shard_balance"].append({"config": name, "error": str(exc)[:300]})
 
         n = len(inp["t"])
         ms_per_step = 1e3 * elapsed / args.steps
@@ -463,6 +525,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak" if survey_ran else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "value_one_shot": (one_shot or {}).get("trial_cells_per_s"),   # host buffers in and out
             "config": {"workload": "%s: %d points, %d periods x %d durations, %.3e trial cells per "
                                    "light curve; %s" % (
                                        args.config, n, len(periods), inp["table"].n_rows, info["grid_cells"],

@@ -180,13 +180,16 @@ int tls_spectra(tls_ctx *ctx, const double *chi2, int64_t n, int64_t kernel, dou
 int tls_grid_cells(const double *t, int64_t n, const double *periods, int64_t n_periods,
                    const tls_template *tmpl, const tls_params *params,
                    int64_t *cells_per_period);
-/* The two data-independent cost features of every period the shard cost model uses (tls_amd/shard.py): its trial
- * cells (as tls_grid_cells) and its expected template taps -- per in-range duration: trial positions x template
- * length x the fraction of white-noise windows of scatter `sigma` whose mean depth exceeds transit_depth_min
- * (core.py:58), the cells the sliding chi^2 of core.py:59-74 is evaluated for (sigma <= 0: all of them). */
+/* The cost of every period for the placement of shard boundaries (tls_amd/shard.py): its trial cells (as
+ * tls_grid_cells), its expected template taps -- per in-range duration: trial positions x template length x the
+ * fraction of white-noise windows of scatter `sigma` whose mean depth exceeds transit_depth_min (core.py:58), the
+ * cells the sliding chi^2 of core.py:59-74 is evaluated for (sigma <= 0: all of them) -- and (time_per_period, may be
+ * NULL) the modelled search time of the period in shader cycles of the kernel variant tls_prepare would choose:
+ * a fixed part per period (fold, sort, prefix sum: O(n) whatever the duration window) + a part per trial cell
+ * (depth predicate) + a part per expected tap, coefficients measured on an MI355X. */
 int tls_period_costs(const double *t, int64_t n, const double *periods, int64_t n_periods,
                      const tls_template *tmpl, const tls_params *params, double sigma,
-                     int64_t *cells_per_period, double *taps_per_period);
+                     int64_t *cells_per_period, double *taps_per_period, double *time_per_period);
 
 /* ---- multi-GPU: period grid sharded over ranks, one RCCL all-gather at the end --- */
 /* rank 0 creates the 128-byte id and hands it to the other ranks by any host channel */

@@ -53,7 +53,7 @@ def _worker(rank, world, port, out_dir):
     inp = synthetic.search_inputs(t, f, period_min=1.0, period_max=6.0)
     periods, p = inp["periods"], inp["params"]
     job = sh.ShardedSearch(rank, world)
-    lo, hi = job.plan(inp["t"], periods, inp["table"], p)
+    lo, hi = job.plan(inp["t"], periods, inp["table"], p, y=inp["y"])
     chi2, row, depth, _ = oracle.search(inp["t"], inp["y"], inp["dy"], periods[lo:hi], inp["table"],
                                         p["transit_depth_min"], p["R_star_min"], p["R_star_max"],
                                         p["M_star_min"], p["M_star_max"], p["T0_fit_margin"],
@@ -71,7 +71,7 @@ def _worker(rank, world, port, out_dir):
 
     full = job.gather(gloo_allgather)
     numpy.savez(os.path.join(out_dir, "rank%d.npz" % rank), chi2=full[0], row=full[1],
-                depth=full[2], lo=lo, hi=hi, cells=job.my_cells())
+                depth=full[2], lo=lo, hi=hi, cells=job.my_cells(), time=float(numpy.sum(job.times[lo:hi])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -97,5 +97,37 @@ def test_sharded_search_equals_single_process(tmp_path, oracle_lib, world):
     assert ranks[0]["lo"] == 0 and ranks[-1]["hi"] == len(inp["periods"])
     for a, b in zip(ranks[:-1], ranks[1:]):
         assert a["hi"] == b["lo"]
-    cells = numpy.array([int(r["cells"]) for r in ranks])
-    assert cells.max() / cells.mean() < 1.05
+    # ... and balanced in MODELLED TIME (tls_period_costs), which is what the boundaries are placed by
+    times = numpy.array([float(r["time"]) for r in ranks])
+    assert times.max() / times.mean() < 1.05
+    assert sum(int(r["cells"]) for r in ranks) == int(numpy.sum(shard._lib.grid_cells(inp["t"], inp["periods"], inp["table"], inp["params"])))
+
+
+@pytest.mark.parametrize("fixture,limit", [("k2_90d", 1.05), ("tess_27d", 1.06), ("kepler_4yr_8", 1.06), ("k2_90d_500", 1.05)])
+def test_time_model_balances_measured_period_cycles(fixture, limit):
+    """The shard boundaries against MEASURED per-period shader cycles (tls_debug_period_cycles on an MI355X,
+    tools/gpu_cost_model.py; committed as tests/golden/period_cycles_*.npz): blocks placed by the time model of
+    tls_period_costs are balanced in measured time at 2, 4 and 8 ranks; blocks placed by trial cells alone (round 2)
+    are not."""
+    from tls_amd import synthetic
+    g = numpy.load(os.path.join(os.path.dirname(__file__), "golden", "period_cycles_%s.npz" % fixture))
+    sigma = float(g["sigma_ppm"]) * 1e-6 or None
+    t, f, kw = synthetic.config(str(g["config"]), sigma=sigma)
+    inp = synthetic.search_inputs(t, f, **kw)
+    periods = inp["periods"][::int(g["stride"])]
+    cycles = g["cycles"].astype(float)
+    assert len(cycles) == len(periods)
+    job = shard.ShardedSearch(0, 1)
+    job.plan(inp["t"], periods, inp["table"], inp["params"], y=inp["y"])
+    worst_model = worst_cells = 0.0
+    for ranks in (2, 4, 8):
+        for cost, label in ((job.times, "model"), (job.costs.astype(float), "cells")):
+            b = shard.partition_by_cost(cost, ranks)
+            blocks = numpy.array([cycles[b[r]:b[r + 1]].sum() for r in range(ranks)])
+            imb = blocks.max() / blocks.mean()
+            if label == "model":
+                worst_model = max(worst_model, imb)
+            else:
+                worst_cells = max(worst_cells, imb)
+    assert worst_model <= limit, (worst_model, worst_cells)
+    assert worst_cells >= 1.15, worst_cells   # what balancing cells alone leaves on the table

@@ -116,7 +116,7 @@ def load():
     lib.tls_grid_cells.restype = ci
     lib.tls_grid_cells.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, _c_int64_p]
     lib.tls_period_costs.restype = ci
-    lib.tls_period_costs.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, dbl, _c_int64_p, _c_double_p]
+    lib.tls_period_costs.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, dbl, _c_int64_p, _c_double_p, _c_double_p]
     lib.tls_comm_unique_id.restype = ci
     lib.tls_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.tls_comm_init.restype = ci
@@ -435,18 +435,19 @@ def grid_cells(t, periods, table, params):
 
 
 def period_costs(t, periods, table, params, sigma):
-    """(trial cells, expected template taps) of every period: the features of the shard cost model
-    (host-only planning call, needs no GPU)."""
+    """(trial cells, expected template taps, modelled search time) of every period: what the shard
+    boundaries are placed by (host-only planning call, needs no GPU)."""
     lib = load()
     t, periods = _f8(t), _f8(periods)
     arrays, tm, pr = Context._pack(table, params)
     cells = numpy.zeros(len(periods), dtype=numpy.int64)
     taps = numpy.zeros(len(periods), dtype=numpy.float64)
+    time = numpy.zeros(len(periods), dtype=numpy.float64)
     rc = lib.tls_period_costs(_dp(t), len(t), _dp(periods), len(periods), ctypes.byref(tm), ctypes.byref(pr),
-                              float(sigma), _ip(cells), _dp(taps))
+                              float(sigma), _ip(cells), _dp(taps), _dp(time))
     if rc != 0:
         raise RuntimeError("tls_amd error %d: %s" % (rc, lib.tls_last_error(None).decode()))
-    return cells, taps
+    return cells, taps, time
 
 
 def device_count():

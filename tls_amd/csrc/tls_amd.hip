@@ -1496,7 +1496,8 @@ int tls_grid_cells(const double* t, int64_t n, const double* periods, int64_t n_
 }
 
 int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t n_periods, const tls_template* tmpl,
-                     const tls_params* params, double sigma, int64_t* cells_per_period, double* taps_per_period) {
+                     const tls_params* params, double sigma, int64_t* cells_per_period, double* taps_per_period,
+                     double* time_per_period) {
     if (!t || !periods || !cells_per_period || !taps_per_period || n < 3 || n_periods < 0) {
         g_create_error = "tls_period_costs: invalid argument";
         return TLS_E_ARG;
@@ -1527,6 +1528,27 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
     }
     for (int64_t p = 0; p < n_periods; ++p)
         taps_per_period[p] = prefix[(size_t)prow[(size_t)p].k_hi] - prefix[(size_t)prow[(size_t)p].k_lo];
+    if (time_per_period) {
+        // Which kernel variant a search of this light curve runs (as tls_prepare decides it, uniform weights assumed),
+        // and that variant's measured cost per period in shader cycles: a0 + aN * n + b * cells + c * taps, fitted to
+        // tls_debug_period_cycles on an MI355X (tools/gpu_cost_model.py, profiles/r03_cost_model_fit.json).  Only the
+        // ratios matter to the callers (tls_amd/shard.py places block boundaries by the cumulative sum).
+        int widest_stride = 1;
+        for (const auto& we : widths) if (we.tiled) widest_stride = std::max(widest_stride, we.xth);
+        const size_t region_doubles = (size_t)(M + 1 + tlsdev::region_pad_for(widest_stride));
+        const size_t hdr = ((size_t)tlsdev::kFixedHeader + 4 * (3 * widths.size() + 2) + 15) / 16 * 16;
+        const size_t resident_bytes = hdr + 2 * 8 * region_doubles;
+        const bool resident = resident_bytes <= kLdsPerCU && n <= 65535;
+        const bool two_per_cu = resident && kLdsPerCU / resident_bytes >= 2;
+        const bool prune = pruning_pays(widths, sigma, params->transit_depth_min, resident);
+        double a0, aN, b, c;
+        if (!resident) { a0 = 458384.0; aN = 4.5716; b = 0.4604; c = 0.03275; }        // HBM slab variant (TESS 27 d + Kepler 4 yr)
+        else if (prune) { a0 = 116100.0; aN = 0.0; b = 1.906; c = 0.0125; }             // LDS-resident, pruning kernel (90 d at 500 ppm)
+        else if (two_per_cu) { a0 = 54603.0; aN = 0.0; b = 0.7823; c = 0.1888; }        // LDS-resident, two 512-thread workgroups per CU (90 d)
+        else { a0 = 56564.0; aN = 0.0; b = 0.3189; c = 0.1267; }                        // LDS-resident, one 1024-thread workgroup per CU (100 d)
+        for (int64_t p = 0; p < n_periods; ++p)
+            time_per_period[p] = a0 + aN * (double)n + b * (double)cells_per_period[p] + c * taps_per_period[p];
+    }
     return TLS_OK;
 }
 

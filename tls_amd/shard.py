@@ -35,24 +35,6 @@ def partition_by_cost(costs, n_ranks):
     return numpy.asarray(bounds, dtype=numpy.int64)
 
 
-# Time model of one period for the placement of the block boundaries: a * N + b * cells + c * taps (N points: fold,
-# sort and prefix sum are O(N) per period whatever its duration window; cells: the depth predicate; taps: the
-# sliding chi^2 of the cells that pass it).  Coefficients in shader cycles, fitted to tls_debug_period_cycles on an
-# MI355X by tools/gpu_cost_model.py (profiles/r03_cost_model_fit.json); only their ratios matter here.  Balancing
-# cells alone leaves the blocks of short periods -- many cheap periods, each with the full fixed cost -- 1.4-1.6x
-# slower than the blocks of long ones at 8 ranks.
-COST_MODEL = {
-    # variant: (a per point, b per trial cell, c per expected template tap)
-    "resident": (20.0, 0.6, 0.08),
-    "slab": (30.0, 0.5, 0.05),
-}
-
-
-def period_time_model(n_points, cells, taps, resident):
-    a, b, c = COST_MODEL["resident" if resident else "slab"]
-    return a * float(n_points) + b * numpy.asarray(cells, dtype=numpy.float64) + c * numpy.asarray(taps, dtype=numpy.float64)
-
-
 def assemble(gathered, bounds, count_per_rank):
     """Undo the padding of an all-gather: `gathered` has n_ranks blocks of
     count_per_rank entries; block r carries bounds[r+1]-bounds[r] valid ones."""
@@ -85,11 +67,19 @@ class ShardedSearch(object):
         self.rank, self.n_ranks = int(rank), int(n_ranks)
         self.bounds = None
         self.count_per_rank = 0
-        self.costs = None
+        self.costs = None    # trial cells per period
+        self.taps = None     # expected template taps per period
+        self.times = None    # modelled search time per period: what the boundaries balance
 
-    def plan(self, t, periods, table, params):
-        self.costs = _lib.grid_cells(t, periods, table, params)
-        self.bounds = partition_by_cost(self.costs, self.n_ranks)
+    def plan(self, t, periods, table, params, y=None):
+        """Block boundaries by cumulative MODELLED TIME (tls_period_costs): per period a fixed part (fold, sort,
+        prefix sum), a part per trial cell and a part per expected template tap.  Balancing trial cells alone
+        leaves the blocks of short periods -- many cheap periods, each with the full fixed cost -- 1.2x (90 d),
+        2.1x (TESS) and 4x (Kepler 4 yr) slower than the mean at 8 ranks (profiles/r03_cost_model_fit.json).
+        y (the flux) only sets the noise level the tap estimate assumes; every rank must pass the same."""
+        sigma = 0.0 if y is None else float(numpy.std(numpy.asarray(y, dtype=numpy.float64)))
+        self.costs, self.taps, self.times = _lib.period_costs(t, periods, table, params, sigma)
+        self.bounds = partition_by_cost(self.times, self.n_ranks)
         self.count_per_rank = max(1, int(numpy.max(numpy.diff(self.bounds))))
         lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         return int(lo), int(hi)

@@ -21,14 +21,15 @@ cases = sys.argv[1:] or ["k2_90d", "tess_27d", "kepler_4yr/16"]
 out = {}
 for case in cases:
     name, _, stride = case.partition("/")
-    t, f, kw = synthetic.config(name)
+    name, _, ppm = name.partition("@")
+    t, f, kw = synthetic.config(name, sigma=float(ppm) * 1e-6 if ppm else None)
     inp = synthetic.search_inputs(t, f, **kw)
     periods = inp["periods"][::int(stride)] if stride else inp["periods"]
     ctx.prepare(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
     ctx.execute()
     ctx.synchronize()
     cyc = numpy.median([ctx.period_cycles().astype(float) for _ in range(3)], axis=0)
-    cells, taps = _lib.period_costs(inp["t"], periods, inp["table"], inp["params"], float(numpy.std(inp["y"])))
+    cells, taps, model_time = _lib.period_costs(inp["t"], periods, inp["table"], inp["params"], float(numpy.std(inp["y"])))
     n = len(inp["t"])
     A = numpy.stack([numpy.full(len(periods), float(n)), cells.astype(float), taps], axis=1)
     coef, *_ = numpy.linalg.lstsq(A, cyc, rcond=None)
@@ -40,11 +41,14 @@ for case in cases:
            "taps_share": float((coef[2] * taps).sum() / cyc.sum()),
            "rel_residual_rms": float(numpy.sqrt(numpy.mean(resid ** 2))), "rel_residual_max": float(numpy.abs(resid).max())}
     for G in (2, 4, 8):
-        for label, cost in (("cells", cells.astype(float)), ("model", shard.period_time_model(n, cells, taps, rec["resident"]))):
+        for label, cost in (("cells", cells.astype(float)), ("model", model_time)):
             b = shard.partition_by_cost(cost, G)
             blocks = numpy.array([cyc[b[r]:b[r + 1]].sum() for r in range(G)])
             rec["imbalance_G%d_%s" % (G, label)] = float(blocks.max() / blocks.mean())
     out[case] = rec
     print(case, json.dumps(rec), flush=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    numpy.savez_compressed("gpurun_out/cost_model_data_%s.npz" % case.replace("/", "_"), cycles=cyc, cells=cells, taps=taps,
+                           periods=periods, n=n, resident=rec["resident"], sigma=float(numpy.std(inp["y"])))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/cost_model_fit.json", "w"), indent=1)
