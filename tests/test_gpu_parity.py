@@ -763,3 +763,36 @@ def test_fast_prefix_mode_decides_the_reference_cells(gpu, oracle_lib, monkeypat
     gpu.execute(phase_clock=True)
     retries = gpu.phase_cycles()["stat_exact_retries"]
     assert 0 <= retries <= max(8, len(sel) // 20), retries
+
+
+@pytest.mark.parametrize("n,cadences_per_day,commensurate", [
+    (4320, 48, [30 / 48.0, 1.0, 2.5, 2.0, 10.0, 45.0]),            # LDS-resident: the six periods of the parity test above
+    (70128, 48, [78 / 48.0, 66.5 / 48.0, 1.0, 80 / 48.0, 131 / 48.0]),   # Kepler size: the slab sort's fallback
+])
+def test_commensurate_periods_cost_no_more_than_their_neighbours(gpu, oracle_lib, n, cadences_per_day, commensurate):
+    """A trial period that is a multiple of the cadence folds a regularly sampled series onto a few dozen phase values;
+    the bucket sort's in-bucket ranking by counting was quadratic in the pile (one such period of the Kepler-size grid:
+    29 ms in one workgroup, 85x its neighbours).  Piled-up buckets now go through the workgroup's bitonic sort
+    (sort_big_bucket): every commensurate period of the LDS-resident configuration within 3x the median period of the
+    same search, a Kepler-size one below 5 ms and within 10x; results unchanged (oracle)."""
+    t = 3.0 + numpy.arange(n) / float(cadences_per_day)       # exact binary cadence
+    y = 1 + numpy.random.RandomState(5).normal(0, 5e-5, n)
+    kw = dict(period_min=0.5, period_max=400) if n > 10000 else {}
+    inp = synthetic.search_inputs(t, y, **kw)
+    ordinary = inp["periods"][:: max(1, len(inp["periods"]) // 300)]
+    periods = numpy.sort(numpy.concatenate([ordinary, commensurate]))
+    got = gpu.search(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
+    cycles = gpu.period_cycles().astype(float)
+    special = numpy.isin(periods, commensurate)
+    median = numpy.median(cycles[~special])
+    worst = cycles[special].max()
+    if n > 10000:
+        # series in HBM: such a period leaves the two-level sort for the general bucket sort through global memory
+        # (~6x an ordinary period whatever the pile-up); the pile-up itself must not add to that
+        assert worst < 5e-3 * 2.4e9            # shader cycles at <= 2.4 GHz: below 5 ms (it was 29 ms)
+        assert worst <= 10.0 * median, (worst, median, periods[special][numpy.argmax(cycles[special])])
+    else:
+        assert worst <= 3.0 * median, (worst, median, periods[special][numpy.argmax(cycles[special])])
+    sel = numpy.nonzero(special)[0]
+    want = oracle_search(oracle_lib, inp, periods=periods[sel])
+    assert_parity(tuple(a[sel] for a in got[:3]), want, n)

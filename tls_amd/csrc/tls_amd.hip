@@ -820,7 +820,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // tiles of `tile_len` window-start positions plus a halo of the widest window
         // sort histogram: one bucket per point while the counters fit the LDS (fewer points per
         // bucket = fewer comparisons in the in-bucket ranking)
-        ctx->nb = (int)std::min<int64_t>(n, (int64_t)((kLdsPerCU - hdr) / 4));
+        // (capped: the LDS behind the counters stages piled-up buckets for the workgroup sort, fold_and_sort)
+        ctx->nb = (int)std::min<int64_t>(std::min<int64_t>(n, 16384), (int64_t)((kLdsPerCU - hdr) / 4));
         size_t halo = (size_t)W + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
         const size_t unit = (size_t)tlsdev::kR * tlsdev::kWave;  // tile bounds: multiples of 320
         {
@@ -1121,6 +1122,7 @@ int tls_spectra(tls_ctx* ctx, const double* chi2, int64_t n, int64_t kernel, dou
     tlsdev::SpectraArgs a;
     a.chi2 = d_in; a.SR = ctx->d_spec.ptr; a.power_raw = ctx->d_spec.ptr + nn; a.power = ctx->d_spec.ptr + 2 * nn;
     a.sde = ctx->d_spec.ptr + 3 * nn; a.n = (int)n; a.kernel = (int)kernel; a.detrend = n > 2 * kernel ? 1 : 0;
+    a.chi2_stride = 0; a.out_stride = 0; a.sde_stride = 0;
     hipLaunchKernelGGL(tlsdev::tls_spectra_head, dim3(1), dim3(1024), 0, ctx->stream, a);
     if (a.detrend) {
         const int n_med = (int)(n - kernel + 1), threads = 256, per = tlsdev::kMedianWindows;

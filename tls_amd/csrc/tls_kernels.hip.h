@@ -1713,13 +1713,74 @@ __device__ __forceinline__ void dot_windows_weighted_rt(const double* ew, const 
 // scatter (arbitrary order inside a bucket), then an exact rank by (phase, index) inside each
 // bucket -- O(n) for the near-uniform phases of a folded time series, correct for any input.
 // ph_orig: n doubles, cnt: nb words, idx_tmp/perm: n entries each; all workgroup-visible.
+// A bucket that many phases fell into -- a trial period commensurate with the cadence folds a regularly sampled series
+// onto a few dozen phase values, each holding N / (P / cadence) points -- is not ranked by counting (b^2 comparisons:
+// 29 ms for ONE such period of the Kepler-size grid) but sorted by the whole workgroup: a bitonic network on
+// (phase, index) in its normalised form (every compare-exchange puts the smaller key at the lower position, so the
+// power-of-two padding is implicit: a partner beyond the bucket's end is +infinity and the exchange is skipped).
+// b log^2 b / 4 exchanges, a workgroup barrier per step.  Keys either staged in LDS (key_l / idx_l: series in HBM) or
+// read through the index (LDS-resident series: everything is in LDS already).  `out[r]` = r-th index of the bucket.
+constexpr int kBigBucket = 48;   // buckets beyond this size leave the counting rank
+#ifndef TLS_WAVE_SORT_MAX
+#define TLS_WAVE_SORT_MAX 2048
+#endif
+constexpr int kWaveSortMax = TLS_WAVE_SORT_MAX;  // piled-up buckets up to this size are sorted by ONE wave (the waves take buckets in turn)
+// WAVE: the calling wave sorts the bucket alone (lanes over the exchanges, wave-level LDS ordering between the steps);
+// otherwise all threads of the workgroup call this (workgroup barriers).
+template <typename IdxT, bool STAGED, bool WAVE>
+__device__ __forceinline__ void sort_big_bucket(const double* ph_orig, IdxT* idx_seg, int m, double* key_l, unsigned int* idx_l,
+                                                IdxT* out) {
+    const int tid = WAVE ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
+    const int nt = WAVE ? kWave : (int)blockDim.x;
+    auto step_sync = [&]() { if constexpr (WAVE) wave_sync(); else __syncthreads(); };
+    if constexpr (STAGED) {
+        for (int j = tid; j < m; j += nt) { const unsigned int i = (unsigned int)idx_seg[j]; idx_l[j] = i; key_l[j] = ph_orig[i]; }
+    }
+    step_sync();
+    int lg = 0;
+    while ((1 << lg) < m) ++lg;
+    const int half_pairs = (1 << lg) >> 1;
+    auto exchange = [&](int x, int y) {   // x < y
+        if (y >= m) return;
+        if constexpr (STAGED) {
+            const double kx = key_l[x], ky = key_l[y];
+            const unsigned int ix = idx_l[x], iy = idx_l[y];
+            if (kx > ky || (kx == ky && ix > iy)) { key_l[x] = ky; key_l[y] = kx; idx_l[x] = iy; idx_l[y] = ix; }
+        } else {
+            const IdxT ix = idx_seg[x], iy = idx_seg[y];
+            const double kx = ph_orig[(int)ix], ky = ph_orig[(int)iy];
+            if (kx > ky || (kx == ky && ix > iy)) { idx_seg[x] = iy; idx_seg[y] = ix; }
+        }
+    };
+    for (int lk = 1; lk <= lg; ++lk) {           // merge blocks of k = 2^lk
+        const int lh = lk - 1;                   // half = 2^lh
+        for (int i = tid; i < half_pairs; i += nt) {
+            const int blk = i >> lh, pos = i & ((1 << lh) - 1);
+            exchange((blk << lk) + pos, (blk << lk) + ((1 << lk) - 1 - pos));
+        }
+        step_sync();
+        for (int lj = lk - 2; lj >= 0; --lj) {   // j = 2^lj
+            for (int i = tid; i < half_pairs; i += nt) {
+                const int x = ((i >> lj) << (lj + 1)) + (i & ((1 << lj) - 1));
+                exchange(x, x + (1 << lj));
+            }
+            step_sync();
+        }
+    }
+    for (int j = tid; j < m; j += nt) out[j] = STAGED ? (IdxT)idx_l[j] : idx_seg[j];
+    step_sync();
+}
+
 template <typename IdxT>
 __device__ __forceinline__ void fold_and_sort(const double* t, int n, double period, double epoch,
                                               double* ph_orig, unsigned int* cnt, int nb, IdxT* idx_tmp,
-                                              IdxT* perm, unsigned int* wsum, PhaseClock& pc) {
+                                              IdxT* perm, unsigned int* wsum, PhaseClock& pc,
+                                              unsigned int* big_list = nullptr, int big_cap = 0,
+                                              double* stage_key = nullptr, unsigned int* stage_idx = nullptr, int stage_cap = 0) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const double nb_d = (double)nb;
     for (int b = tid; b < nb; b += nt) cnt[b] = 0;
+    if (tid == 0 && big_cap > 0) big_list[0] = 0u;   // [0]: number of big buckets, [1..]: their first slots
     __syncthreads();
     for (int i = tid; i < n; i += nt) {
         double ph = fold_phase(t[i], period, epoch);
@@ -1744,6 +1805,17 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
         const double ph = ph_orig[i];
         const int b = bucket_of(ph, nb_d, nb);
         const int lo = b ? (int)cnt[b - 1] : 0, hi = (int)cnt[b];
+        if (hi - lo > kBigBucket && big_cap > 0) {
+            // piled-up phases: the bucket's first slot registers it for the workgroup sort below; if the list is
+            // full (more than big_cap such buckets) the counting rank does it after all
+            bool listed = true;
+            if (s == lo) {
+                const unsigned int at = atomicAdd(&big_list[0], 1u);
+                if (at < (unsigned int)(big_cap - 1)) big_list[1 + at] = (unsigned int)lo;
+            }
+            (void)listed;
+            continue;
+        }
         int rank = 0;
         for (int s2 = lo; s2 < hi; ++s2) {
             const int i2 = (int)idx_tmp[s2];
@@ -1753,6 +1825,110 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
         perm[lo + rank] = (IdxT)i;
     }
     __syncthreads();
+    if (big_cap > 0) {
+        const int n_big_all = (int)big_list[0];
+        const int n_big = n_big_all < big_cap - 1 ? n_big_all : big_cap - 1;
+        auto bucket_size = [&](int lo) { return (int)cnt[bucket_of(ph_orig[(int)idx_tmp[lo]], nb_d, nb)] - lo; };
+        if (stage_cap == 0) {
+            // everything is in LDS already (resident series): buckets of moderate size go one to a wave, the waves side
+            // by side, sorted in place through the index; larger ones afterwards by the whole workgroup
+            const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave)), n_waves = nt / kWave;
+            for (int q = wave_id; q < n_big; q += n_waves) {
+                const int lo = __builtin_amdgcn_readfirstlane((int)big_list[1 + q]);
+                const int m = __builtin_amdgcn_readfirstlane(bucket_size(lo));
+                if (m <= kWaveSortMax) sort_big_bucket<IdxT, false, true>(ph_orig, idx_tmp + lo, m, nullptr, nullptr, perm + lo);
+            }
+            __syncthreads();
+            for (int q = 0; q < n_big; ++q) {
+                const int lo = (int)big_list[1 + q];
+                const int m = bucket_size(lo);
+                if (m > kWaveSortMax) sort_big_bucket<IdxT, false, false>(ph_orig, idx_tmp + lo, m, nullptr, nullptr, perm + lo);
+            }
+        } else {
+            // series in HBM: as many buckets as fit the LDS staging area are sorted TOGETHER by the workgroup (one
+            // barrier per step of the network for the whole batch instead of one per bucket and step)
+            int q0 = 0;
+            while (q0 < n_big) {
+                int count = 0, used = 0, lg_max = 0;
+                // (uniform: every thread walks the same list)
+                int lo_b[16], m_b[16], off_b[16];
+                while (q0 + count < n_big && count < 16) {
+                    const int lo = (int)big_list[1 + q0 + count];
+                    const int m = bucket_size(lo);
+                    if (m > stage_cap) break;                     // does not fit at all: alone, below
+                    if (used + m > stage_cap) break;
+                    lo_b[count] = lo; m_b[count] = m; off_b[count] = used; used += m;
+                    int lg = 0; while ((1 << lg) < m) ++lg;
+                    lg_max = lg > lg_max ? lg : lg_max;
+                    ++count;
+                }
+                if (count == 0) {   // a bucket larger than the staging area: in place, through global memory
+                    const int lo = (int)big_list[1 + q0];
+                    sort_big_bucket<IdxT, false, false>(ph_orig, idx_tmp + lo, bucket_size(lo), nullptr, nullptr, perm + lo);
+                    ++q0;
+                    continue;
+                }
+                for (int g = 0; g < count; ++g)
+                    for (int j = tid; j < m_b[g]; j += nt) {
+                        const unsigned int i = (unsigned int)idx_tmp[lo_b[g] + j];
+                        stage_idx[off_b[g] + j] = i; stage_key[off_b[g] + j] = ph_orig[i];
+                    }
+                __syncthreads();
+                const int half_pairs = (1 << lg_max) >> 1;
+                auto exchange = [&](int g, int x, int y) {
+                    if (y >= m_b[g]) return;
+                    double* key_l = stage_key + off_b[g];
+                    unsigned int* idx_l = stage_idx + off_b[g];
+                    const double kx = key_l[x], ky = key_l[y];
+                    const unsigned int ix = idx_l[x], iy = idx_l[y];
+                    if (kx > ky || (kx == ky && ix > iy)) { key_l[x] = ky; key_l[y] = kx; idx_l[x] = iy; idx_l[y] = ix; }
+                };
+                for (int lk = 1; lk <= lg_max; ++lk) {
+                    const int lh = lk - 1;
+                    for (int i = tid; i < count * half_pairs; i += nt) {
+                        const int g = i >> (lg_max - 1), ii = i & (half_pairs - 1);
+                        const int blk = ii >> lh, pos = ii & ((1 << lh) - 1);
+                        exchange(g, (blk << lk) + pos, (blk << lk) + ((1 << lk) - 1 - pos));
+                    }
+                    __syncthreads();
+                    for (int lj = lk - 2; lj >= 0; --lj) {
+                        for (int i = tid; i < count * half_pairs; i += nt) {
+                            const int g = i >> (lg_max - 1), ii = i & (half_pairs - 1);
+                            const int x = ((ii >> lj) << (lj + 1)) + (ii & ((1 << lj) - 1));
+                            exchange(g, x, x + (1 << lj));
+                        }
+                        __syncthreads();
+                    }
+                }
+                for (int g = 0; g < count; ++g)
+                    for (int j = tid; j < m_b[g]; j += nt) perm[lo_b[g] + j] = (IdxT)stage_idx[off_b[g] + j];
+                __syncthreads();
+                q0 += count;
+            }
+        }
+        if (n_big_all > n_big) {
+            // more piled-up buckets than list slots: those beyond the list are ranked by counting after all
+            // (a listed bucket's segment of perm is complete and is not touched: its first slot is in the list)
+            for (int s = tid; s < n; s += nt) {
+                const int i = (int)idx_tmp[s];
+                const double ph = ph_orig[i];
+                const int b = bucket_of(ph, nb_d, nb);
+                const int lo = b ? (int)cnt[b - 1] : 0, hi = (int)cnt[b];
+                if (hi - lo <= kBigBucket) continue;
+                bool in_list = false;
+                for (int q = 0; q < n_big; ++q) in_list |= (int)big_list[1 + q] == lo;
+                if (in_list) continue;
+                int rank = 0;
+                for (int s2 = lo; s2 < hi; ++s2) {
+                    const int i2 = (int)idx_tmp[s2];
+                    const double ph2 = ph_orig[i2];
+                    rank += (ph2 < ph || (ph2 == ph && i2 < i)) ? 1 : 0;
+                }
+                perm[lo + rank] = (IdxT)i;
+            }
+            __syncthreads();
+        }
+    }
     pc.mark(3);
 }
 
@@ -2664,7 +2840,22 @@ tls_search_kernel(const SearchArgs a) {
                 pc.start(a.phase_cycles);   // (the call kept its own clock)
             }
         }
-        if (!sorted && !fused) fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc);
+        if (!sorted && !fused) {
+            // (piled-up buckets are sorted by the workgroup: their list lives in the idle prefix-sum scratch; the slab
+            // variant stages them in the LDS behind its bucket counters, the resident one sorts through the index)
+            unsigned int* big_list = reinterpret_cast<unsigned int*>(cumsum_scratch);
+            constexpr int kBigCap = kCumsumScratchBytes / 4;
+            if constexpr (RESIDENT) {
+                fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc, big_list, kBigCap);
+            } else {
+                double* stage_key = reinterpret_cast<double*>(cnt + ((nb + 1) & ~1));
+                const long long room = a.lds_bytes - a.hdr_bytes - 4LL * ((nb + 1) & ~1);
+                const int stage_cap = room > 0 ? (int)(room / 12) : 0;
+                unsigned int* stage_idx = reinterpret_cast<unsigned int*>(stage_key + stage_cap);
+                fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc, big_list, kBigCap,
+                                    stage_key, stage_idx, stage_cap);
+            }
+        }
         // survey mode: the permutation depends on (t, period) only, so every light curve of the
         // batch reuses it; it must outlive the prefix sum that overwrites its LDS home
         const IdxT* perm_use = perm;
@@ -3680,7 +3871,9 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a) {
         const int work = s_work[0];
         __syncthreads();
         if (work >= a.n_epochs) break;
-        fold_and_sort<IdxT>(a.t, n, a.period, a.epochs[work], regA, cnt, a.nb, idx_tmp, perm, wsum, pc);
+        // (a trial epoch does not change how the phases pile up: the period does -- same remedy as in the search)
+        fold_and_sort<IdxT>(a.t, n, a.period, a.epochs[work], regA, cnt, a.nb, idx_tmp, perm, wsum, pc,
+                            reinterpret_cast<unsigned int*>(wred), 2 * kMaxWaves);
         for (int k = tid; k < n; k += nt) regA[k] = a.y[(int)perm[k]];   // phases are dead
         __syncthreads();
         // flux rolled once: F1[k] = F[(k - roll) mod n]; weights: F2[k] = F[(k - 2 roll) mod n]
@@ -3721,7 +3914,18 @@ struct SpectraArgs {
     double* power;
     double* sde;        // [0] SDE_raw, [1] SDE
     int n, kernel, detrend;   // detrend: n > 2 * kernel (stats.py:118)
+    // survey batches (tls_power_batch): light curve c = blockIdx.y reads chi2 + c * chi2_stride and writes
+    // SR / power_raw / power + c * out_stride, sde + c * sde_stride (all 0 for one light curve)
+    long long chi2_stride, out_stride, sde_stride;
 };
+__device__ __forceinline__ SpectraArgs spectra_of_curve(const SpectraArgs& a) {
+    SpectraArgs b = a;
+    const long long c = blockIdx.y;
+    b.chi2 = a.chi2 + c * a.chi2_stride;
+    b.SR = a.SR + c * a.out_stride; b.power_raw = a.power_raw + c * a.out_stride; b.power = a.power + c * a.out_stride;
+    b.sde = a.sde + c * a.sde_stride;
+    return b;
+}
 
 template <typename Op>
 __device__ __forceinline__ double block_reduce(double v, Op op, double* red /* LDS [kMaxWaves + 1] */) {
@@ -3740,7 +3944,8 @@ __device__ __forceinline__ double block_reduce(double v, Op op, double* red /* L
     return red[kMaxWaves];
 }
 
-__global__ void __launch_bounds__(1024) tls_spectra_head(const SpectraArgs a) {
+__global__ void __launch_bounds__(1024) tls_spectra_head(const SpectraArgs a0) {
+    const SpectraArgs a = spectra_of_curve(a0);
     __shared__ double red[kMaxWaves + 1];
     const int tid = threadIdx.x, nt = blockDim.x, n = a.n;
     auto add = [](double x, double y) { return x + y; };
@@ -3771,7 +3976,8 @@ __global__ void __launch_bounds__(1024) tls_spectra_head(const SpectraArgs a) {
 // the median of its (odd) window iff exactly kernel/2 elements precede it in (value, position) order.  (One
 // window per thread walked up to kernel^2 elements serially: 0.28 ms for 9679 periods, on 38 CUs.)
 constexpr int kMedianWindows = 16;
-__global__ void __launch_bounds__(256) tls_spectra_median(const SpectraArgs a) {
+__global__ void __launch_bounds__(256) tls_spectra_median(const SpectraArgs a0) {
+    const SpectraArgs a = spectra_of_curve(a0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, n = a.n, k = a.kernel;
     const int n_med = n - k + 1, first = blockIdx.x * kMedianWindows;
@@ -3780,6 +3986,9 @@ __global__ void __launch_bounds__(256) tls_spectra_median(const SpectraArgs a) {
     double* w = reinterpret_cast<double*>(smem);            // [kMedianWindows + kernel - 1]
     double* med = w + (kMedianWindows + k - 1);               // [kMedianWindows]
     for (int j = tid; j < staged; j += nt) w[j] = a.power_raw[first + j];
+    // a window that holds a NaN has no candidate of the right rank (every comparison is false): its median is NaN,
+    // as numpy.median's (helpers.py:96)
+    for (int i = tid; i < kMedianWindows; i += nt) med[i] = __longlong_as_double(0x7ff8000000000000LL);
     __syncthreads();
     for (int pair = tid; pair < windows * k; pair += nt) {
         const int i = pair / k, j = pair - i * k;
@@ -3797,7 +4006,8 @@ __global__ void __launch_bounds__(256) tls_spectra_median(const SpectraArgs a) {
     if (first + windows == n_med) for (int j = front + n_med + tid; j < n; j += nt) a.power[j] = a.power_raw[j] - med[windows - 1];
 }
 
-__global__ void __launch_bounds__(1024) tls_spectra_tail(const SpectraArgs a) {
+__global__ void __launch_bounds__(1024) tls_spectra_tail(const SpectraArgs a0) {
+    const SpectraArgs a = spectra_of_curve(a0);
     __shared__ double red[kMaxWaves + 1];
     const int tid = threadIdx.x, nt = blockDim.x, n = a.n;
     auto add = [](double x, double y) { return x + y; };
@@ -3820,6 +4030,103 @@ __global__ void __launch_bounds__(1024) tls_spectra_tail(const SpectraArgs a) {
     const double scale = sde / pmax;                                                           // :126
     for (int k = tid; k < n; k += nt) a.power[k] = a.power[k] * scale;
     if (tid == 0) a.sde[1] = sde;
+}
+
+// Survey-mode power(): what main.py:198-212,269-272 read off the spectra of one light curve -- one workgroup per
+// light curve (blockIdx.x).  out[c][0..7] = chi2_min, index of the FIRST minimum of chi2 (numpy.argmin), index of the
+// FIRST maximum of the detrended power (numpy.argmax), period and depth at the power peak, template row at the chi2
+// minimum, max(chi2) == min(chi2) ("no transit was fit", main.py:203), reserved.
+struct PickArgs {
+    const double* chi2; const long long* row; const double* depth;   // [n_curves][n] (stride n)
+    const double* power;                                             // [n_curves] stride power_stride
+    const double* periods;                                           // [n]
+    double* out;                                                     // [n_curves][8]
+    long long power_stride;
+    int n;
+};
+__global__ void __launch_bounds__(1024) tls_power_pick(const PickArgs a) {
+    __shared__ double red_v[kMaxWaves];
+    __shared__ int red_i[kMaxWaves];
+    const int tid = threadIdx.x, nt = blockDim.x, n = a.n;
+    const int lane = tid & (kWave - 1), wave = tid / kWave, nw = nt / kWave;
+    const long long c = blockIdx.x;
+    const double* chi2 = a.chi2 + c * n;
+    const double* power = a.power + c * a.power_stride;
+    // first minimum of chi2, first maximum of power, maximum of chi2: (value, index) reductions, lower index wins ties
+    double vmin = INFINITY, vmax = -INFINITY, cmax = -INFINITY;
+    int imin = 0x7fffffff, imax = 0x7fffffff;
+    for (int k = tid; k < n; k += nt) {
+        const double x = chi2[k], pw = power[k];
+        if (x < vmin) { vmin = x; imin = k; }
+        if (pw > vmax) { vmax = pw; imax = k; }
+        cmax = x > cmax ? x : cmax;
+    }
+    auto reduce_first = [&](double v, int i, bool want_min) -> int {
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            const double ov = __shfl_down(v, d, kWave);
+            const int oi = __shfl_down(i, d, kWave);
+            const bool take = want_min ? (ov < v || (ov == v && oi < i)) : (ov > v || (ov == v && oi < i));
+            if (take) { v = ov; i = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { red_v[wave] = v; red_i[wave] = i; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < nw; ++w) {
+                const double ov = red_v[w]; const int oi = red_i[w];
+                const bool take = want_min ? (ov < v || (ov == v && oi < i)) : (ov > v || (ov == v && oi < i));
+                if (take) { v = ov; i = oi; }
+            }
+            red_i[0] = i; red_v[0] = v;
+        }
+        __syncthreads();
+        return red_i[0];
+    };
+    const int best = reduce_first(vmin, imin, true);
+    const double chi2_min = red_v[0];
+    const int peak = reduce_first(vmax, imax, false);
+    (void)reduce_first(cmax, 0, false);
+    const double chi2_max = red_v[0];
+    if (tid == 0) {
+        double* o = a.out + c * 8;
+        const int b = best < n ? best : 0, pk = peak < n ? peak : 0;   // (all-NaN input: index 0, like numpy)
+        o[0] = chi2_min; o[1] = (double)b; o[2] = (double)pk;
+        o[3] = a.periods[pk]; o[4] = a.depth[c * n + pk]; o[5] = (double)a.row[c * n + b];
+        o[6] = chi2_max == chi2_min ? 1.0 : 0.0; o[7] = 0.0;
+    }
+}
+
+// The final T0 fit's choice (stats.py:196-201): the trial epoch of the FIRST strict minimum of the residuals, or 0
+// when none is below +inf.  One workgroup per light curve; fit c has n_epochs[c] residuals at residuals + c * stride.
+struct FirstMinArgs {
+    const double* residuals; const double* epochs;   // [n_curves] stride `stride`
+    const int* n_epochs;                             // [n_curves]
+    double* T0;                                      // [n_curves]
+    long long stride;
+};
+__global__ void __launch_bounds__(1024) tls_first_min(const FirstMinArgs a) {
+    __shared__ double red_v[kMaxWaves];
+    __shared__ int red_i[kMaxWaves];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (kWave - 1), wave = tid / kWave, nw = nt / kWave;
+    const long long c = blockIdx.x;
+    const int n = a.n_epochs[c];
+    const double* r = a.residuals + c * a.stride;
+    double v = INFINITY; int i = 0x7fffffff;
+    for (int k = tid; k < n; k += nt) { const double x = r[k]; if (x < v) { v = x; i = k; } }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        const double ov = __shfl_down(v, d, kWave);
+        const int oi = __shfl_down(i, d, kWave);
+        if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    if (lane == 0) { red_v[wave] = v; red_i[wave] = i; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < nw; ++w) if (red_v[w] < v || (red_v[w] == v && red_i[w] < i)) { v = red_v[w]; i = red_i[w]; }
+        a.T0[c] = (v < INFINITY && i < n) ? a.epochs[c * a.stride + i] : 0.0;
+    }
 }
 
 // Developer/test entry: the exact sequential cumsum on an arbitrary non-negative series
