@@ -174,6 +174,27 @@ int tls_t0_fit(tls_ctx *ctx, const double *t, const double *y, int64_t n, double
 int tls_spectra(tls_ctx *ctx, const double *chi2, int64_t n, int64_t kernel, double *out_SR,
                 double *out_power_raw, double *out_power, double *out_sde);
 
+/* ---- survey-mode power(): search + spectra + final T0 fit of many light curves, all on the device --------- */
+/* What main.py:198-283 derives for ONE light curve from the search results -- SDE and SDE_raw (stats.py:105-132),
+ * the period and depth at the peak of the detrended power, the template row at the chi^2 minimum, the mid-transit
+ * time of the final T0 fit (stats.py:135-204) -- for every light curve of a batch that shares t, the grids and the
+ * template (the contract of tls_search_batch).  80 bytes come back per light curve instead of three arrays of
+ * n_periods entries; the per-period arrays (chi2/row/depth together, and the detrended power) on request.
+ * `median_kernel` = oversampling_factor * SDE_MEDIAN_KERNEL_SIZE (as tls_spectra). */
+typedef struct tls_power_summary {
+    double SDE, SDE_raw, chi2_min, period, T0, depth;
+    int64_t index_best;    /* numpy.argmin(chi2)  (main.py:198) */
+    int64_t index_power;   /* numpy.argmax(power) (main.py:270) */
+    int64_t best_row;      /* template row at index_best: lc_cache_overview["duration"][best_row] is the duration */
+    int64_t no_fit;        /* 1: max(chi2) == min(chi2), "no transit was fit" (main.py:203): SDE 0, depth 1, period NaN */
+} tls_power_summary;
+int tls_power_batch(tls_ctx *ctx, const double *t, const double *y, const double *dy, int64_t n,
+                    int64_t n_curves, const double *periods, int64_t n_periods,
+                    const tls_template *tmpl, const tls_params *params, int64_t median_kernel,
+                    tls_power_summary *out_summary,
+                    double *out_chi2 /* [n_curves][n_periods] or NULL */, int64_t *out_row /* with out_chi2 */,
+                    double *out_depth /* with out_chi2 */, double *out_power /* [n_curves][n_periods] or NULL */);
+
 /* ---- host-only planning (no GPU needed) ------------------------------------------ */
 /* Trial cells (duration x T0 positions) each period will enumerate: the data-independent
  * cost used to place shard boundaries and to report cells/s.  Mirrors core.py:50-57,143-156. */

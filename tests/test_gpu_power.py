@@ -2,12 +2,14 @@
 against golden results of the unmodified reference and the reference's own
 known-answer tests (same checks as test_power_host.py, real HIP search)."""
 import os
+import warnings
 
 import numpy
 import pytest
 
 import tls_amd
 import pins
+from tls_amd import synthetic, transit_model
 
 pytestmark = pytest.mark.gpu
 
@@ -117,3 +119,62 @@ def test_power_gpu_equals_power_with_oracle_search(monkeypatch, oracle_lib, seed
         numpy.testing.assert_allclose(numpy.asarray(got[key], dtype=float), numpy.asarray(want[key], dtype=float),
                                       rtol=1e-9, atol=atol, err_msg=key)
     assert int(numpy.argmin(got.chi2)) == int(numpy.argmin(want.chi2))
+
+
+@pytest.mark.parametrize("weights", [False, True])
+def test_power_batch_equals_power_per_curve_and_the_oracle(oracle_lib, weights):
+    """Survey-mode power() (tls_power_batch: search + spectra + final T0 fit on the device, 80 bytes back per light
+    curve) against (i) the drop-in power() of every light curve on its own -- which is pinned to the reference -- for
+    12 seeds from three different 32-curve launch groups, (ii) the oracle: its search, its spectra and its T0-fit
+    residuals fed the same way (main.py:198-283, stats.py:105-204)."""
+    import tls_amd
+    from tls_amd import survey, _lib
+    ctx = _lib.Context(0)
+    n_curves = 70
+    t = numpy.linspace(3.0, 33.0, 720)
+    rng = numpy.random.RandomState(11)
+    fluxes, dys = [], []
+    for s in range(n_curves):
+        per = float(rng.uniform(2.0, 7.0))
+        f = transit_model.light_curve(t, 3.2 + rng.uniform(0, 1), per, float(rng.uniform(0.03, 0.08)), 12, 89.8, 0, 90,
+                                      [0.4, 0.3], "quadratic") + rng.normal(0, 4e-4, len(t))
+        if s == 5:
+            f = 1 + rng.normal(0, 1e-9, len(t)) * 0 + 0.0        # flat: nothing passes transit_depth_min
+            f[::7] += 1e-7
+        fluxes.append(f)
+        dys.append(rng.uniform(0.8, 1.3, len(t)) * 4e-4)
+    fluxes = numpy.array(fluxes)
+    dy_batch = numpy.array(dys) if weights else None
+    kw = dict(period_min=1.5, period_max=9.0, oversampling_factor=2, T0_fit_margin=0.02)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        summary, periods, chi2, row, depth, power = survey.power_batch(t, fluxes, dy_batch, context=ctx, with_arrays=True, **kw)
+        assert len(summary) == n_curves
+        for s in (0, 1, 5, 17, 31, 32, 33, 47, 63, 64, 65, 69):
+            one = tls_amd.transitleastsquares(t, fluxes[s], None if dy_batch is None else dy_batch[s], verbose=False).power(
+                context=ctx, verbose=False, show_progress_bar=False, **kw)
+            rec = summary[s]
+            numpy.testing.assert_array_equal(chi2[s], one.chi2)          # same kernel, same launch-group invariance
+            assert rec["chi2_min"] == one.chi2_min
+            if rec["no_fit"]:
+                assert one.SDE == 0 and numpy.isnan(one.period) and one.depth == 1 and one.T0 == 0
+                assert rec["SDE"] == 0 and numpy.isnan(rec["period"]) and rec["depth"] == 1 and rec["T0"] == 0
+                continue
+            assert rec["period"] == one.period and rec["depth"] == one.depth
+            assert rec["T0"] == one.T0, (s, rec["T0"], one.T0)
+            numpy.testing.assert_allclose([rec["SDE"], rec["SDE_raw"]], [one.SDE, one.SDE_raw], rtol=1e-12)
+            numpy.testing.assert_allclose(power[s], one.power, rtol=1e-12, atol=1e-13)
+            assert rec["index_best"] == int(numpy.argmin(one.chi2)) and rec["index_power"] == int(numpy.argmax(one.power))
+            # the oracle, fed the way main.py:198-283 feeds its own pieces
+            inp = synthetic.search_inputs(t, fluxes[s], None if dy_batch is None else dy_batch[s], **kw)
+            p = inp["params"]
+            o_chi2, o_row, o_depth, _ = oracle_lib.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"],
+                                                          p["transit_depth_min"], p["R_star_min"], p["R_star_max"],
+                                                          p["M_star_min"], p["M_star_max"], p["T0_fit_margin"])
+            o_SR, o_praw, o_power, o_sde_raw, o_sde = oracle_lib.spectra(o_chi2, 60)
+            assert int(numpy.argmin(o_chi2)) == rec["index_best"] and int(numpy.argmax(o_power)) == rec["index_power"]
+            assert o_row[rec["index_best"]] == rec["best_row"]
+            numpy.testing.assert_allclose([rec["SDE"], rec["SDE_raw"], rec["chi2_min"]], [o_sde, o_sde_raw, o_chi2.min()], rtol=1e-8)
+            assert abs(rec["depth"] - o_depth[rec["index_power"]]) < 1e-11
+            assert rec["duration"] == inp["overview"]["duration"][rec["best_row"]]
+    ctx.close()

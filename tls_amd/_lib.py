@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("TLS_AMD_LIB") or os.path.join(_HERE, "libtls_amd.so")
 # every symbol include/tls_amd.h declares (tests check the export list against the header)
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
-    "tls_device_name", "tls_search", "tls_search_batch", "tls_prepare", "tls_update_flux", "tls_execute",
+    "tls_device_name", "tls_search", "tls_search_batch", "tls_power_batch", "tls_prepare", "tls_update_flux", "tls_execute",
     "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_period_cycles",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
@@ -36,6 +36,19 @@ class _Params(ctypes.Structure):
     _fields_ = [("transit_depth_min", ctypes.c_double), ("R_star_min", ctypes.c_double),
                 ("R_star_max", ctypes.c_double), ("M_star_min", ctypes.c_double),
                 ("M_star_max", ctypes.c_double), ("T0_fit_margin", ctypes.c_double)]
+
+
+class PowerSummary(ctypes.Structure):
+    """tls_power_summary: what main.py:198-283 derives from the search results of one light curve."""
+    _fields_ = [("SDE", ctypes.c_double), ("SDE_raw", ctypes.c_double), ("chi2_min", ctypes.c_double),
+                ("period", ctypes.c_double), ("T0", ctypes.c_double), ("depth", ctypes.c_double),
+                ("index_best", ctypes.c_int64), ("index_power", ctypes.c_int64), ("best_row", ctypes.c_int64),
+                ("no_fit", ctypes.c_int64)]
+
+
+POWER_SUMMARY_DTYPE = numpy.dtype([("SDE", "f8"), ("SDE_raw", "f8"), ("chi2_min", "f8"), ("period", "f8"), ("T0", "f8"),
+                                   ("depth", "f8"), ("index_best", "i8"), ("index_power", "i8"), ("best_row", "i8"),
+                                   ("no_fit", "i8")])
 
 
 class Counters(ctypes.Structure):
@@ -79,6 +92,9 @@ def load():
     lib.tls_search_batch.restype = ci
     lib.tls_search_batch.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, i64, _c_double_p, i64,
                                      tp, pp, _c_double_p, _c_int64_p, _c_double_p]
+    lib.tls_power_batch.restype = ci
+    lib.tls_power_batch.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, i64, _c_double_p, i64,
+                                    tp, pp, i64, ctypes.c_void_p, _c_double_p, _c_int64_p, _c_double_p, _c_double_p]
     lib.tls_prepare.restype = ci
     lib.tls_prepare.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, _c_double_p, i64,
                                 tp, pp]
@@ -233,6 +249,35 @@ class Context(object):
                                                _dp(chi2), _ip(row), _dp(depth)))
         self._n_periods = n_p
         return chi2, row, depth
+
+    def power_batch(self, t, y_batch, dy_batch, periods, table, params, median_kernel, with_arrays=False,
+                    with_power=False):
+        """Survey-mode power(): structured array (POWER_SUMMARY_DTYPE) with one record per light curve -- SDE,
+        SDE_raw, chi2_min, period, T0, depth, the argmin/argmax indices, the template row -- from search,
+        spectra and final T0 fit on the device (tls_power_batch); optionally the per-period arrays."""
+        t, periods = _f8(t), _f8(periods)
+        y_batch = numpy.ascontiguousarray(y_batch, dtype=numpy.float64)
+        dy_batch = numpy.ascontiguousarray(dy_batch, dtype=numpy.float64)
+        if y_batch.ndim != 2 or y_batch.shape != dy_batch.shape or y_batch.shape[1] != len(t):
+            raise ValueError("y_batch and dy_batch must both have shape [n_curves, len(t)]")
+        arrays, tm, pr = self._pack(table, params)
+        n_c, n_p = y_batch.shape[0], len(periods)
+        summary = numpy.zeros(n_c, dtype=POWER_SUMMARY_DTYPE)
+        assert summary.dtype.itemsize == ctypes.sizeof(PowerSummary)
+        chi2 = row = depth = power = None
+        if with_arrays:
+            chi2 = numpy.empty((n_c, n_p), dtype=numpy.float64)
+            row = numpy.empty((n_c, n_p), dtype=numpy.int64)
+            depth = numpy.empty((n_c, n_p), dtype=numpy.float64)
+        if with_power:
+            power = numpy.empty((n_c, n_p), dtype=numpy.float64)
+        self._check(self._lib.tls_power_batch(
+            self._h, _dp(t), _dp(y_batch), _dp(dy_batch), len(t), n_c, _dp(periods), n_p, ctypes.byref(tm),
+            ctypes.byref(pr), int(median_kernel), summary.ctypes.data_as(ctypes.c_void_p),
+            None if chi2 is None else _dp(chi2), None if row is None else _ip(row),
+            None if depth is None else _dp(depth), None if power is None else _dp(power)))
+        self._n_periods = n_p
+        return summary, chi2, row, depth, power
 
     def prepare(self, t, y, dy, periods, table, params):
         t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)

@@ -666,6 +666,45 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     return TLS_OK;
 }
 
+// T0-fit launch shared by tls_t0_fit and tls_power_batch: every pointer on the device, nothing waited for
+int launch_t0_fit(tls_ctx* ctx, const double* d_t, const double* d_y, const double* d_signal, const double* d_epochs,
+                  double* d_residuals, unsigned int* d_queue, int64_t n, double period, int64_t dur, int64_t n_epochs,
+                  int64_t roll) {
+    tlsdev::T0FitArgs a;
+    a.t = d_t; a.y = d_y; a.signal = d_signal; a.epochs = d_epochs;
+    a.residuals = d_residuals; a.queue = d_queue; a.scratch = nullptr; a.scratch_stride = 0;
+    a.period = period; a.n = (int)n; a.dur = (int)dur; a.roll = (int)(roll % n); a.n_epochs = (int)n_epochs;
+    const size_t hdr = 272;
+    const size_t resident_bytes = hdr + 16 * (size_t)n;
+    const bool resident = resident_bytes <= kLdsPerCU && n <= 65535;
+    size_t lds; int threads, blocks;
+    if (resident) {
+        a.nb = (int)n; lds = resident_bytes;
+        const size_t per_cu = kLdsPerCU / resident_bytes;
+        threads = per_cu >= 2 ? 512 : 1024;
+        const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)threads);
+        blocks = (int)std::min<int64_t>(n_epochs, (int64_t)wg_per_cu * ctx->n_cu);
+    } else {
+        a.nb = (int)std::min<int64_t>(n, 16384); lds = hdr + 4 * (size_t)a.nb;
+        threads = 512; blocks = (int)std::min<int64_t>(n_epochs, (int64_t)2 * ctx->n_cu);
+        a.scratch_stride = 3 * n;
+        TLS_HIP(ctx, ctx->d_fscratch.reserve((size_t)blocks * (size_t)a.scratch_stride));
+        a.scratch = ctx->d_fscratch.ptr;
+    }
+    hipError_t e;
+    if (resident) {
+        auto kernel = tlsdev::tls_t0fit_kernel<true, unsigned short>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
+    } else {
+        auto kernel = tlsdev::tls_t0fit_kernel<false, unsigned int>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
+    }
+    if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("t0 fit launch: ") + hipGetErrorString(e));
+    return TLS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1065,38 +1104,8 @@ int tls_t0_fit(tls_ctx* ctx, const double* t, const double* y, int64_t n, double
     if ((rc = upload(ctx, ctx->d_fep, epochs, (size_t)n_epochs))) return rc;
     TLS_HIP(ctx, ctx->d_fres.reserve((size_t)n_epochs));
     TLS_HIP(ctx, hipMemsetAsync(ctx->d_queue.ptr, 0, sizeof(unsigned int), ctx->stream));
-    tlsdev::T0FitArgs a;
-    a.t = ctx->d_ft.ptr; a.y = ctx->d_fy.ptr; a.signal = ctx->d_fsig.ptr; a.epochs = ctx->d_fep.ptr;
-    a.residuals = ctx->d_fres.ptr; a.queue = ctx->d_queue.ptr; a.scratch = nullptr; a.scratch_stride = 0;
-    a.period = period; a.n = (int)n; a.dur = (int)dur; a.roll = (int)(roll % n); a.n_epochs = (int)n_epochs;
-    const size_t hdr = 272;
-    const size_t resident_bytes = hdr + 16 * (size_t)n;
-    const bool resident = resident_bytes <= kLdsPerCU && n <= 65535;
-    size_t lds; int threads, blocks;
-    if (resident) {
-        a.nb = (int)n; lds = resident_bytes;
-        const size_t per_cu = kLdsPerCU / resident_bytes;
-        threads = per_cu >= 2 ? 512 : 1024;
-        const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)threads);
-        blocks = (int)std::min<int64_t>(n_epochs, (int64_t)wg_per_cu * ctx->n_cu);
-    } else {
-        a.nb = (int)std::min<int64_t>(n, 16384); lds = hdr + 4 * (size_t)a.nb;
-        threads = 512; blocks = (int)std::min<int64_t>(n_epochs, (int64_t)2 * ctx->n_cu);
-        a.scratch_stride = 3 * n;
-        TLS_HIP(ctx, ctx->d_fscratch.reserve((size_t)blocks * (size_t)a.scratch_stride));
-        a.scratch = ctx->d_fscratch.ptr;
-    }
-    hipError_t e;
-    if (resident) {
-        auto kernel = tlsdev::tls_t0fit_kernel<true, unsigned short>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
-    } else {
-        auto kernel = tlsdev::tls_t0fit_kernel<false, unsigned int>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
-    }
-    if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("t0 fit launch: ") + hipGetErrorString(e));
+    if ((rc = launch_t0_fit(ctx, ctx->d_ft.ptr, ctx->d_fy.ptr, ctx->d_fsig.ptr, ctx->d_fep.ptr, ctx->d_fres.ptr, ctx->d_queue.ptr,
+                            n, period, dur, n_epochs, roll))) return rc;
     TLS_HIP(ctx, hipMemcpyAsync(out_residuals, ctx->d_fres.ptr, (size_t)n_epochs * 8, hipMemcpyDeviceToHost, ctx->stream));
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TLS_OK;
@@ -1106,7 +1115,8 @@ int tls_spectra(tls_ctx* ctx, const double* chi2, int64_t n, int64_t kernel, dou
                 double* out_power, double* out_sde) {
     if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
     if (!out_SR || !out_power_raw || !out_power || !out_sde) return fail(ctx, TLS_E_ARG, "null output");
-    if (kernel < 1 || kernel > 8191) return fail(ctx, TLS_E_ARG, "median kernel out of range [1, 8191]");
+    // ((32 + kernel) doubles of dynamic LDS per median workgroup must stay within the 64 KB a launch gets without asking)
+    if (kernel < 1 || kernel > 8000) return fail(ctx, TLS_E_ARG, "median kernel out of range [1, 8000]");
     if (!chi2 && !(ctx->executed && ctx->n_periods > 0)) return fail(ctx, TLS_E_STATE, "tls_spectra without chi2 needs a finished search");
     if (chi2 && (n < 1 || n > 100000000)) return fail(ctx, TLS_E_ARG, "n out of range");
     TLS_HIP(ctx, hipSetDevice(ctx->device));
@@ -1473,6 +1483,219 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
     // the context keeps the plan, but the search ran on the batch slots: a staged execute
     // must be preceded by tls_update_flux or a new tls_prepare
     ctx->executed = false;
+    return rc;
+}
+
+int tls_power_batch(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n, int64_t n_curves,
+                    const double* periods, int64_t n_periods, const tls_template* tmpl, const tls_params* params,
+                    int64_t median_kernel, tls_power_summary* out_summary, double* out_chi2, int64_t* out_row,
+                    double* out_depth, double* out_power) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (n_curves < 0) return fail(ctx, TLS_E_ARG, "negative number of light curves");
+    if (n_curves == 0) return TLS_OK;
+    if (!t || !y || !dy || !periods || !tmpl || !params || !out_summary) return fail(ctx, TLS_E_ARG, "null argument");
+    if (n_periods < 1) return fail(ctx, TLS_E_ARG, "tls_power_batch needs at least one period");
+    if (median_kernel < 1 || median_kernel > 8000) return fail(ctx, TLS_E_ARG, "median kernel out of range [1, 8000]");
+    if ((out_row == nullptr) != (out_chi2 == nullptr) || (out_depth == nullptr) != (out_chi2 == nullptr))
+        return fail(ctx, TLS_E_ARG, "out_chi2, out_row and out_depth go together (all or none)");
+    int rc = tls_prepare(ctx, t, y, dy, n, periods, n_periods, tmpl, params);   // the plan, from the first curve
+    if (rc) return rc;
+    int64_t kernel = median_kernel;
+    if (kernel % 2 == 0) kernel += 1;                                   // stats.py:115-117
+    const int64_t group = 32;
+    const size_t np = (size_t)n_periods, nn = (size_t)n;
+    const bool uni = ctx->uniform_w;
+    const int detrend = n_periods > 2 * kernel ? 1 : 0;
+    double t_min = t[0];
+    for (int64_t i = 1; i < n; ++i) t_min = std::min(t_min, t[i]);
+    int64_t max_len = 1;
+    for (int64_t r = 0; r < tmpl->n_rows; ++r) max_len = std::max(max_len, tmpl->length[r]);
+    // device buffers of one group: flux (weights), per-curve constants, search results, spectra, summaries, T0-fit inputs
+    auto& sl = ctx->slot[0];
+    TLS_HIP(ctx, sl.d_y.reserve((size_t)group * nn));
+    if (!uni) TLS_HIP(ctx, sl.d_w.reserve((size_t)group * nn));
+    TLS_HIP(ctx, sl.d_S0.reserve((size_t)group));
+    TLS_HIP(ctx, sl.d_w0.reserve((size_t)group));
+    TLS_HIP(ctx, sl.d_chi2.reserve((size_t)group * np));
+    TLS_HIP(ctx, sl.d_row.reserve((size_t)group * np));
+    TLS_HIP(ctx, sl.d_depth.reserve((size_t)group * np));
+    TLS_HIP(ctx, ctx->d_perm.reserve((size_t)ctx->blocks * nn));
+    const size_t spec_stride = 3 * np;                                  // SR | power_raw | power of one curve
+    TLS_HIP(ctx, ctx->d_spec.reserve((size_t)group * spec_stride + 2 * (size_t)group + 8 * (size_t)group + (size_t)group));
+    double* d_sde = ctx->d_spec.ptr + (size_t)group * spec_stride;      // [group][2]
+    double* d_pick = d_sde + 2 * (size_t)group;                         // [group][8]
+    double* d_T0 = d_pick + 8 * (size_t)group;                          // [group]
+    const size_t fit_stride = nn;                                       // epochs / residuals of one curve (<= n each)
+    TLS_HIP(ctx, ctx->d_fep.reserve((size_t)group * fit_stride));
+    TLS_HIP(ctx, ctx->d_fres.reserve((size_t)group * fit_stride));
+    TLS_HIP(ctx, ctx->d_fsig.reserve((size_t)group * (size_t)max_len + (size_t)group));   // signals | n_epochs (as int, behind)
+    DevBuf<unsigned int> d_queues;
+    TLS_HIP(ctx, d_queues.reserve((size_t)group));
+    // pinned staging: flux in; summaries, T0 and (on request) the per-period arrays out; epochs + signals in
+    const size_t in_doubles = (size_t)group * nn * (uni ? 1 : 2) + 2 * (size_t)group;
+    const size_t fit_doubles = (size_t)group * fit_stride + (size_t)group * (size_t)max_len + (size_t)group;
+    const size_t out_doubles = 11 * (size_t)group + (out_chi2 ? 3 * (size_t)group * np : 0) + (out_power ? (size_t)group * np : 0);
+    const size_t want_in = std::max(in_doubles, fit_doubles);
+    if (sl.h_in_cap < want_in) {
+        if (sl.h_in) TLS_HIP(ctx, hipHostFree(sl.h_in));
+        sl.h_in = nullptr; sl.h_in_cap = 0;
+        TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.h_in), want_in * 8, hipHostMallocDefault));
+        sl.h_in_cap = want_in;
+    }
+    if (sl.h_out_cap < out_doubles) {
+        if (sl.h_out) TLS_HIP(ctx, hipHostFree(sl.h_out));
+        sl.h_out = nullptr; sl.h_out_cap = 0;
+        TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), out_doubles * 8, hipHostMallocDefault));
+        sl.h_out_cap = out_doubles;
+    }
+    std::vector<double> w;
+    std::vector<int> n_epochs_h((size_t)group);
+    rc = TLS_OK;
+    const int64_t n_groups = (n_curves + group - 1) / group;
+    for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
+        const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
+        // ---- flux of the group into the device, search (tls_search_batch's launch: fold + sort shared by the group)
+        double* h_y = sl.h_in;
+        double* h_w = sl.h_in + (size_t)group * nn;
+        double* h_S0 = sl.h_in + (size_t)group * nn * (uni ? 1 : 2);
+        double* h_w0 = h_S0 + group;
+        double sigma_sum = 0.0, group_y_max = 0.0;
+        for (int64_t c = 0; c < gc; ++c) {
+            bool uniform; double w0, S0;
+            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0, &group_y_max);
+            if (uniform != uni) { rc = fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy"); break; }
+            h_S0[c] = S0; h_w0[c] = w0;
+            std::memcpy(h_y + (size_t)c * nn, y + (c0 + c) * n, nn * 8);
+            if (!uniform) std::memcpy(h_w + (size_t)c * nn, w.data(), nn * 8);
+            sigma_sum += flux_scatter(y + (c0 + c) * n, n);
+        }
+        if (rc) break;
+        TLS_HIP(ctx, hipMemcpyAsync(sl.d_y.ptr, h_y, (size_t)gc * nn * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (!uni) TLS_HIP(ctx, hipMemcpyAsync(sl.d_w.ptr, h_w, (size_t)gc * nn * 8, hipMemcpyHostToDevice, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(sl.d_S0.ptr, h_S0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(sl.d_w0.ptr, h_w0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->stream));
+        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = group_y_max;
+        ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident);
+        ctx->batch_curves = (int)gc;
+        ctx->over_y = sl.d_y.ptr; ctx->over_w = uni ? nullptr : sl.d_w.ptr; ctx->over_S0 = sl.d_S0.ptr; ctx->over_w0 = sl.d_w0.ptr;
+        ctx->over_chi2 = sl.d_chi2.ptr; ctx->over_row = sl.d_row.ptr; ctx->over_depth = sl.d_depth.ptr;
+        rc = enqueue(ctx, false);
+        ctx->batch_curves = 1;
+        ctx->over_y = ctx->over_w = ctx->over_S0 = ctx->over_w0 = nullptr;
+        ctx->over_chi2 = nullptr; ctx->over_row = nullptr; ctx->over_depth = nullptr;
+        if (rc) break;
+        // ---- spectra of every curve of the group (stats.py:105-132), then what main.py:198-212,269-272 read off them
+        tlsdev::SpectraArgs sa;
+        sa.chi2 = sl.d_chi2.ptr; sa.SR = ctx->d_spec.ptr; sa.power_raw = ctx->d_spec.ptr + np; sa.power = ctx->d_spec.ptr + 2 * np;
+        sa.sde = d_sde; sa.n = (int)n_periods; sa.kernel = (int)kernel; sa.detrend = detrend;
+        sa.chi2_stride = (long long)np; sa.out_stride = (long long)spec_stride; sa.sde_stride = 2;
+        hipLaunchKernelGGL(tlsdev::tls_spectra_head, dim3(1, (unsigned)gc), dim3(1024), 0, ctx->stream, sa);
+        if (detrend) {
+            const int n_med = (int)(n_periods - kernel + 1), per = tlsdev::kMedianWindows;
+            const size_t lds = (size_t)(2 * per + kernel) * 8;
+            hipLaunchKernelGGL(tlsdev::tls_spectra_median, dim3((unsigned)((n_med + per - 1) / per), (unsigned)gc), dim3(256), lds,
+                               ctx->stream, sa);
+            hipLaunchKernelGGL(tlsdev::tls_spectra_tail, dim3(1, (unsigned)gc), dim3(1024), 0, ctx->stream, sa);
+        }
+        tlsdev::PickArgs pa;
+        pa.chi2 = sl.d_chi2.ptr; pa.row = sl.d_row.ptr; pa.depth = sl.d_depth.ptr; pa.power = ctx->d_spec.ptr + 2 * np;
+        pa.periods = ctx->d_periods.ptr; pa.out = d_pick; pa.power_stride = (long long)spec_stride; pa.n = (int)n_periods;
+        hipLaunchKernelGGL(tlsdev::tls_power_pick, dim3((unsigned)gc), dim3(1024), 0, ctx->stream, pa);
+        TLS_HIP(ctx, hipGetLastError());
+        double* h_pick = sl.h_out;                        // [group][8]
+        double* h_sde = sl.h_out + 8 * (size_t)group;     // [group][2]
+        double* h_T0 = h_sde + 2 * (size_t)group;         // [group]
+        double* h_arrays = h_T0 + group;                  // chi2 | row | depth | power, on request
+        TLS_HIP(ctx, hipMemcpyAsync(h_pick, d_pick, (size_t)gc * 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(h_sde, d_sde, (size_t)gc * 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // ---- final T0 fit of every curve (stats.py:135-204): trial epochs and the depth-scaled template on the host
+        // (a few KB per curve), the fold + sort + residual of every epoch on the device, first minimum on the device
+        double* h_ep = sl.h_in;                                            // [group][fit_stride]
+        double* h_sig = sl.h_in + (size_t)group * fit_stride;              // [group][max_len]
+        int* h_nep = reinterpret_cast<int*>(h_sig + (size_t)group * (size_t)max_len);
+        for (int64_t c = 0; c < gc; ++c) {
+            const double* pk = h_pick + 8 * c;
+            int points = 0;
+            if (pk[6] == 0.0) {   // a transit was fit (main.py:203-216 otherwise: T0 = 0)
+                const int64_t best_row = (int64_t)pk[5];
+                const int64_t dur = tmpl->length[best_row];
+                const double depth = pk[4], period = pk[3];
+                const double scale = 0.5 / (1 - depth);                   // SIGNAL_DEPTH / (1 - depth), stats.py:142
+                const double* sig = tmpl->values + tmpl->offset[best_row];
+                for (int64_t j = 0; j < dur; ++j) h_sig[(size_t)c * (size_t)max_len + (size_t)j] = 1 - ((1 - sig[j]) / scale);
+                if (params->T0_fit_margin == 0) points = (int)n;
+                else points = (int)((double)n / (params->T0_fit_margin * (double)dur));   // stats.py:150
+                if (points > n) points = (int)n;
+                if (points < 0) points = 0;
+                // numpy.linspace(min t, min t + period, points): arange * step + start, the end point set exactly
+                const double stop = t_min + period;
+                if (points == 1) h_ep[(size_t)c * fit_stride] = t_min;
+                else if (points > 1) {
+                    const double step = (stop - t_min) / (double)(points - 1);
+                    for (int i = 0; i < points; ++i) {
+                        volatile double prod = (double)i * step;           // two roundings, like numpy (no contraction)
+                        h_ep[(size_t)c * fit_stride + (size_t)i] = prod + t_min;
+                    }
+                    h_ep[(size_t)c * fit_stride + (size_t)points - 1] = stop;
+                }
+            }
+            n_epochs_h[(size_t)c] = points;
+            h_nep[c] = points;
+        }
+        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_fep.ptr, h_ep, (size_t)gc * fit_stride * 8, hipMemcpyHostToDevice, ctx->stream));
+        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_fsig.ptr, h_sig, ((size_t)group * (size_t)max_len + (size_t)group) * 8,
+                                    hipMemcpyHostToDevice, ctx->stream));
+        TLS_HIP(ctx, hipMemsetAsync(d_queues.ptr, 0, (size_t)group * sizeof(unsigned int), ctx->stream));
+        for (int64_t c = 0; c < gc && rc == TLS_OK; ++c) {
+            if (n_epochs_h[(size_t)c] == 0) continue;
+            const double* pk = h_pick + 8 * c;
+            const int64_t dur = tmpl->length[(int64_t)pk[5]];
+            rc = launch_t0_fit(ctx, ctx->d_t.ptr, sl.d_y.ptr + (size_t)c * nn, ctx->d_fsig.ptr + (size_t)c * (size_t)max_len,
+                               ctx->d_fep.ptr + (size_t)c * fit_stride, ctx->d_fres.ptr + (size_t)c * fit_stride,
+                               d_queues.ptr + c, n, pk[3], dur, n_epochs_h[(size_t)c], dur / 2 + 1);
+        }
+        if (rc) break;
+        tlsdev::FirstMinArgs fa;
+        fa.residuals = ctx->d_fres.ptr; fa.epochs = ctx->d_fep.ptr;
+        fa.n_epochs = reinterpret_cast<const int*>(ctx->d_fsig.ptr + (size_t)group * (size_t)max_len);
+        fa.T0 = d_T0; fa.stride = (long long)fit_stride;
+        hipLaunchKernelGGL(tlsdev::tls_first_min, dim3((unsigned)gc), dim3(1024), 0, ctx->stream, fa);
+        TLS_HIP(ctx, hipGetLastError());
+        TLS_HIP(ctx, hipMemcpyAsync(h_T0, d_T0, (size_t)gc * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_chi2) {
+            TLS_HIP(ctx, hipMemcpyAsync(h_arrays, sl.d_chi2.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+            TLS_HIP(ctx, hipMemcpyAsync(h_arrays + (size_t)group * np, sl.d_row.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+            TLS_HIP(ctx, hipMemcpyAsync(h_arrays + 2 * (size_t)group * np, sl.d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        double* h_power = h_arrays + (out_chi2 ? 3 * (size_t)group * np : 0);
+        if (out_power)
+            for (int64_t c = 0; c < gc; ++c)
+                TLS_HIP(ctx, hipMemcpyAsync(h_power + (size_t)c * np, ctx->d_spec.ptr + (size_t)c * spec_stride + 2 * np, np * 8,
+                                            hipMemcpyDeviceToHost, ctx->stream));
+        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int64_t c = 0; c < gc; ++c) {
+            const double* pk = h_pick + 8 * c;
+            tls_power_summary& o = out_summary[c0 + c];
+            const bool no_fit = pk[6] != 0.0;
+            o.chi2_min = pk[0]; o.index_best = (int64_t)pk[1]; o.index_power = (int64_t)pk[2];
+            o.best_row = (int64_t)pk[5]; o.no_fit = no_fit ? 1 : 0;
+            if (no_fit) {   // main.py:216-267: flat spectra
+                o.SDE = 0; o.SDE_raw = 0; o.period = std::nan(""); o.T0 = 0; o.depth = 1;
+            } else {
+                o.SDE_raw = h_sde[2 * c]; o.SDE = h_sde[2 * c + 1]; o.period = pk[3]; o.depth = pk[4]; o.T0 = h_T0[c];
+            }
+        }
+        if (out_chi2) {
+            std::memcpy(out_chi2 + c0 * n_periods, h_arrays, (size_t)gc * np * 8);
+            std::memcpy(out_row + c0 * n_periods, h_arrays + (size_t)group * np, (size_t)gc * np * 8);
+            std::memcpy(out_depth + c0 * n_periods, h_arrays + 2 * (size_t)group * np, (size_t)gc * np * 8);
+        }
+        if (out_power) std::memcpy(out_power + c0 * n_periods, h_power, (size_t)gc * np * 8);
+    }
+    if (rc != TLS_OK) (void)hipStreamSynchronize(ctx->stream);
+    d_queues.release();
+    ctx->executed = false;   // the search ran on the batch slot, see tls_search_batch
     return rc;
 }
 

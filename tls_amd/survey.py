@@ -8,26 +8,19 @@ Across GPUs the light curves are simply dealt to the ranks (one process per GPU)
 import numpy
 
 from . import search as _search
-from . import synthetic
+from .planning import search_inputs
 
 
-def search_batch(t, flux_batch, dy_batch=None, context=None, device=None, **power_kwargs):
-    """Search every light curve of `flux_batch` (shape [n_curves, n_points]) on the grids that
-    `transitleastsquares(t, flux).power(**power_kwargs)` would use.
-
-    Returns (periods, chi2[n_curves, n_periods], row[...], depth[...]).  All light curves must
-    share `t` and be free of invalid points (clean them first); a `dy_batch` must have the same
-    weight structure for every curve (all uniform or all per-point).
-    """
+def _batch_inputs(t, flux_batch, dy_batch, power_kwargs):
+    """(inp, y_rows, dy_rows): the plan inputs of the first curve and every curve's (y, dy) exactly as
+    validate.py would hand them to a single search (validate.py:18,39-40)."""
     flux_batch = numpy.asarray(flux_batch, dtype=numpy.float64)
     if flux_batch.ndim != 2 or flux_batch.shape[1] != len(t):
         raise ValueError("flux_batch must have shape [n_curves, len(t)]")
-    ctx = context if context is not None else _search.default_context(device)
     first_dy = None if dy_batch is None else numpy.asarray(dy_batch[0], dtype=numpy.float64)
-    inp = synthetic.search_inputs(t, flux_batch[0], first_dy, **power_kwargs)
+    inp = search_inputs(t, flux_batch[0], first_dy, **power_kwargs)
     if len(inp["t"]) != len(t):
         raise ValueError("light curves must be cleaned before a batched search")
-    # dy exactly as validate.py would hand it to every single search (validate.py:18,39-40)
     dy_rows = numpy.empty_like(flux_batch)
     dy_rows[0] = inp["dy"]
     for k in range(1, len(flux_batch)):
@@ -38,5 +31,47 @@ def search_batch(t, flux_batch, dy_batch=None, context=None, device=None, **powe
             dy_rows[k] = dy / numpy.mean(dy)
     y_rows = flux_batch.copy()
     y_rows[0] = inp["y"]
+    return inp, y_rows, dy_rows
+
+
+def power_batch(t, flux_batch, dy_batch=None, context=None, device=None, with_arrays=False, **power_kwargs):
+    """Survey-mode power(): for every light curve of `flux_batch` what `transitleastsquares(t, flux).power(**kwargs)`
+    reports as SDE, SDE_raw, chi2_min, period, T0, depth and duration (fractional, lc_cache_overview["duration"] of
+    the template row at the chi^2 minimum, main.py:199-200) -- search, SDE spectra and final T0 fit all on the
+    device (tls_power_batch), one record of 80 bytes back per light curve.
+
+    Returns (summary, periods[, chi2, row, depth, power]): summary is a numpy structured array with the fields of
+    tls_power_summary plus "duration".  The per-transit statistics of power() (SNR, odd/even, counts) are host work
+    on a handful of candidates and are not part of the batch call."""
+    ctx = context if context is not None else _search.default_context(device)
+    inp, y_rows, dy_rows = _batch_inputs(t, flux_batch, dy_batch, power_kwargs)
+    from . import constants as C
+    osf = power_kwargs.get("oversampling_factor", C.OVERSAMPLING_FACTOR)
+    kernel = osf * C.SDE_MEDIAN_KERNEL_SIZE
+    if kernel != int(kernel):
+        raise ValueError("oversampling_factor * %d must be an integer" % C.SDE_MEDIAN_KERNEL_SIZE)
+    raw, chi2, row, depth, power = ctx.power_batch(inp["t"], y_rows, dy_rows, inp["periods"], inp["table"], inp["params"],
+                                                   int(kernel), with_arrays=with_arrays, with_power=with_arrays)
+    names = list(raw.dtype.names) + ["duration"]
+    summary = numpy.zeros(len(raw), dtype=[(k, raw.dtype[k]) for k in raw.dtype.names] + [("duration", "f8")])
+    for k in raw.dtype.names:
+        summary[k] = raw[k]
+    summary["duration"] = numpy.where(raw["no_fit"] != 0, numpy.nan, inp["table"].duration[raw["best_row"]])
+    assert names == list(summary.dtype.names)
+    if with_arrays:
+        return summary, inp["periods"], chi2, row, depth, power
+    return summary, inp["periods"]
+
+
+def search_batch(t, flux_batch, dy_batch=None, context=None, device=None, **power_kwargs):
+    """Search every light curve of `flux_batch` (shape [n_curves, n_points]) on the grids that
+    `transitleastsquares(t, flux).power(**power_kwargs)` would use.
+
+    Returns (periods, chi2[n_curves, n_periods], row[...], depth[...]).  All light curves must
+    share `t` and be free of invalid points (clean them first); a `dy_batch` must have the same
+    weight structure for every curve (all uniform or all per-point).
+    """
+    ctx = context if context is not None else _search.default_context(device)
+    inp, y_rows, dy_rows = _batch_inputs(t, flux_batch, dy_batch, power_kwargs)
     chi2, row, depth = ctx.search_batch(inp["t"], y_rows, dy_rows, inp["periods"], inp["table"], inp["params"])
     return inp["periods"], chi2, row, depth
