@@ -796,3 +796,50 @@ def test_commensurate_periods_cost_no_more_than_their_neighbours(gpu, oracle_lib
     sel = numpy.nonzero(special)[0]
     want = oracle_search(oracle_lib, inp, periods=periods[sel])
     assert_parity(tuple(a[sel] for a in got[:3]), want, n)
+
+
+def test_post_search_kernels_at_kepler_and_tess_size(gpu, oracle_lib):
+    """The two post-search kernels at the sizes of BASELINE configs 3 and 4 (round 2 checked them at K2 size only):
+    tls_t0_fit vs the oracle at N = 70 128 (250 trial epochs: the non-resident T0-fit path with its HBM slabs, a
+    period commensurate with the cadence among them) and at N = 19 440; tls_spectra vs the oracle on the
+    182 388-period Kepler chi^2 array, handed in and resident after the search."""
+    for name, n_epochs, periods in (("kepler_4yr", 250, (10.12452, 78 / 48.0)), ("tess_27d", 300, (3.377,))):
+        t, f, kw = synthetic.config(name)
+        inp = synthetic.search_inputs(t, f, **kw)
+        row = len(inp["rows"]) // 2
+        signal = 1 - (1 - inp["rows"][row]) * 0.002
+        roll = int(len(signal) / 2) + 1
+        for period in periods:
+            epochs = numpy.linspace(t.min(), t.min() + period, n_epochs)
+            want = oracle_lib.t0_residuals(inp["t"], inp["y"], period, signal, epochs, roll)
+            got = gpu.t0_fit_residuals(inp["t"], inp["y"], period, signal, epochs, roll)
+            numpy.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+            assert int(numpy.argmin(got)) == int(numpy.argmin(want))
+    # spectra on the Kepler-size chi^2 (kernel 90 = oversampling 3 x 30): the reductions of tls_spectra_head/tail run as
+    # ONE workgroup over 182 388 values, the running median as 11 394 workgroups
+    inp = _inputs("kepler_4yr")
+    chi2 = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])[0]
+    assert len(chi2) == 182388
+    want = oracle_lib.spectra(chi2, 90)
+    # numpy restatement of stats.py:105-132 (numpy sums pairwise, as the reference does; the oracle sums left to right,
+    # and over 182 388 values that moves the mean of SR by ~5e-14 -- 3e-9 after the division by std SR)
+    from tls_amd.helpers import running_median
+    SR = numpy.min(chi2) / chi2
+    sde_raw = (1 - numpy.mean(SR)) / numpy.std(SR)
+    praw = SR - numpy.mean(SR)
+    praw = praw * (sde_raw / numpy.max(praw))
+    power = praw - running_median(praw, 91)
+    power = power - numpy.mean(power)
+    sde = numpy.max(power / numpy.std(power))
+    power = power * (sde / numpy.max(power))
+    for got in (gpu.spectra(90, chi2), gpu.spectra(90)):
+        numpy.testing.assert_allclose(got[0], SR, rtol=1e-13)
+        numpy.testing.assert_allclose(got[1], praw, rtol=1e-10, atol=2e-11)
+        numpy.testing.assert_allclose(got[2], power, rtol=1e-10, atol=2e-11)
+        numpy.testing.assert_allclose(got[3:], [sde_raw, sde], rtol=1e-11)
+        assert int(numpy.argmax(got[2])) == int(numpy.argmax(power))
+        numpy.testing.assert_allclose(got[0], want[0], rtol=1e-13)
+        for x, y in zip(got[1:3], want[1:3]):
+            numpy.testing.assert_allclose(x, y, rtol=1e-8, atol=1e-8)
+        numpy.testing.assert_allclose(got[3:], want[3:], rtol=1e-9)
+        assert int(numpy.argmax(got[2])) == int(numpy.argmax(want[2]))

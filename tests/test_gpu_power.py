@@ -178,3 +178,35 @@ def test_power_batch_equals_power_per_curve_and_the_oracle(oracle_lib, weights):
             assert abs(rec["depth"] - o_depth[rec["index_power"]]) < 1e-11
             assert rec["duration"] == inp["overview"]["duration"][rec["best_row"]]
     ctx.close()
+
+
+def test_power_at_tess_size_gpu_equals_power_with_oracle_search(oracle_lib, monkeypatch):
+    """One whole power() call at the size of BASELINE config 4 (N = 19 440, 2459 periods: the HBM-slab kernel, the
+    non-resident T0 fit): every result of the drop-in on the GPU against the same host layer fed by the oracle's
+    search, spectra and T0-fit residuals."""
+    t, f, kw = synthetic.config("tess_27d")
+    kwargs = dict(kw, verbose=False, show_progress_bar=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = make_model(t, f, None).power(**kwargs)
+
+        def oracle_search_periods(t_, y_, dy_, periods, table, transit_depth_min, R_star_min, R_star_max,
+                                  M_star_min, M_star_max, T0_fit_margin, **_unused):
+            return oracle_lib.search(t_, y_, dy_, periods, table, transit_depth_min, R_star_min, R_star_max,
+                                     M_star_min, M_star_max, T0_fit_margin)[:3]
+
+        monkeypatch.setattr(tls_amd.search, "spectra",
+                            lambda chi2_, osf_, **kw_: oracle_lib.spectra(chi2_, int(osf_ * 30)))
+        monkeypatch.setattr(tls_amd.search, "search_periods", oracle_search_periods)
+        monkeypatch.setattr(tls_amd.search, "t0_fit_residuals",
+                            lambda t_, y_, p_, s_, e_, r_, **kw_: oracle_lib.t0_residuals(t_, y_, p_, s_, e_, r_))
+        want = make_model(t, f, None).power(**kwargs)
+    assert list(got.keys()) == list(want.keys())
+    for key in pins.SCALARS:
+        numpy.testing.assert_allclose(float(got[key]), float(want[key]), rtol=1e-9, atol=1e-12, err_msg=key)
+    for key in pins.ARRAYS:
+        atol = 2e-9 if key in ("power", "power_raw", "SR") else 1e-11
+        numpy.testing.assert_allclose(numpy.asarray(got[key], dtype=float), numpy.asarray(want[key], dtype=float),
+                                      rtol=1e-9, atol=atol, err_msg=key)
+    assert int(numpy.argmin(got.chi2)) == int(numpy.argmin(want.chi2))
+    assert abs(got.period - 10.123) < 0.05
