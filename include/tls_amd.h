@@ -30,6 +30,10 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a struct of this header changes its layout or an entry point its signature (3: tls_counters has
+ * five fields, tls_period_costs / tls_power_batch exist).  A binding compares it with tls_abi_version(). */
+#define TLS_AMD_ABI_VERSION 3
+
 #define TLS_OK 0
 #define TLS_E_ARG (-1)      /* invalid argument */
 #define TLS_E_HIP (-2)      /* HIP runtime error (message has the HIP error string) */
@@ -74,6 +78,7 @@ tls_ctx *tls_ctx_create(int device_id);     /* NULL on failure, see tls_last_err
 void tls_ctx_destroy(tls_ctx *ctx);
 const char *tls_last_error(const tls_ctx *ctx);
 const char *tls_version(void);
+int tls_abi_version(void);                  /* TLS_AMD_ABI_VERSION the library was built with */
 /* "gfx950 ..." style description of the context's device (valid until ctx destroy) */
 const char *tls_device_name(const tls_ctx *ctx);
 
@@ -210,7 +215,8 @@ int tls_grid_cells(const double *t, int64_t n, const double *periods, int64_t n_
  * (depth predicate) + a part per expected tap, coefficients measured on an MI355X. */
 int tls_period_costs(const double *t, int64_t n, const double *periods, int64_t n_periods,
                      const tls_template *tmpl, const tls_params *params, double sigma,
-                     int64_t *cells_per_period, double *taps_per_period, double *time_per_period);
+                     int64_t *cells_per_period, double *taps_per_period, double *time_per_period,
+                     int64_t *workgroups_in_flight /* periods one MI355X searches side by side, may be NULL */);
 
 /* ---- multi-GPU: period grid sharded over ranks, one RCCL all-gather at the end --- */
 /* rank 0 creates the 128-byte id and hands it to the other ranks by any host channel */

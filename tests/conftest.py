@@ -57,7 +57,7 @@ def gpu():
     from tls_amd import _lib
     ctx = _lib.Context(0)
     yield ctx
-    # a checked build (make -C tls_amd/csrc debug, TLS_AMD_LIB=.../libtls_amd_debug.so) counts every violated
+    # a checked build (make -C tls_amd/csrc debug, TLS_AMD_DEBUG=1 TLS_AMD_LIB=.../libtls_amd_debug.so) counts every violated
     # device-side bound: after the whole session none may have fired
     checked, counts = ctx.check_counts()
     ctx.close()

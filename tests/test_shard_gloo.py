@@ -71,7 +71,8 @@ def _worker(rank, world, port, out_dir):
 
     full = job.gather(gloo_allgather)
     numpy.savez(os.path.join(out_dir, "rank%d.npz" % rank), chi2=full[0], row=full[1],
-                depth=full[2], lo=lo, hi=hi, cells=job.my_cells(), time=float(numpy.sum(job.times[lo:hi])))
+                depth=full[2], lo=lo, hi=hi, cells=job.my_cells(), time=float(numpy.sum(job.times[lo:hi])),
+                span=sh.block_makespan(job.times[lo:hi], job.slots), slots=job.slots, times=job.times)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -97,9 +98,12 @@ def test_sharded_search_equals_single_process(tmp_path, oracle_lib, world):
     assert ranks[0]["lo"] == 0 and ranks[-1]["hi"] == len(inp["periods"])
     for a, b in zip(ranks[:-1], ranks[1:]):
         assert a["hi"] == b["lo"]
-    # ... and balanced in MODELLED TIME (tls_period_costs), which is what the boundaries are placed by
-    times = numpy.array([float(r["time"]) for r in ranks])
-    assert times.max() / times.mean() < 1.05
+    # ... placed by the modelled time at which a rank's LAST round of periods ends (tls_period_costs, block_makespan):
+    # the slowest rank is never slower than with blocks of equal summed time
+    spans = numpy.array([float(r["span"]) for r in ranks])
+    times, slots = ranks[0]["times"], int(ranks[0]["slots"])
+    by_sum = shard.partition_by_cost(times, world)
+    assert spans.max() <= max(shard.block_makespan(times[by_sum[r]:by_sum[r + 1]], slots) for r in range(world)) * (1 + 1e-12)
     assert sum(int(r["cells"]) for r in ranks) == int(numpy.sum(shard._lib.grid_cells(inp["t"], inp["periods"], inp["table"], inp["params"])))
 
 
@@ -119,6 +123,7 @@ def test_time_model_balances_measured_period_cycles(fixture, limit):
     assert len(cycles) == len(periods)
     job = shard.ShardedSearch(0, 1)
     job.plan(inp["t"], periods, inp["table"], inp["params"], y=inp["y"])
+    assert job.slots in (256, 512)
     worst_model = worst_cells = 0.0
     for ranks in (2, 4, 8):
         for cost, label in ((job.times, "model"), (job.costs.astype(float), "cells")):
@@ -131,3 +136,29 @@ def test_time_model_balances_measured_period_cycles(fixture, limit):
                 worst_cells = max(worst_cells, imb)
     assert worst_model <= limit, (worst_model, worst_cells)
     assert worst_cells >= 1.15, worst_cells   # what balancing cells alone leaves on the table
+
+
+def test_partition_by_makespan_fills_whole_rounds():
+    """A rank's GPU searches `slots` periods side by side: a block of 307 periods on 256 slots takes two rounds.  The
+    boundaries are placed by the time at which a block's LAST round ends (block_makespan), not by summed time."""
+    times = numpy.full(2459, 1.0)                      # TESS: 2459 periods of (here) equal cost, 8 ranks, 256 slots
+    b = shard.partition_by_makespan(times, 8, 256)
+    assert b[0] == 0 and b[-1] == 2459 and numpy.all(numpy.diff(b) >= 0)
+    spans = [shard.block_makespan(times[b[r]:b[r + 1]], 256) for r in range(8)]
+    by_sum = shard.partition_by_cost(times, 8)
+    spans_sum = [shard.block_makespan(times[by_sum[r]:by_sum[r + 1]], 256) for r in range(8)]
+    assert max(spans) <= max(spans_sum)                # never worse than balancing the sums
+    assert max(spans) == 2.0                            # 2459 / 8 = 307 > 256: two rounds somewhere, but never three
+    assert shard.block_makespan(numpy.full(307, 1.0), 256) == 2.0
+    assert shard.block_makespan(numpy.full(256, 1.0), 256) == 1.0
+    # many rounds per rank: the same as balancing sums
+    big = numpy.random.RandomState(1).uniform(1, 3, 200000)
+    numpy.testing.assert_array_equal(shard.partition_by_makespan(big, 4, 8), shard.partition_by_cost(big, 4))
+    # monotone costs, few rounds: the makespan of the slowest block does not exceed the sum-balanced one
+    ramp = numpy.linspace(1.0, 2.5, 9679)
+    for ranks in (2, 4, 8):
+        bm = shard.partition_by_makespan(ramp, ranks, 512)
+        bs = shard.partition_by_cost(ramp, ranks)
+        worst_m = max(shard.block_makespan(ramp[bm[r]:bm[r + 1]], 512) for r in range(ranks))
+        worst_s = max(shard.block_makespan(ramp[bs[r]:bs[r + 1]], 512) for r in range(ranks))
+        assert worst_m <= worst_s * (1 + 1e-12)

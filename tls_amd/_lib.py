@@ -6,16 +6,22 @@ shared library is missing, or no GPU is usable, the error surfaces here.
 """
 import ctypes
 import os
+import weakref
 
 import numpy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# TLS_AMD_LIB: developer switch for A/B timing of two builds of the same source (tls_amd/csrc/Makefile `variant`)
-LIB_PATH = os.environ.get("TLS_AMD_LIB") or os.path.join(_HERE, "libtls_amd.so")
+# Developer switch for A/B timing of two builds of the same source (tls_amd/csrc/Makefile `variant`, `debug`): another
+# library is loaded only when TLS_AMD_DEBUG=1 says this is a developer session AND TLS_AMD_LIB names it -- a stray
+# TLS_AMD_LIB in a user's environment does not redirect the product.
+LIB_PATH = os.path.join(_HERE, "libtls_amd.so")
+if os.environ.get("TLS_AMD_DEBUG") == "1" and os.environ.get("TLS_AMD_LIB"):
+    LIB_PATH = os.environ["TLS_AMD_LIB"]
+ABI_VERSION = 3   # include/tls_amd.h TLS_AMD_ABI_VERSION: checked against the library at load time
 
 # every symbol include/tls_amd.h declares (tests check the export list against the header)
 SYMBOLS = (
-    "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version",
+    "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version", "tls_abi_version",
     "tls_device_name", "tls_search", "tls_search_batch", "tls_power_batch", "tls_prepare", "tls_update_flux", "tls_execute",
     "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_period_cycles",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
@@ -74,6 +80,10 @@ def load():
             "g.build()'` or `make -C tls_amd/csrc`; there is no CPU fallback" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+    lib.tls_abi_version.restype = ci
+    if lib.tls_abi_version() != ABI_VERSION:
+        raise RuntimeError("tls_amd: %s implements ABI version %d, this binding expects %d (struct layouts differ): "
+                           "rebuild with `make -C tls_amd/csrc`" % (LIB_PATH, lib.tls_abi_version(), ABI_VERSION))
     lib.tls_device_count.restype = ci
     lib.tls_ctx_create.restype = vp
     lib.tls_ctx_create.argtypes = [ci]
@@ -132,7 +142,8 @@ def load():
     lib.tls_grid_cells.restype = ci
     lib.tls_grid_cells.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, _c_int64_p]
     lib.tls_period_costs.restype = ci
-    lib.tls_period_costs.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, dbl, _c_int64_p, _c_double_p, _c_double_p]
+    lib.tls_period_costs.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, dbl, _c_int64_p, _c_double_p, _c_double_p,
+                                     _c_int64_p]
     lib.tls_comm_unique_id.restype = ci
     lib.tls_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.tls_comm_init.restype = ci
@@ -186,6 +197,7 @@ class Context(object):
                                + self._lib.tls_last_error(None).decode())
         self.device = int(device)
         self._n_periods = 0
+        self._resident_chi2 = None   # weak reference to the chi2 array the last fetch returned (see spectra)
 
     # -- plumbing
     def close(self):
@@ -280,6 +292,7 @@ class Context(object):
         return summary, chi2, row, depth, power
 
     def prepare(self, t, y, dy, periods, table, params):
+        self._resident_chi2 = None
         t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)
         if not (t.ndim == y.ndim == dy.ndim == 1 and len(t) == len(y) == len(dy)):
             raise ValueError("t, y, dy must be 1-dimensional and of equal length")
@@ -293,6 +306,7 @@ class Context(object):
         self._check(self._lib.tls_update_flux(self._h, _dp(y), _dp(dy)))
 
     def execute(self, count_work=False, phase_clock=False):
+        self._resident_chi2 = None
         self._check(self._lib.tls_execute(self._h, (1 if count_work else 0) | (2 if phase_clock else 0)))
 
     def t0_fit_residuals(self, t, y, period, signal, epochs, roll):
@@ -302,6 +316,12 @@ class Context(object):
         self._check(self._lib.tls_t0_fit(self._h, _dp(t), _dp(y), len(t), float(period), _dp(signal),
                                          len(signal), _dp(epochs), len(epochs), int(roll), _dp(out)))
         return out
+
+    def holds(self, chi2):
+        """True if `chi2` is the very array the last fetch of this context returned and no search has run since:
+        the device then still holds the same values and tls_spectra may read them in place."""
+        ref = self._resident_chi2
+        return ref is not None and ref() is chi2 and len(chi2) == self._n_periods
 
     def spectra(self, kernel, chi2=None):
         """SR, power_raw, power, SDE_raw, SDE (stats.py:105-132) on the device; chi2=None takes the
@@ -382,6 +402,7 @@ class Context(object):
         depth = numpy.empty(n, dtype=numpy.float64)
         c = Counters()
         self._check(self._lib.tls_fetch(self._h, _dp(chi2), _ip(row), _dp(depth), ctypes.byref(c)))
+        self._resident_chi2 = weakref.ref(chi2)   # exactly this array is what the device still holds
         if with_counters:
             return chi2, row, depth, c.as_dict()
         return chi2, row, depth
@@ -479,7 +500,7 @@ def grid_cells(t, periods, table, params):
     return out
 
 
-def period_costs(t, periods, table, params, sigma):
+def period_costs(t, periods, table, params, sigma, with_slots=False):
     """(trial cells, expected template taps, modelled search time) of every period: what the shard
     boundaries are placed by (host-only planning call, needs no GPU)."""
     lib = load()
@@ -488,10 +509,13 @@ def period_costs(t, periods, table, params, sigma):
     cells = numpy.zeros(len(periods), dtype=numpy.int64)
     taps = numpy.zeros(len(periods), dtype=numpy.float64)
     time = numpy.zeros(len(periods), dtype=numpy.float64)
+    slots = ctypes.c_int64(0)
     rc = lib.tls_period_costs(_dp(t), len(t), _dp(periods), len(periods), ctypes.byref(tm), ctypes.byref(pr),
-                              float(sigma), _ip(cells), _dp(taps), _dp(time))
+                              float(sigma), _ip(cells), _dp(taps), _dp(time), ctypes.byref(slots))
     if rc != 0:
         raise RuntimeError("tls_amd error %d: %s" % (rc, lib.tls_last_error(None).decode()))
+    if with_slots:
+        return cells, taps, time, int(slots.value)
     return cells, taps, time
 
 

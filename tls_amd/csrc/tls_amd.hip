@@ -709,7 +709,9 @@ int launch_t0_fit(tls_ctx* ctx, const double* d_t, const double* d_y, const doub
 
 extern "C" {
 
-const char* tls_version(void) { return "tls_amd 0.1 (gfx950)"; }
+const char* tls_version(void) { return "tls_amd 0.3 (gfx950)"; }
+
+int tls_abi_version(void) { return TLS_AMD_ABI_VERSION; }
 
 int tls_device_count(void) {
     int n = 0;
@@ -1165,12 +1167,15 @@ int tls_debug_folded(tls_ctx* ctx, double* out, int64_t capacity) {
     DevBuf<double> d_out;
     TLS_HIP(ctx, d_out.reserve((size_t)need));
     int rc = enqueue(ctx, false, false, d_out.ptr);
-    if (rc) { d_out.release(); return rc; }
-    ctx->executed = true;
-    TLS_HIP(ctx, hipMemcpyAsync(out, d_out.ptr, (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));
-    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    d_out.release();
-    return TLS_OK;
+    if (rc == TLS_OK) {
+        ctx->executed = true;
+        hipError_t e = hipMemcpyAsync(out, d_out.ptr, (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, TLS_E_HIP, hipGetErrorString(e));
+    }
+    if (rc != TLS_OK) (void)hipStreamSynchronize(ctx->stream);
+    d_out.release();   // (on every path)
+    return rc;
 }
 
 int tls_debug_prefix(tls_ctx* ctx, double* out, int64_t capacity, int64_t* row_length) {
@@ -1185,12 +1190,15 @@ int tls_debug_prefix(tls_ctx* ctx, double* out, int64_t capacity, int64_t* row_l
     DevBuf<double> d_out;
     TLS_HIP(ctx, d_out.reserve((size_t)need));
     int rc = enqueue(ctx, false, false, nullptr, d_out.ptr);
-    if (rc) { d_out.release(); return rc; }
-    ctx->executed = true;
-    TLS_HIP(ctx, hipMemcpyAsync(out, d_out.ptr, (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream));
-    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    d_out.release();
-    return TLS_OK;
+    if (rc == TLS_OK) {
+        ctx->executed = true;
+        hipError_t e = hipMemcpyAsync(out, d_out.ptr, (size_t)need * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, TLS_E_HIP, hipGetErrorString(e));
+    }
+    if (rc != TLS_OK) (void)hipStreamSynchronize(ctx->stream);
+    d_out.release();   // (on every path)
+    return rc;
 }
 
 int tls_debug_period_cycles(tls_ctx* ctx, uint64_t* cycles, int64_t capacity) {
@@ -1430,7 +1438,11 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         return TLS_OK;
     };
     std::vector<double> w;
-    rc = TLS_OK;
+    // (every HIP failure inside the pipeline leaves through `run`'s return value: the cleanup below then waits for
+    // both streams -- asynchronous copies may still target the pinned slots and the caller's arrays -- and clears
+    // the launch overrides)
+    auto run = [&]() -> int {
+    int rc = TLS_OK;
     for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
         auto& sl = ctx->slot[g & 1];
         const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
@@ -1475,10 +1487,16 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         TLS_HIP(ctx, hipMemcpyAsync(sl.h_out + 2 * (size_t)group * np, sl.d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
         TLS_HIP(ctx, hipEventRecord(sl.ev_out, ctx->copy_stream));
     }
-    if (rc == TLS_OK) {
+    if (rc == TLS_OK)
         for (int64_t g = std::max<int64_t>(0, n_groups - 2); g < n_groups && rc == TLS_OK; ++g) rc = drain(g);
-    } else {
+    return rc;
+    };
+    rc = run();
+    if (rc != TLS_OK) {
         (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->copy_stream);
+        ctx->batch_curves = 1;
+        ctx->over_y = ctx->over_w = ctx->over_S0 = ctx->over_w0 = nullptr;
+        ctx->over_chi2 = nullptr; ctx->over_row = nullptr; ctx->over_depth = nullptr;
     }
     // the context keeps the plan, but the search ran on the batch slots: a staged execute
     // must be preceded by tls_update_flux or a new tls_prepare
@@ -1722,7 +1740,7 @@ int tls_grid_cells(const double* t, int64_t n, const double* periods, int64_t n_
 
 int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t n_periods, const tls_template* tmpl,
                      const tls_params* params, double sigma, int64_t* cells_per_period, double* taps_per_period,
-                     double* time_per_period) {
+                     double* time_per_period, int64_t* workgroups_in_flight) {
     if (!t || !periods || !cells_per_period || !taps_per_period || n < 3 || n_periods < 0) {
         g_create_error = "tls_period_costs: invalid argument";
         return TLS_E_ARG;
@@ -1773,6 +1791,11 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         else { a0 = 56564.0; aN = 0.0; b = 0.3189; c = 0.1267; }                        // LDS-resident, one 1024-thread workgroup per CU (100 d)
         for (int64_t p = 0; p < n_periods; ++p)
             time_per_period[p] = a0 + aN * (double)n + b * (double)cells_per_period[p] + c * taps_per_period[p];
+        // periods searched side by side on one GPU (one workgroup each): 256 CUs, two workgroups per CU when two
+        // folded series fit its LDS.  A block of n periods takes ceil(n / this) rounds, not n / this.
+        if (workgroups_in_flight) *workgroups_in_flight = two_per_cu ? 512 : 256;
+    } else if (workgroups_in_flight) {
+        *workgroups_in_flight = 256;
     }
     return TLS_OK;
 }

@@ -56,5 +56,7 @@ def spectra(chi2, oversampling_factor, context=None, device=None, resident=False
         # (the reference indexes past the end of its window array for such a kernel, helpers.py:95-97)
         raise ValueError("oversampling_factor * %d must be an integer" % C.SDE_MEDIAN_KERNEL_SIZE)
     ctx = context if context is not None else default_context(device)
-    # resident: chi2 is exactly what the search that has just finished on this context left in HBM
-    return ctx.spectra(int(kernel), None if resident else chi2)
+    # resident: read the chi2 the search left in HBM -- but only if `chi2` IS the array that search's fetch returned
+    # and nothing has run on the context since (Context.holds); any other array (a patched search, an edited
+    # copy, a second search in between) is uploaded
+    return ctx.spectra(int(kernel), None if (resident and ctx.holds(chi2)) else chi2)

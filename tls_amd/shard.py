@@ -35,6 +35,57 @@ def partition_by_cost(costs, n_ranks):
     return numpy.asarray(bounds, dtype=numpy.int64)
 
 
+def block_makespan(times, slots):
+    """Time one GPU needs for a block of periods with the given modelled times when `slots` of them are searched
+    side by side, most expensive first (the kernel's work queue): the full rounds share their work evenly, the
+    last, partly filled round adds its most expensive period.  (A block of 307 periods on 256 workgroup slots takes
+    two rounds, not 1.2.)"""
+    n = len(times)
+    if n == 0:
+        return 0.0
+    c = numpy.sort(numpy.asarray(times, dtype=numpy.float64))[::-1]
+    rounds = -(-n // slots)
+    full = (rounds - 1) * slots
+    return float(numpy.sum(c[:full]) / slots + c[full])
+
+
+def partition_by_makespan(times, n_ranks, slots):
+    """Contiguous blocks whose block_makespan is as equal as a bisection on the target makes it; falls back to
+    equal summed time where blocks are many rounds long (the two agree there)."""
+    times = numpy.asarray(times, dtype=numpy.float64)
+    n = len(times)
+    if n_ranks <= 1 or n == 0:
+        return numpy.asarray([0] + [n] * max(n_ranks, 1), dtype=numpy.int64)[: n_ranks + 1]
+    if n >= 64 * slots * n_ranks:      # >= 64 rounds per rank: the last round is noise
+        return partition_by_cost(times, n_ranks)
+
+    def fill(target):
+        """Greedy: every block as long as its makespan stays <= target.  Returns the bounds (n reached or not)."""
+        bounds, lo = [0], 0
+        for _ in range(n_ranks):
+            a, b = lo, n                      # largest hi in [lo, n] with makespan(lo:hi) <= target
+            while a < b:
+                mid = (a + b + 1) // 2
+                if block_makespan(times[lo:mid], slots) <= target:
+                    a = mid
+                else:
+                    b = mid - 1
+            lo = a
+            bounds.append(lo)
+        return bounds
+
+    lo_t, hi_t = 0.0, block_makespan(times, slots)
+    for _ in range(40):
+        mid_t = 0.5 * (lo_t + hi_t)
+        if fill(mid_t)[-1] >= n:
+            hi_t = mid_t
+        else:
+            lo_t = mid_t
+    bounds = fill(hi_t)
+    bounds[-1] = n
+    return numpy.asarray(bounds, dtype=numpy.int64)
+
+
 def assemble(gathered, bounds, count_per_rank):
     """Undo the padding of an all-gather: `gathered` has n_ranks blocks of
     count_per_rank entries; block r carries bounds[r+1]-bounds[r] valid ones."""
@@ -78,8 +129,9 @@ class ShardedSearch(object):
         2.1x (TESS) and 4x (Kepler 4 yr) slower than the mean at 8 ranks (profiles/r03_cost_model_fit.json).
         y (the flux) only sets the noise level the tap estimate assumes; every rank must pass the same."""
         sigma = 0.0 if y is None else float(numpy.std(numpy.asarray(y, dtype=numpy.float64)))
-        self.costs, self.taps, self.times = _lib.period_costs(t, periods, table, params, sigma)
-        self.bounds = partition_by_cost(self.times, self.n_ranks)
+        self.costs, self.taps, self.times, self.slots = _lib.period_costs(t, periods, table, params, sigma, with_slots=True)
+        # (a rank's GPU searches `slots` periods side by side: what is balanced is the time of its LAST round's end)
+        self.bounds = partition_by_makespan(self.times, self.n_ranks, self.slots)
         self.count_per_rank = max(1, int(numpy.max(numpy.diff(self.bounds))))
         lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         return int(lo), int(hi)

@@ -113,6 +113,13 @@ def pink_noise(data, width):
     return numpy.cumsum(terms)[-1] / n_windows
 
 
+def spectra(chi2, oversampling_factor):
+    """SR, power_raw, power, SDE_raw, SDE (reference stats.py:105-132): evaluated on the device
+    (tls_amd.search.spectra -> tls_spectra); kept here so that the module reads like the reference's."""
+    from . import search as _search
+    return _search.spectra(chi2, oversampling_factor)
+
+
 def period_uncertainty(periods, power):
     """Half of the full width at half maximum of the highest power peak; inf if
     the peak touches either end of the grid (reference stats.py:80-102)."""

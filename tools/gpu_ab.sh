@@ -7,5 +7,5 @@ CFGS=${*:-tess_27d kepler_4yr/64}
 cd "$ROOT"; mkdir -p gpurun_out/ab_$NAME
 for rep in 1 2; do
   echo "== default"; timeout 300 python tools/gpu_phases.py $CFGS 2>&1 | cut -c1-700
-  echo "== $NAME"; TLS_AMD_LIB=$ROOT/tls_amd/libtls_amd_$NAME.so timeout 300 python tools/gpu_phases.py $CFGS 2>&1 | cut -c1-700
+  echo "== $NAME"; TLS_AMD_DEBUG=1 TLS_AMD_LIB=$ROOT/tls_amd/libtls_amd_$NAME.so timeout 300 python tools/gpu_phases.py $CFGS 2>&1 | cut -c1-700
 done | tee gpurun_out/ab_$NAME/phases.txt
