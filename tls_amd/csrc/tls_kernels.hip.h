@@ -475,6 +475,7 @@ struct SearchArgs {
     double eps_fast;            // fast mode: half-width of the undecided band around depth_min (depth_pass)
     double slack_unit;          // pruning: rounding allowance of window_bound per sample of a window
     int exact_prefix;           // != 0: every period in exact mode (developer switch TLS_EXACT_PREFIX=1, debug entries)
+    int fast_slab;              // != 0: fast mode also for a series in the HBM slab (the host's choice: few undecided windows)
     double S0;
     double w0;
     int n, W, M;            // points, patch length, n + W
@@ -2794,7 +2795,8 @@ tls_search_kernel(const SearchArgs a) {
         }
         int flag_slot = 1;   // the "undecided" flag of the attempt in flight: s_work[1] and s_work[2] take turns
         // exact mode: X = k - numpy.cumsum, bit for bit; fast mode: X = plain prefix sum of 1 - f (depth_pass)
-        const bool period_exact = !RESIDENT || retry_exact || a.exact_prefix != 0 || a.debug_prefix != nullptr;
+        const bool period_exact = (!RESIDENT && (a.fast_slab == 0 || a.sort3 != 0)) || retry_exact || a.exact_prefix != 0 ||
+                                  a.debug_prefix != nullptr;
         retry_exact = false;
         bool curve_exact = false;   // batches: this light curve again in exact mode (the permutation is kept: no new sort)
         if (work >= a.n_periods) {
@@ -2956,6 +2958,30 @@ tls_search_kernel(const SearchArgs a) {
                 }
                 lds_barrier();
                 pc.mark(26);
+                if (!exact_mode) {
+                    // fast mode (depth_pass): X[k+1] = X[k] + (1 - f[k]) as a plain scan, in place over the staged f
+                    double* wtot = reinterpret_cast<double*>(cumsum_scratch);
+                    int per = (len + nt - 1) / nt;
+                    if ((per & 1) == 0) per += 1;
+                    const int lo = tid * per < len ? tid * per : len;
+                    const int hi = lo + per < len ? lo + per : len;
+                    double local = 0.0;
+                    for (int k = lo; k < hi; ++k) local += 1.0 - buf[1 + k];
+                    const double incl = wave_inclusive_sum(local);
+                    if (lane == kWave - 1) wtot[wave] = incl;
+                    lds_barrier();
+                    double run = carry;
+                    for (int v = 0; v < wave; ++v) run += wtot[v];
+                    run += incl - local;
+                    for (int k = lo; k < hi; ++k) { const double e1 = 1.0 - buf[1 + k]; run += e1; buf[1 + k] = run; }
+                    if (tid == 0) buf[0] = carry;
+                    double total = carry;
+                    for (int v = 0; v < nw; ++v) total += wtot[v];
+                    carry = total;                                    // the same additions in every thread
+                    lds_barrier();
+                    pc.mark(5);
+                    copy_out_stream(regB + c0, buf, len + 1, tid);    // (buf holds X itself)
+                } else {
                 if (len <= 16 * nt) {
                     carry = exact_cumsum_round_call(lds_address(buf), len, carry, lds_address(cumsum_scratch),
                                                     (global_ptr<unsigned long long>)a.phase_cycles);
@@ -2964,6 +2990,7 @@ tls_search_kernel(const SearchArgs a) {
                 }
                 pc.mark(5);
                 copy_out_stream_x(regB + c0, buf, len + 1, tid, c0);   // the slab keeps X[k] = k - C[k]
+                }
                 lds_barrier();
                 pc.mark(27);
             }
@@ -3367,7 +3394,9 @@ tls_search_kernel(const SearchArgs a) {
                     const double ov = widths_c[k].overshoot, k_mono = widths_c[k].k_mono, var_q = widths_c[k].var_q;
                     const double sum_q2 = widths_c[k].sum_q2;
                     const const_screen_ptr scr = screens_c + k;
-                    const bool screened = RESIDENT && prunable && scr->valid != 0;
+                    // (the screen reads kSeg + 1 values of X per window through c_base: LDS when the series is resident or
+                    // the tile holds X beside the samples; not worth it from the HBM slab)
+                    const bool screened = (RESIDENT || STAGE_C) && prunable && scr->valid != 0;
                     const double slack = slack_unit * (double)(d + 64);
                     const int reach = tiled ? (kR - 1) * xth + d : d;   // samples covered by the windows of a unit
                     const int step = tiled ? kR * xth : xth;            // samples between two units
@@ -3552,7 +3581,7 @@ tls_search_kernel(const SearchArgs a) {
                         const double dX = c_base[i + d] - c_base[i];   // past the grid: sentinel
                         pass = depth_pass(dX, inv_d, dd, dmin, rule.eps, exact_mode, undecided);
                         if (bound_row && pass) {
-                            if (RESIDENT && screened_row)
+                            if ((RESIDENT || STAGE_C) && screened_row)
                                 pass = (double)window_bound(c_base, i, d, dd, inv_d, ov, widths_c[k].sum_q2, screens_c + k, P2,
                                                             a.p2_shift, p2_blocks, dmin, rule.eps, exact_mode, undecided,
                                                             slack_unit * (double)(d + 64)) >= T;
