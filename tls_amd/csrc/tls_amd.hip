@@ -545,6 +545,13 @@ bool plan_periods(const std::vector<tlsdev::WidthEntry>& widths, const tls_param
     return true;
 }
 
+// sort buckets of the general fold_and_sort for a series of n points (the resident kernel uses n; the slab variant
+// what its LDS holds): only the order of magnitude matters to the caller
+int64_t ctx_nb_for(int64_t n, size_t n_widths) {
+    const size_t hdr = ((size_t)tlsdev::kFixedHeader + 4 * (3 * n_widths + 2) + 15) / 16 * 16;
+    return std::min<int64_t>(n, (int64_t)((kLdsPerCU - hdr) / 4));
+}
+
 // work order of the period queue: most expensive first (longest-processing-time first), ties in grid order --
 // a stable LSD radix sort of the 32-bit key (max cost - cost), three passes of 11 bits
 void order_by_cost(const std::vector<int64_t>& cost, std::vector<int>& order) {
@@ -833,7 +840,31 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             return fail(ctx, TLS_E_ARG, "periods must be positive and finite");
         pc.grid_cells = gp.cells; pc.pd_pairs = gp.pairs;
     }
-    order_by_cost(cost, order);
+    // Work order: most expensive first.  A period commensurate with the cadence of a regularly sampled series piles
+    // the phases onto a few values and its sort costs several ordinary periods: such a period
+    // goes to the head of the queue, where its long run overlaps everything else instead of ending the launch.
+    {
+        std::vector<int64_t> queue_cost(cost);
+        bool regular = n >= 64;
+        double dt = 0.0;
+        if (regular) {
+            dt = (t[n - 1] - t[0]) / (double)(n - 1);
+            regular = dt > 0;
+            for (int64_t i = 1; i < n && regular; ++i) regular = std::fabs((t[i] - t[i - 1]) - dt) <= 1e-3 * dt;
+        }
+        if (regular) {
+            for (int64_t p = 0; p < n_periods; ++p) {
+                const double r = periods[p] / dt;                 // samples per period
+                for (int k = 1; k <= 4; ++k) {
+                    const double a = std::round(r * k);           // r ~ a / k: `a` distinct phase values
+                    if (a < 1 || (double)n / a < 48) continue;
+                    const double width = (double)n * std::fabs((double)k / a - 1.0 / r);   // phase range of one pile
+                    if (width * (double)ctx_nb_for(n, widths.size()) < 4.0) { queue_cost[(size_t)p] += 50 * cost[(size_t)p]; break; }
+                }
+            }
+        }
+        order_by_cost(queue_cost, order);
+    }
 
     // weights
     std::vector<double> w;
@@ -867,8 +898,10 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // tiles of `tile_len` window-start positions plus a halo of the widest window
         // sort histogram: one bucket per point while the counters fit the LDS (fewer points per
         // bucket = fewer comparisons in the in-bucket ranking)
-        // (capped: the LDS behind the counters stages piled-up buckets for the workgroup sort, fold_and_sort)
-        ctx->nb = (int)std::min<int64_t>(std::min<int64_t>(n, 16384), (int64_t)((kLdsPerCU - hdr) / 4));
+        // (as fine as the LDS allows: a NEARLY commensurate period spreads its piles over neighbouring buckets, and fine
+        // buckets keep them below the size from which the counting rank is left; what LDS remains behind the counters
+        // stages piled-up buckets for the workgroup sort, fold_and_sort)
+        ctx->nb = (int)std::min<int64_t>(n, (int64_t)((kLdsPerCU - hdr) / 4));
         size_t halo = (size_t)W + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
         const size_t unit = (size_t)tlsdev::kR * tlsdev::kWave;  // tile bounds: multiples of 320
         {

@@ -1781,7 +1781,11 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
     const int tid = threadIdx.x, nt = blockDim.x;
     const double nb_d = (double)nb;
     for (int b = tid; b < nb; b += nt) cnt[b] = 0;
-    if (tid == 0 && big_cap > 0) big_list[0] = 0u;   // [0]: number of big buckets, [1..]: their first slots
+    // [0]: number of big buckets, then (first slot, size) pairs -- the size is recorded by the registering thread from
+    // the LDS counters, so that every thread of the workgroup takes the same branches on it below (a size re-derived
+    // from idx_tmp in global memory while other waves reorder that segment need not be the same for every reader)
+    if (tid == 0 && big_cap > 0) big_list[0] = 0u;
+    const int list_slots = (big_cap - 1) / 2;
     __syncthreads();
     for (int i = tid; i < n; i += nt) {
         double ph = fold_phase(t[i], period, epoch);
@@ -1812,7 +1816,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
             bool listed = true;
             if (s == lo) {
                 const unsigned int at = atomicAdd(&big_list[0], 1u);
-                if (at < (unsigned int)(big_cap - 1)) big_list[1 + at] = (unsigned int)lo;
+                if (at < (unsigned int)list_slots) { big_list[1 + 2 * at] = (unsigned int)lo; big_list[2 + 2 * at] = (unsigned int)(hi - lo); }
             }
             (void)listed;
             continue;
@@ -1828,21 +1832,20 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
     __syncthreads();
     if (big_cap > 0) {
         const int n_big_all = (int)big_list[0];
-        const int n_big = n_big_all < big_cap - 1 ? n_big_all : big_cap - 1;
-        auto bucket_size = [&](int lo) { return (int)cnt[bucket_of(ph_orig[(int)idx_tmp[lo]], nb_d, nb)] - lo; };
+        const int n_big = n_big_all < list_slots ? n_big_all : list_slots;
         if (stage_cap == 0) {
             // everything is in LDS already (resident series): buckets of moderate size go one to a wave, the waves side
             // by side, sorted in place through the index; larger ones afterwards by the whole workgroup
             const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave)), n_waves = nt / kWave;
             for (int q = wave_id; q < n_big; q += n_waves) {
-                const int lo = __builtin_amdgcn_readfirstlane((int)big_list[1 + q]);
-                const int m = __builtin_amdgcn_readfirstlane(bucket_size(lo));
+                const int lo = __builtin_amdgcn_readfirstlane((int)big_list[1 + 2 * q]);
+                const int m = __builtin_amdgcn_readfirstlane((int)big_list[2 + 2 * q]);
                 if (m <= kWaveSortMax) sort_big_bucket<IdxT, false, true>(ph_orig, idx_tmp + lo, m, nullptr, nullptr, perm + lo);
             }
             __syncthreads();
             for (int q = 0; q < n_big; ++q) {
-                const int lo = (int)big_list[1 + q];
-                const int m = bucket_size(lo);
+                const int lo = (int)big_list[1 + 2 * q];
+                const int m = (int)big_list[2 + 2 * q];
                 if (m > kWaveSortMax) sort_big_bucket<IdxT, false, false>(ph_orig, idx_tmp + lo, m, nullptr, nullptr, perm + lo);
             }
         } else {
@@ -1854,8 +1857,8 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
                 // (uniform: every thread walks the same list)
                 int lo_b[16], m_b[16], off_b[16];
                 while (q0 + count < n_big && count < 16) {
-                    const int lo = (int)big_list[1 + q0 + count];
-                    const int m = bucket_size(lo);
+                    const int lo = (int)big_list[1 + 2 * (q0 + count)];
+                    const int m = (int)big_list[2 + 2 * (q0 + count)];
                     if (m > stage_cap) break;                     // does not fit at all: alone, below
                     if (used + m > stage_cap) break;
                     lo_b[count] = lo; m_b[count] = m; off_b[count] = used; used += m;
@@ -1864,8 +1867,8 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
                     ++count;
                 }
                 if (count == 0) {   // a bucket larger than the staging area: in place, through global memory
-                    const int lo = (int)big_list[1 + q0];
-                    sort_big_bucket<IdxT, false, false>(ph_orig, idx_tmp + lo, bucket_size(lo), nullptr, nullptr, perm + lo);
+                    const int lo = (int)big_list[1 + 2 * q0];
+                    sort_big_bucket<IdxT, false, false>(ph_orig, idx_tmp + lo, (int)big_list[2 + 2 * q0], nullptr, nullptr, perm + lo);
                     ++q0;
                     continue;
                 }
@@ -1917,7 +1920,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
                 const int lo = b ? (int)cnt[b - 1] : 0, hi = (int)cnt[b];
                 if (hi - lo <= kBigBucket) continue;
                 bool in_list = false;
-                for (int q = 0; q < n_big; ++q) in_list |= (int)big_list[1 + q] == lo;
+                for (int q = 0; q < n_big; ++q) in_list |= (int)big_list[1 + 2 * q] == lo;
                 if (in_list) continue;
                 int rank = 0;
                 for (int s2 = lo; s2 < hi; ++s2) {
