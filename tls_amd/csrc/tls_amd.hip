@@ -952,22 +952,32 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // LDS tile stays `tile + halo` doubles; PeriodRows::pad carries the period's own tile length.
         {
             const size_t staged = tile + halo;
+            // (widths ascend and strides never decrease with them: the widest in-range window and the largest stride
+            // of a period are those of its last in-range row that is not oversize -- one table over k_hi, one look-up
+            // per period instead of a walk over its rows)
+            const size_t nw = widths.size();
+            std::vector<int> tile_for_khi(nw + 1, 0);
+            {
+                size_t wmax = 1; int stride_p = 1;
+                for (size_t k = 0; k < nw; ++k) {
+                    const auto& we = widths[k];
+                    if (!we.oversize) {
+                        wmax = std::max(wmax, (size_t)we.width);
+                        if (we.tiled) stride_p = std::max(stride_p, we.xth);
+                    }
+                    const size_t halo_p = wmax + (wmax & 1) + (size_t)(tlsdev::kR - 1) * (size_t)std::max(stride_p, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
+                    if (halo_p >= halo) continue;   // (0: the plan's tile length)
+                    const size_t cap_p = (staged - halo_p) / unit * unit;
+                    const size_t tiles_p = ((size_t)M + cap_p - 1) / cap_p;
+                    size_t tile_p = (((size_t)M + tiles_p - 1) / tiles_p + unit - 1) / unit * unit;
+                    if (tile_p > cap_p) tile_p = cap_p;
+                    if (tile_p > tile) tile_for_khi[k + 1] = (int)tile_p;
+                }
+            }
             for (int64_t p = 0; p < n_periods; ++p) {
                 tlsdev::PeriodRows& pr = prow[(size_t)p];
-                size_t wmax = 1; int stride_p = 1;
-                for (int k = pr.k_lo; k < pr.k_hi; ++k) {
-                    const auto& we = widths[(size_t)k];
-                    if (we.oversize) continue;
-                    wmax = std::max(wmax, (size_t)we.width);
-                    if (we.tiled) stride_p = std::max(stride_p, we.xth);
-                }
-                const size_t halo_p = wmax + (wmax & 1) + (size_t)(tlsdev::kR - 1) * (size_t)std::max(stride_p, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
-                if (halo_p >= halo) continue;   // (pad 0: the plan's tile length)
-                const size_t cap_p = (staged - halo_p) / unit * unit;
-                const size_t tiles_p = ((size_t)M + cap_p - 1) / cap_p;
-                size_t tile_p = (((size_t)M + tiles_p - 1) / tiles_p + unit - 1) / unit * unit;
-                if (tile_p > cap_p) tile_p = cap_p;
-                if (tile_p > tile) pr.pad = (int)tile_p;
+                // (the running maxima above start at row 0, the period's at k_lo: the same whenever the period has a row)
+                pr.pad = pr.k_hi > pr.k_lo ? tile_for_khi[(size_t)pr.k_hi] : 0;
             }
         }
         const size_t cumsum_bytes = 8 * (2 * (size_t)tlsdev::kCumsumChunk + 4);

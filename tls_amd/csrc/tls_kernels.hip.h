@@ -1578,7 +1578,7 @@ struct DepthRule {   // how the depth predicate is decided in this period (depth
 };
 __device__ __forceinline__ void consider(Best& best, double x_lo, double x_hi, int i, double inv_d,
                                          double dd, const DepthRule& rule, double overshoot, double A, double B,
-                                         int k, unsigned long long& n_eval, bool& undecided) {
+                                         int k, unsigned int& n_eval, bool& undecided) {
     const double dX = x_hi - x_lo;
     if (!depth_pass(dX, inv_d, dd, rule.dmin, rule.eps, rule.exact_mode, undecided)) return;
     n_eval += 1;
@@ -3031,7 +3031,8 @@ tls_search_kernel(const SearchArgs a) {
 
         Best best;
         best.stat = INFINITY; best.td = 0.0; best.k = 0x7fffffff; best.i = 0x7fffffff;
-        unsigned long long n_eval = 0, n_steps = 0;
+        unsigned int n_eval = 0;          // cells this lane evaluated in this period (32 bits: one add per window)
+        unsigned long long n_steps = 0;
         unsigned long long n_issued = 0;   // FMAs per lane of this wave's dot products (wave-uniform)
         bool p2_ready = false;
         // ---- phase 3 runs over TILES of window-start positions [p_lo, p_hi).  Resident variant:
@@ -3487,7 +3488,7 @@ tls_search_kernel(const SearchArgs a) {
                 for (int r = 0; r < kR; ++r) { const double v = lane_value(Bc[r], 0); if (lane == r) Bmine = v; }
                 if (lane < n_win) {
                     const int i = i0 + lane * xth;
-                    unsigned long long ignored = 0;
+                    unsigned int ignored = 0;
                     consider(trial, c_base[i], c_base[i + d], i, inv_d, (double)d, rule, overshoot, sum_q2, Bmine, ck, ignored, undecided);
                 }
             }
@@ -3663,7 +3664,7 @@ tls_search_kernel(const SearchArgs a) {
                 // re-listed rows keep their positions behind the chunk entries
                 const int unit = have ? (int)active_list[list_base + (n_singles ? n_live : 0) + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
-                const unsigned long long evals_before = n_eval;
+                const unsigned int evals_before = n_eval;
                 if (a.counters) {   // what the loops below issue per lane, padding and idle lanes included
                     const int reach = (tiled && n_singles == 0) ? (kR - 1) * xth : 0;
                     n_issued += (unsigned long long)((L + reach + kU - 1) / kU * kU) * (reach ? kR : 1) * (UNIFORM_W ? 1 : 2);
@@ -3742,7 +3743,7 @@ tls_search_kernel(const SearchArgs a) {
                             const int i = unit * xth;
                             consider(best, regB[i], regB[i + d], i, inv_d, dd, rule, overshoot, myA, myB, k, n_eval, undecided);
                         }
-                        n_steps += (n_eval - evals_before) * (unsigned long long)L;
+                        n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
                         continue;
                     }
                     const int i = unit * xth;
@@ -3778,7 +3779,7 @@ tls_search_kernel(const SearchArgs a) {
                     }
                     if (have) consider(best, c_base[i], c_base[i + d], i, inv_d, dd, rule, overshoot, A0 + A1, B0 + B1, k, n_eval, undecided);
                 }
-                n_steps += (n_eval - evals_before) * (unsigned long long)L;
+                n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
             }
         }
         pc.mark(7);
@@ -3836,11 +3837,11 @@ tls_search_kernel(const SearchArgs a) {
         if (a.counters) {
 #pragma unroll
             for (int delta = kWave / 2; delta > 0; delta >>= 1) {
-                n_eval += __shfl_down(n_eval, delta, kWave);
+                n_eval += __shfl_down(n_eval, delta, kWave);     // (a wave's cells of one period: far below 2^32)
                 n_steps += __shfl_down(n_steps, delta, kWave);
             }
             if (lane == 0 && n_eval) {
-                atomicAdd(&a.counters[0], n_eval);
+                atomicAdd(&a.counters[0], (unsigned long long)n_eval);
                 atomicAdd(&a.counters[1], n_steps);
             }
             if (lane == 0 && n_issued) atomicAdd(&a.counters[2], n_issued * kWave);
