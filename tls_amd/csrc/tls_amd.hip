@@ -153,6 +153,7 @@ struct tls_ctx {
     bool uniform_w = true, resident = true;
     int n = 0, W = 0, M = 0, n_periods = 0, n_widths = 0, nb = 0;
     int threads = 512, blocks = 0;
+    int cumsum_round = 2 * tlsdev::kCumsumChunk;
     size_t lds_bytes = 0;
     double S0 = 0, w0 = 1, depth_min = 0;
     double y_abs_max = 1.0;   // largest |flux| of the light curve(s) of the next launch: bounds the prefix sum (fast mode's eps)
@@ -209,7 +210,7 @@ int stage_reserve(tls_ctx* ctx, size_t bytes) {
 
 std::string plan_env() {   // developer switches that change the plan
     std::string e;
-    for (const char* name : {"TLS_PRUNE", "TLS_PRUNE_MIN_LIVE", "TLS_SORT2", "TLS_SORT3", "TLS_THREADS", "TLS_BLOCKS", "TLS_STAGE_C"}) {
+    for (const char* name : {"TLS_PRUNE", "TLS_PRUNE_MIN_LIVE", "TLS_SORT2", "TLS_SORT3", "TLS_THREADS", "TLS_BLOCKS", "TLS_STAGE_C", "TLS_SLAB_WGS"}) {
         const char* v = std::getenv(name);
         e += v ? v : "-";
         e += '|';
@@ -633,6 +634,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.chunk_lists = ctx->d_lists.ptr; a.list_stride = 3 * (long long)ctx->list_stride; a.list_cap = (long long)ctx->list_stride;
     a.prune_min_live = ctx->prune_min_live; a.p2_shift = ctx->p2_shift; a.hdr_bytes = ctx->hdr_bytes; a.tile_len = ctx->tile_len; a.tile_halo = ctx->tile_halo;
     a.depth_min = ctx->depth_min; a.S0 = ctx->S0; a.w0 = ctx->w0;
+    a.cumsum_round = ctx->cumsum_round;
     {
         // the sequential cumsum C of the reference (helpers.py:72) rounds by at most half an ulp of its running value
         // per step, and C <= (n + W) * max|flux|: the two constants below follow from that (tls_kernels.hip.h,
@@ -901,7 +903,12 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // (as fine as the LDS allows: a NEARLY commensurate period spreads its piles over neighbouring buckets, and fine
         // buckets keep them below the size from which the counting rank is left; what LDS remains behind the counters
         // stages piled-up buckets for the workgroup sort, fold_and_sort)
-        ctx->nb = (int)std::min<int64_t>(n, (int64_t)((kLdsPerCU - hdr) / 4));
+        // Workgroups per CU of the slab variant: one 1024-thread workgroup with all of the LDS, or (TLS_SLAB_WGS=2, measured
+        // below) two 512-thread ones with half each, so that one period's latency-bound phases overlap another's arithmetic.
+        int slab_wgs = 1;
+        if (const char* env = std::getenv("TLS_SLAB_WGS")) slab_wgs = std::atoi(env) == 2 ? 2 : 1;
+        const size_t lds_budget = kLdsPerCU / (size_t)slab_wgs;
+        ctx->nb = (int)std::min<int64_t>(n, (int64_t)((lds_budget - hdr) / 4));
         size_t halo = (size_t)W + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
         const size_t unit = (size_t)tlsdev::kR * tlsdev::kWave;  // tile bounds: multiples of 320
         {
@@ -910,7 +917,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             // widely strided) trial positions are listed and evaluated straight from the slab, one window per
             // wavefront, and the tile halo only has to cover the other rows.  The reference has no size
             // limit (core.py:96-188).
-            const size_t cap1 = (kLdsPerCU - hdr) / 8 / ((uniform ? 1 : 2));
+            const size_t cap1 = (lds_budget - hdr) / 8 / ((uniform ? 1 : 2));
             if (cap1 < halo + 4 * unit) {
                 const size_t halo_cap = cap1 / 2;
                 size_t widest_fit = 1;
@@ -931,7 +938,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // tiles (TESS: 2 instead of 3, -8 %; Kepler-size: 7 instead of 82, most of a tile is halo)
         const size_t buffers_c = (uniform ? 1 : 2) + 1, buffers_noc = buffers_c - 1;
         auto tiles_for = [&](size_t buffers) -> size_t {
-            const size_t cap = (kLdsPerCU - hdr) / 8 / buffers;
+            const size_t cap = (lds_budget - hdr) / 8 / buffers;
             if (cap < halo + unit) return 0;  // does not fit
             const size_t cap_tile = (cap - halo) / unit * unit;
             return ((size_t)M + cap_tile - 1) / cap_tile;
@@ -941,7 +948,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         ctx->stage_c = tiles_c != 0 && tiles_c <= tiles_noc;
         if (const char* env = std::getenv("TLS_STAGE_C")) ctx->stage_c = tiles_c != 0 && std::atoi(env) != 0;   // A/B switch
         const size_t buffers = ctx->stage_c ? buffers_c : buffers_noc;
-        const size_t cap_doubles = (kLdsPerCU - hdr) / 8 / buffers;
+        const size_t cap_doubles = (lds_budget - hdr) / 8 / buffers;
         const size_t cap_tile = (cap_doubles - halo) / unit * unit;
         const size_t n_tiles = ((size_t)M + cap_tile - 1) / cap_tile;
         size_t tile = (((size_t)M + n_tiles - 1) / n_tiles + unit - 1) / unit * unit;
@@ -980,18 +987,19 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
                 pr.pad = pr.k_hi > pr.k_lo ? tile_for_khi[(size_t)pr.k_hi] : 0;
             }
         }
-        const size_t cumsum_bytes = 8 * (2 * (size_t)tlsdev::kCumsumChunk + 4);
+        ctx->cumsum_round = 2 * tlsdev::kCumsumChunk / slab_wgs;
+        const size_t cumsum_bytes = 8 * ((size_t)ctx->cumsum_round + 4);
         ctx->lds_bytes = hdr + std::max<size_t>(std::max<size_t>(4 * (size_t)ctx->nb, cumsum_bytes),
                                                 buffers * 8 * (tile + halo));
-        ctx->threads = 1024;
+        ctx->threads = slab_wgs == 2 ? 512 : 1024;
         if (const char* env = std::getenv("TLS_THREADS")) ctx->threads = std::max(64, std::min(1024, std::atoi(env) / 64 * 64));   // developer switch
-        ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)ctx->n_cu);
+        ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)ctx->n_cu * slab_wgs);
         if (const char* env = std::getenv("TLS_BLOCKS"))   // developer switch: workgroups in flight (memory-system experiments)
             ctx->blocks = std::max(1, std::min(ctx->blocks, std::atoi(env)));
         // two-level sort with sequential HBM accesses (fold_and_sort_tiled) when its LDS windows fit
-        const size_t sort2_bytes = hdr + (size_t)tlsdev::sort2_lds_bytes((int)n);
+        const size_t sort2_bytes = hdr + (size_t)tlsdev::sort2_lds_bytes((int)n, ctx->threads);
         const char* env_sort2 = std::getenv("TLS_SORT2");
-        ctx->sort2 = sort2_bytes <= kLdsPerCU && !(env_sort2 && std::atoi(env_sort2) == 0);
+        ctx->sort2 = sort2_bytes <= lds_budget && !(env_sort2 && std::atoi(env_sort2) == 0);
         if (ctx->sort2) ctx->lds_bytes = std::max(ctx->lds_bytes, sort2_bytes);
         // one light curve per launch: partition into large phase bins, per-bin LDS sort fused with the prefix sum
         const size_t sort3_bytes = hdr + (size_t)tlsdev::sort3_lds_bytes();
@@ -1000,7 +1008,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // period -- but 32 % more kernel time, its 23 bin rounds of eleven barriers each cost more than the
         // gather they avoid; on the TESS-size series 15 % slower.  The two-level sort stays the default,
         // TLS_SORT3=1 selects this path; both are tested.)
-        ctx->sort3 = sort3_bytes <= kLdsPerCU && tlsdev::sort3_bins((int)n) <= tlsdev::kSort3MaxBins && (int64_t)W <= n &&
+        ctx->sort3 = sort3_bytes <= lds_budget && tlsdev::sort3_bins((int)n) <= tlsdev::kSort3MaxBins && (int64_t)W <= n &&
                      (env_sort3 ? std::atoi(env_sort3) != 0 : false);
         if (ctx->sort3) {
             ctx->lds_bytes = std::max(ctx->lds_bytes, sort3_bytes);

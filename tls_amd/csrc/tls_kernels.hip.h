@@ -475,6 +475,7 @@ struct SearchArgs {
     double eps_fast;            // fast mode: half-width of the undecided band around depth_min (depth_pass)
     double slack_unit;          // pruning: rounding allowance of window_bound per sample of a window
     int exact_prefix;           // != 0: every period in exact mode (developer switch TLS_EXACT_PREFIX=1, debug entries)
+    int cumsum_round;           // slab variant: elements the prefix sum takes through LDS per round
     int fast_slab;              // != 0: fast mode also for a series in the HBM slab (the host's choice: few undecided windows)
     double S0;
     double w0;
@@ -1975,11 +1976,12 @@ constexpr int kSort2MaxBins = 1024;
 __host__ __device__ constexpr int sort2_bins(int n) {
     return (n + kSort2BinMean - 1) / kSort2BinMean < kSort2MaxBins ? (n + kSort2BinMean - 1) / kSort2BinMean : kSort2MaxBins;
 }
-__host__ __device__ constexpr long long sort2_lds_bytes(int n) {
+__host__ __device__ constexpr long long sort2_lds_bytes(int n, int threads = 1024) {
     // counters (4 arrays of bins+1 words) + the larger of the pass-1 staging and the pass-2 windows
     const long long counters = 4LL * 4 * (sort2_bins(n) + 1);
-    const long long stage = 10LL * kSort2Chunk;                                      // record (u64) + bin (u16) per point
-    const long long windows = (long long)kMaxWaves * ((8 + 4) * kSort2BinCap + 16);  // record, counter (+ end)
+    const long long chunk = (long long)(kSort2Chunk / 1024) * threads < kSort2Chunk ? (long long)(kSort2Chunk / 1024) * threads : kSort2Chunk;
+    const long long stage = 10LL * chunk;                                            // record (u64) + bin (u16) per point
+    const long long windows = (long long)(threads / kWave) * ((8 + 4) * kSort2BinCap + 16);  // record, counter (+ end)
     return (counters + 15) / 16 * 16 + (stage > windows ? stage : windows);
 }
 
@@ -2051,9 +2053,9 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
     // ---- pass 1: partition, one chunk of points per round ---------------------------------------
     {
         unsigned long long* st_rec = reinterpret_cast<unsigned long long*>(area);
-        unsigned short* st_bin = reinterpret_cast<unsigned short*>(st_rec + kSort2Chunk);
         constexpr int kPer = kSort2Chunk / 1024;   // points per thread and round (1024-thread workgroups)
         const int chunk = kPer * nt < kSort2Chunk ? kPer * nt : kSort2Chunk;
+        unsigned short* st_bin = reinterpret_cast<unsigned short*>(st_rec + chunk);
         for (int c0 = 0; c0 < n; c0 += chunk) {
             const int cn = n - c0 < chunk ? n - c0 : chunk;
             double ph[kPer];
@@ -2942,7 +2944,7 @@ tls_search_kernel(const SearchArgs a) {
             // (C[k+1] over f[k]); the patch (core.py:126: the first W samples again) is an index mapping
             // of the copy-in; LDS-only barriers, so the prefix-sum stores of a round stay in flight
             double* buf = reinterpret_cast<double*>(smem + a.hdr_bytes) + 1;   // C[0..len], f = buf + 1 (16-byte aligned)
-            constexpr int kRound = 2 * kCumsumChunk;
+            const int kRound = a.cumsum_round;   // elements per LDS round (the host sizes it to the workgroup's LDS share)
             double carry = 0.0;
             const bool dma = TLS_SLAB_DMA && (n & 1) == 0;   // pairs of samples never straddle the patch boundary
             for (int c0 = 0; c0 < M; c0 += kRound) {
