@@ -1419,17 +1419,6 @@ __device__ __forceinline__ void prefix_sum_of_e(double* fe, const double* w, dou
 }
 
 // Depth predicate of one trial cell (core.py:58): mean = 1 - (C[i+d]-C[i])/d > depth_min.
-// The quotient is replaced by a multiplication (the two differ by < 3e-16); only a result
-// within 1e-15 of the threshold is re-decided with the exact quotient, so the decision is
-// exactly the reference's.  Returns +1 pass, 0 fail, -1 undecided (border).
-__device__ __forceinline__ int depth_class(double dC, double inv_d, double dmin) {
-    const double m_fast = fma(-dC, inv_d, 1.0);
-    return m_fast > dmin + 1e-15 ? 1 : (m_fast >= dmin - 1e-15 ? -1 : 0);
-}
-__device__ __forceinline__ bool depth_exact(double dC, double dd, double dmin) {
-    return (1.0 - dC / dd) > dmin;
-}
-
 // The kernels keep the prefix sum in the form  X[k] = k - C[k]  (the running sum of e = 1 - f): a window's
 // X[i+d] - X[i] = d - (C[i+d] - C[i]) is d times its mean depth.  Two ways to fill X:
 //   exact mode  C is the sequential fp64 cumsum, bit for bit numpy.cumsum (exact_cumsum), and X[k] = k - C[k]
