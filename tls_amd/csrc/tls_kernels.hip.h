@@ -102,7 +102,10 @@ constexpr int kPhases = 40;    // phase-clock slots 0..31 and work statistics 32
 #endif
 constexpr int kR = TLS_KR;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
 constexpr int kU = 8;          // template taps per unrolled iteration
-constexpr int kSparseRow = 40;      // rows with at most this many live chunks are re-listed position by position
+#ifndef TLS_SPARSE_ROW
+#define TLS_SPARSE_ROW 24
+#endif
+constexpr int kSparseRow = TLS_SPARSE_ROW;   // rows with at most this many live chunks are re-listed position by position
 constexpr int kMaxTiledStride = 5;  // T0 strides up to this have a dot product with compile-time tap offsets
 constexpr int kMaxRuntimeStride = 128;  // larger strides (only with a huge T0_fit_margin) go one window per lane
 // A row is "tiled" (kR windows per lane share every folded sample) when its stride is small
@@ -528,28 +531,22 @@ __device__ __forceinline__ Best shfl_down_best(const Best& v, int delta) {
     return o;
 }
 
-// Exclusive prefix sum of cnt[0..nb) in place; `wsum` is LDS scratch of kMaxWaves+1 words.
+// Exclusive prefix sum of cnt[0..nb) in place; `wsum` is LDS scratch of kMaxWaves+1 words.  Two barriers: every
+// thread adds up the totals of the waves in front of its own (broadcast reads), the wave scan runs on the DPP crossbar.
+__device__ __forceinline__ unsigned int wave_inclusive_sum_u32(unsigned int v);
 __device__ __forceinline__ void block_exclusive_scan(unsigned int* cnt, int nb, unsigned int* wsum) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int lane = tid & (kWave - 1), wave = tid / kWave, nw = nt / kWave;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int chunk = (nb + nt - 1) / nt;
     const int lo = tid * chunk, hi = min(lo + chunk, nb);
     unsigned int local = 0;
     for (int b = lo; b < hi; ++b) local += cnt[b];
-    unsigned int incl = local;  // inclusive scan across the wave
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        unsigned int o = __shfl_up(incl, d, kWave);
-        if (lane >= d) incl += o;
-    }
+    const unsigned int incl = wave_inclusive_sum_u32(local);
     if (lane == kWave - 1) wsum[wave] = incl;
     __syncthreads();
-    if (tid == 0) {
-        unsigned int run = 0;
-        for (int v = 0; v < nw; ++v) { unsigned int s = wsum[v]; wsum[v] = run; run += s; }
-    }
-    __syncthreads();
-    unsigned int run = wsum[wave] + incl - local;
+    unsigned int run = incl - local;
+    for (int v = 0; v < wave; ++v) run += wsum[v];
     for (int b = lo; b < hi; ++b) { unsigned int c = cnt[b]; cnt[b] = run; run += c; }
     __syncthreads();
 }
@@ -1812,10 +1809,12 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
             continue;
         }
         int rank = 0;
-        for (int s2 = lo; s2 < hi; ++s2) {
-            const int i2 = (int)idx_tmp[s2];
-            const double ph2 = ph_orig[i2];
-            rank += (ph2 < ph || (ph2 == ph && i2 < i)) ? 1 : 0;
+        if (hi - lo > 1) {   // (most buckets of a folded time series hold one point)
+            for (int s2 = lo; s2 < hi; ++s2) {
+                const int i2 = (int)idx_tmp[s2];
+                const double ph2 = ph_orig[i2];
+                rank += (ph2 < ph || (ph2 == ph && i2 < i)) ? 1 : 0;
+            }
         }
         perm[lo + rank] = (IdxT)i;
     }
@@ -3108,7 +3107,10 @@ tls_search_kernel(const SearchArgs a) {
                 // of one dependent atomic round trip per row.
                 unsigned long long row_mask = 0ull;
                 // kRowBatch durations per step: all LDS reads of the step are in flight together
-                constexpr int kRowBatch = 4;
+#ifndef TLS_ROW_BATCH
+#define TLS_ROW_BATCH 2
+#endif
+                constexpr int kRowBatch = TLS_ROW_BATCH;
                 for (int k = k_lo; k < k_x; k += kRowBatch) {
                     int dv[kRowBatch];
                     double inv[kRowBatch], dC[kRowBatch];
