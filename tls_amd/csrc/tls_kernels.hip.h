@@ -103,7 +103,7 @@ constexpr int kPhases = 40;    // phase-clock slots 0..31 and work statistics 32
 constexpr int kR = TLS_KR;          // T0 positions per lane in the sliding dot product (odd: no LDS conflicts)
 constexpr int kU = 8;          // template taps per unrolled iteration
 #ifndef TLS_SPARSE_ROW
-#define TLS_SPARSE_ROW 24
+#define TLS_SPARSE_ROW 16
 #endif
 constexpr int kSparseRow = TLS_SPARSE_ROW;   // rows with at most this many live chunks are re-listed position by position
 constexpr int kMaxTiledStride = 5;  // T0 strides up to this have a dot product with compile-time tap offsets
