@@ -105,6 +105,13 @@ constexpr int kU = 8;          // template taps per unrolled iteration
 #ifndef TLS_SPARSE_ROW
 #define TLS_SPARSE_ROW 16
 #endif
+#ifndef TLS_TAIL_RELIST
+#define TLS_TAIL_RELIST 1    // (LDS-resident series) a row's last, mostly empty batch of live chunks runs position by position
+#endif
+#ifndef TLS_TAIL_MAX
+#define TLS_TAIL_MAX 20      // ...when it holds at most this many chunks (and its live positions fit one batch)
+#endif
+constexpr int kTailMax = TLS_TAIL_MAX;
 constexpr int kSparseRow = TLS_SPARSE_ROW;   // rows with at most this many live chunks are re-listed position by position
 constexpr int kMaxTiledStride = 5;  // T0 strides up to this have a dot product with compile-time tap offsets
 constexpr int kMaxRuntimeStride = 128;  // larger strides (only with a huge T0_fit_margin) go one window per lane
@@ -3566,14 +3573,20 @@ tls_search_kernel(const SearchArgs a) {
             const double ov = widths_c[k].overshoot, k_mono = widths_c[k].k_mono, var_q = widths_c[k].var_q;
             unsigned int* list = active_list + list_base;
             unsigned int count = 0;
-            if (tiled && n_live > 0 && n_live <= kSparseRow && n_units >= (kR + 1) * kSparseRow) {
+            // which units are re-listed: all of a sparse row; of a longer row the LAST batch when it is mostly empty
+            // (it would run 64 lanes wide for a handful of units) -- kept only if its positions fit one batch
+            const bool sparse = n_live <= kSparseRow;
+            const int n_tail = sparse ? n_live : (TLS_TAIL_RELIST && RESIDENT ? (n_live & (kWave - 1)) : 0);
+            const int first = n_live - n_tail;
+            if (tiled && n_tail > 0 && n_tail <= kTailMax && n_units >= (kR + 1) * kSparseRow && first + n_tail * kR <= n_units) {
+                // the units travel in registers (lane j: unit first + j): their list slots take the positions
+                const unsigned int my_unit = lane < n_tail ? list[first + lane] : 0u;
 #pragma unroll 1
-                for (int base = 0; base < n_live * kR; base += kWave) {
+                for (int base = 0; base < n_tail * kR; base += kWave) {
                     const int idx = base + lane;
                     bool pass = false;
-                    int u = 0;
-                    if (idx < n_live * kR) {
-                        u = (int)list[idx / kR] * kR + idx % kR;   // T0 position index
+                    const int u = __shfl((int)my_unit, (idx / kR) & (kWave - 1), kWave) * kR + idx % kR;   // T0 position index
+                    if (idx < n_tail * kR) {
                         const int i = u * xth;
                         const double dX = c_base[i + d] - c_base[i];   // past the grid: sentinel
                         pass = depth_pass(dX, inv_d, dd, dmin, rule.eps, exact_mode, undecided);
@@ -3588,10 +3601,15 @@ tls_search_kernel(const SearchArgs a) {
                         }
                     }
                     const unsigned long long mask = __ballot(pass);
-                    if (pass) list[n_live + count + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)u;
+                    if (pass) list[first + count + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)u;
                     count += (unsigned int)__popcll(mask);
                 }
-                if (count == 0) n_live = 0;   // every window of every selected chunk was pruned
+                if (sparse || count <= (unsigned int)kWave) {
+                    n_live = first;   // (a sparse row whose every window was pruned has nothing left at all)
+                } else {          // more positions than one batch: the tail stays in chunk form
+                    if (lane < n_tail) list[first + lane] = my_unit;
+                    count = 0;
+                }
             }
             TLS_CHECK(a, (unsigned int)n_live + count <= (unsigned int)n_units, kChkSinglesCap);
             if (lane == 0) { rt.live[row] = (unsigned int)n_live; rt.singles[row] = count; }
@@ -3604,8 +3622,7 @@ tls_search_kernel(const SearchArgs a) {
                 const int row = r0 + lane;
                 unsigned int mine = 0;
                 if (row < n_rows) {
-                    const unsigned int units = rt.singles[row] ? rt.singles[row] : rt.live[row];
-                    mine = (units + kWave - 1) / kWave;
+                    mine = (rt.live[row] + kWave - 1) / kWave + (rt.singles[row] + kWave - 1) / kWave;
                 }
                 unsigned int incl = mine;
 #pragma unroll
@@ -3650,19 +3667,23 @@ tls_search_kernel(const SearchArgs a) {
                 const double overshoot = widths_c[k].overshoot, sum_q2 = widths_c[k].sum_q2;
                 const double inv_d = widths_c[k].inv_d, dd = (double)d;
                 const int tiled = widths_c[k].tiled;
-                const unsigned int slot = (gg - rt.batch_start[row]) * kWave + lane;
                 const int n_singles = __builtin_amdgcn_readfirstlane((int)rt.singles[row]);
                 const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
-                const bool have = slot < (unsigned int)(n_singles ? n_singles : n_live);
-                // re-listed rows keep their positions behind the chunk entries
-                const int unit = have ? (int)active_list[list_base + (n_singles ? n_live : 0) + slot] : 0;
+                // a row's batches: its chunks (or, strided rows, its positions) first, then its re-listed positions,
+                // which sit behind the chunk entries
+                const unsigned int in_row = gg - (unsigned int)__builtin_amdgcn_readfirstlane((int)rt.batch_start[row]);
+                const unsigned int chunk_batches = ((unsigned int)n_live + kWave - 1) / kWave;
+                const bool relisted = in_row >= chunk_batches;
+                const unsigned int slot = (relisted ? in_row - chunk_batches : in_row) * kWave + lane;
+                const bool have = slot < (unsigned int)(relisted ? n_singles : n_live);
+                const int unit = have ? (int)active_list[list_base + (relisted ? n_live : 0) + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
                 const unsigned int evals_before = n_eval;
                 if (a.counters) {   // what the loops below issue per lane, padding and idle lanes included
-                    const int reach = (tiled && n_singles == 0) ? (kR - 1) * xth : 0;
+                    const int reach = (tiled && !relisted) ? (kR - 1) * xth : 0;
                     n_issued += (unsigned long long)((L + reach + kU - 1) / kU * kU) * (reach ? kR : 1) * (UNIFORM_W ? 1 : 2);
                 }
-                if (tiled && n_singles == 0) {
+                if (tiled && !relisted) {
                     // kR windows per lane, xth samples apart
                     const int u0 = unit * kR;
                     const int b = u0 * xth;
