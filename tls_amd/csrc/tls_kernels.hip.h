@@ -276,6 +276,12 @@ __device__ __forceinline__ void vmem_wait_all() {
 #ifndef TLS_SLAB_DMA
 #define TLS_SLAB_DMA 1
 #endif
+#ifndef TLS_FOLD_DEPTH
+#define TLS_FOLD_DEPTH 3     // time stamps a thread folds per step
+#endif
+#ifndef TLS_RANK_BY_INDEX
+#define TLS_RANK_BY_INDEX 0  // 1: the ranking pass of the bucket sort walks the points in index order (measured: +-0.5 %)
+#endif
 #ifndef TLS_GATHER_DEPTH
 #define TLS_GATHER_DEPTH 3   // flux values a thread gathers per step (their L2 round trips overlap)
 #endif
@@ -516,11 +522,27 @@ __device__ __forceinline__ int bucket_of(double phase, double nb_d, int nb) {
 }
 
 struct Best {
-    double stat;  // rs * (rs*A - 2B), smaller is better; +inf = nothing evaluated
+    double stat;  // rs * (rs*A - 2B) as the reference computes it, smaller is better; +inf = nothing evaluated
     double td;    // target depth of that cell
     int k;        // index into widths
     int i;        // T0 sample index
 };
+// A lane's best cell WHILE a period is searched: what the reference's value is computed from (consider).  The cheap
+// estimate of the statistic orders the cells; settle_best turns the winner into a Best (one division per lane and
+// period instead of one per promising cell).
+struct Lead {
+    double stat;  // the estimate of rs * (rs*A - 2B); +inf = nothing evaluated
+    double dX;    // X[i+d] - X[i] of the cell
+    double B;     // its dot product sum q_j e_j w_j
+    double A;     // its sum q_j^2 w_j (per-point weights only; uniform weights: the row's constant)
+    int k;        // index into widths
+    int i;        // T0 sample index
+};
+__device__ __forceinline__ Lead no_lead() {
+    Lead l;
+    l.stat = INFINITY; l.dX = 0.0; l.B = 0.0; l.A = 0.0; l.k = 0x7fffffff; l.i = 0x7fffffff;
+    return l;
+}
 
 __device__ __forceinline__ bool better(const Best& a, const Best& b) {
     // strict '<' with first-visited-wins ties: ascending width, then ascending T0
@@ -1568,24 +1590,123 @@ __device__ __forceinline__ float unit_bound(const double* x, int b, int n_win, i
 // past the end of the T0 grid read the +huge sentinels behind C and fail the predicate.
 struct DepthRule {   // how the depth predicate is decided in this period (depth_pass)
     double dmin, eps;
+    double reach;        // relative band in which two cells' estimated statistics do not order them (consider)
     bool exact_mode;
 };
-__device__ __forceinline__ void consider(Best& best, double x_lo, double x_hi, int i, double inv_d,
-                                         double dd, const DepthRule& rule, double overshoot, double A, double B,
-                                         int k, unsigned int& n_eval, bool& undecided) {
-    const double dX = x_hi - x_lo;
-    if (!depth_pass(dX, inv_d, dd, rule.dmin, rule.eps, rule.exact_mode, undecided)) return;
-    n_eval += 1;
-    // cheap estimate first; the exact quotient only for cells that can beat the lane's best
-    const double rs_f = 2.0 * ((dX * inv_d) * overshoot);
-    const double stat_f = rs_f * (rs_f * A - 2.0 * B);
-    if (!(stat_f <= best.stat + 1e-9 * fabs(best.stat))) return;
+// The statistic of a cell as the reference computes it (core.py:61-69 on helpers.py:73's mean).
+__device__ __forceinline__ void exact_cell(double dX, double dd, double overshoot, double A, double B, double& stat, double& td) {
     const double mean = 1.0 - (dd - dX) / dd;   // helpers.py:73 + core.py:167; dd - dX is C[i+d] - C[i] (exact mode: its bits)
-    const double td = mean * overshoot;          // core.py:61
-    const double rs = 2.0 * td;                  // 1/(SIGNAL_DEPTH/td), core.py:62-63
-    Best c;
-    c.stat = rs * (rs * A - 2.0 * B); c.td = td; c.k = k; c.i = i;
-    if (better(c, best)) best = c;
+    td = mean * overshoot;                        // core.py:61
+    const double rs = 2.0 * td;                   // 1/(SIGNAL_DEPTH/td), core.py:62-63
+    stat = rs * (rs * A - 2.0 * B);
+}
+
+// One trial cell against the lane's best (core.py:58-74).  Cells are ordered by an ESTIMATE of the statistic (the mean
+// depth as dX/d instead of the reference's 1 - (d - dX)/d: the two differ by the rounding of a quotient near 1, about
+// 1e-16 absolute on the mean, i.e. below rule.reach / 4 relative on the statistic).  An estimate that is lower than the
+// best one by more than rule.reach (relative) belongs to a cell whose reference value is lower too; one that is higher by
+// more than that cannot win; in between (about one cell in 1e8) both cells are evaluated as the reference does and
+// compared with its tie rule.  Straight-line code otherwise: no division and no branch per cell.
+// KEEP_DX: the lead carries its dX; otherwise X stays addressable for the whole period (x_all: the series resident in
+// LDS) and dX is read again the one or two times it is needed -- two registers less through the whole search.
+template <bool UNIFORM_W, bool KEEP_DX>
+__device__ __forceinline__ void consider(Lead& best, double x_lo, double x_hi, int i, double inv_d,
+                                         double dd, const DepthRule& rule, double overshoot, double A, double B,
+                                         int k, unsigned int& n_eval, bool& undecided, const_width_ptr widths_c,
+                                         const double* x_all) {
+    const double dX = x_hi - x_lo;
+    const double m_fast = dX * inv_d;
+    bool live = m_fast > rule.dmin + rule.eps;                  // depth_pass, with its rare band out of line
+    if (!live && m_fast >= rule.dmin - rule.eps) {
+        if (rule.exact_mode) live = (1.0 - (dd - dX) / dd) > rule.dmin;
+        else undecided = true;
+    }
+    n_eval += live ? 1u : 0u;
+    const double rs_f = 2.0 * (m_fast * overshoot);
+    const double stat_f = rs_f * (rs_f * A - 2.0 * B);
+    const double reach = rule.reach * fabs(best.stat);
+    // (nothing evaluated yet: inf - inf is NaN and the comparison false, so the first live cell wins)
+    bool wins = live && !(stat_f >= best.stat - reach);
+    if (live && !wins && stat_f <= best.stat + reach) {
+        double s_new, td_new, s_old, td_old;
+        exact_cell(dX, dd, overshoot, A, B, s_new, td_new);
+        const double A_old = UNIFORM_W ? widths_c[best.k].sum_q2 : best.A;
+        const int d_old = widths_c[best.k].width;
+        const double dX_old = KEEP_DX ? best.dX : x_all[best.i + d_old] - x_all[best.i];
+        exact_cell(dX_old, (double)d_old, widths_c[best.k].overshoot, A_old, best.B, s_old, td_old);
+        // strict '<' with first-visited-wins ties: ascending width, then ascending T0
+        wins = s_new < s_old || (s_new == s_old && (k < best.k || (k == best.k && i < best.i)));
+    }
+    if (wins) {
+        best.stat = stat_f; best.B = B; best.k = k; best.i = i;
+        if constexpr (KEEP_DX) best.dX = dX;
+        if constexpr (!UNIFORM_W) best.A = A;
+    }
+}
+
+// R cells of one row at once (the kR windows of a chunk, or one window): consider()'s decisions in straight-line code
+// with selects -- and whatever consider() would settle out of line (a window inside the undecided band of the depth
+// predicate, two estimates within reach of each other) only raises `pending`; such a lane then takes all R cells through
+// consider() itself.  The result does not depend on the order in which cells meet the lead (every comparison is decided
+// by the reference's values whenever the estimates are close), and a cell that meets itself there ties and stays.
+// (X is read here, x[i0 + r*step] and x[i0 + r*step + d], and read AGAIN by a pending lane: nothing but the dot products
+// stays in registers for the rare case)
+template <bool UNIFORM_W, bool KEEP_DX, int R>
+__device__ __forceinline__ void consider_cells(Lead& best, const double* x, int i0, int step, int d,
+                                               double inv_d, double dd, const DepthRule& rule, double overshoot,
+                                               const double (&A)[R], const double (&B)[R], int k, unsigned int& n_eval,
+                                               bool& undecided, const_width_ptr widths_c, const double* x_all) {
+    const double hi = rule.dmin + rule.eps, lo = rule.dmin - rule.eps;
+    bool pending = false;
+    unsigned int n_fast = 0;
+    double x_lo[R], x_hi[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { x_lo[r] = x[i0 + r * step]; x_hi[r] = x[i0 + r * step + d]; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double dX = x_hi[r] - x_lo[r];
+        const double m_fast = dX * inv_d;
+        const bool live = m_fast > hi;
+        pending |= !live && m_fast >= lo;
+        n_fast += live ? 1u : 0u;
+        const double rs_f = 2.0 * (m_fast * overshoot);            // (the same expressions as consider)
+        const double stat_f = rs_f * (rs_f * A[r] - 2.0 * B[r]);
+        const double reach = rule.reach * fabs(best.stat);
+        const bool wins = live && !(stat_f >= best.stat - reach);
+        pending |= live && !wins && stat_f <= best.stat + reach;
+        best.stat = wins ? stat_f : best.stat;
+        best.B = wins ? B[r] : best.B;
+        best.k = wins ? k : best.k;
+        best.i = wins ? i0 + r * step : best.i;
+        if constexpr (KEEP_DX) best.dX = wins ? dX : best.dX;
+        if constexpr (!UNIFORM_W) best.A = wins ? A[r] : best.A;
+    }
+    if (pending) {
+        unsigned int n_slow = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double* xr = x + (i0 + r * step);
+            asm volatile("" : "+v"(xr));   // a second read, not a value kept from the first
+            consider<UNIFORM_W, KEEP_DX>(best, xr[0], xr[d], i0 + r * step, inv_d, dd, rule, overshoot, A[r], B[r], k, n_slow,
+                                         undecided, widths_c, x_all);
+        }
+        n_fast = n_slow;
+    }
+    n_eval += n_fast;
+}
+
+// The lane's best cell in the reference's numbers (before the lanes' candidates are compared with each other).
+template <bool UNIFORM_W, bool KEEP_DX>
+__device__ __forceinline__ Best settle_best(const Lead& lead, const_width_ptr widths_c, const double* x_all) {
+    Best b;
+    b.stat = INFINITY; b.td = 0.0; b.k = lead.k; b.i = lead.i;
+    if (lead.stat < INFINITY) {
+        const double A = UNIFORM_W ? widths_c[lead.k].sum_q2 : lead.A;
+        const int d = widths_c[lead.k].width;
+        const double dX = KEEP_DX ? lead.dX : x_all[lead.i + d] - x_all[lead.i];
+        exact_cell(dX, (double)d, widths_c[lead.k].overshoot, A, lead.B, b.stat, b.td);
+    }
+    return b;
 }
 
 // append the live lanes' units to the row's list (order inside a list is irrelevant)
@@ -1781,10 +1902,24 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
     if (tid == 0 && big_cap > 0) big_list[0] = 0u;
     const int list_slots = (big_cap - 1) / 2;
     __syncthreads();
-    for (int i = tid; i < n; i += nt) {
-        double ph = fold_phase(t[i], period, epoch);
-        ph_orig[i] = ph;
-        atomicAdd(&cnt[bucket_of(ph, nb_d, nb)], 1u);
+    {
+        // kF time stamps per step: their L2 round trips overlap (the compiler keeps a global load behind the LDS atomic
+        // of the step before it)
+        constexpr int kF = TLS_FOLD_DEPTH;
+        for (int i0 = tid; i0 < n; i0 += kF * nt) {
+            double tv[kF];
+#pragma unroll
+            for (int g = 0; g < kF; ++g) tv[g] = t[i0 + g * nt < n ? i0 + g * nt : i0];
+#pragma unroll
+            for (int g = 0; g < kF; ++g) {
+                const int i = i0 + g * nt;
+                if (i < n) {
+                    const double ph = fold_phase(tv[g], period, epoch);
+                    ph_orig[i] = ph;
+                    atomicAdd(&cnt[bucket_of(ph, nb_d, nb)], 1u);
+                }
+            }
+        }
     }
     __syncthreads();
     pc.mark(0);
@@ -1799,8 +1934,15 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
     pc.mark(2);
     // ...made deterministic here: rank by (phase, original index) inside the bucket.
     // cnt[b] now holds the END of bucket b.
+    // (a thread takes the points in index order: phase and bucket of a point come from a sequential read, only the
+    // bucket's bounds -- and, where a bucket holds several points, its members -- are dependent reads)
+#if TLS_RANK_BY_INDEX
+#pragma unroll 2
+    for (int i = tid; i < n; i += nt) {
+#else
     for (int s = tid; s < n; s += nt) {
         const int i = (int)idx_tmp[s];
+#endif
         const double ph = ph_orig[i];
         const int b = bucket_of(ph, nb_d, nb);
         const int lo = b ? (int)cnt[b - 1] : 0, hi = (int)cnt[b];
@@ -1808,7 +1950,11 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
             // piled-up phases: the bucket's first slot registers it for the workgroup sort below; if the list is
             // full (more than big_cap such buckets) the counting rank does it after all
             bool listed = true;
+#if TLS_RANK_BY_INDEX
+            if ((int)idx_tmp[lo] == i) {
+#else
             if (s == lo) {
+#endif
                 const unsigned int at = atomicAdd(&big_list[0], 1u);
                 if (at < (unsigned int)list_slots) { big_list[1 + 2 * at] = (unsigned int)lo; big_list[2 + 2 * at] = (unsigned int)(hi - lo); }
             }
@@ -2872,6 +3018,9 @@ tls_search_kernel(const SearchArgs a) {
         curve_exact = false;
         DepthRule rule;
         rule.dmin = a.depth_min; rule.eps = exact_mode ? 1e-15 : a.eps_fast; rule.exact_mode = exact_mode;
+        // (the estimate's mean depth is off by ~1e-16 absolute: negligible against transit_depth_min = 1e-5, the whole
+        // story for a transit_depth_min near zero -- then every cell takes the exact comparison)
+        rule.reach = (rule.dmin - rule.eps > 4e-15) ? fmin(fmax(1e-9, 4e-15 / (rule.dmin - rule.eps)), 1.0) : 1.0;
         bool undecided = false;
         const double* y_c = a.y + (long long)curve * n;
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  kG
@@ -3026,8 +3175,7 @@ tls_search_kernel(const SearchArgs a) {
         __syncthreads();
         pc.mark(8);
 
-        Best best;
-        best.stat = INFINITY; best.td = 0.0; best.k = 0x7fffffff; best.i = 0x7fffffff;
+        Lead lead = no_lead();
         unsigned int n_eval = 0;          // cells this lane evaluated in this period (32 bits: one add per window)
         unsigned long long n_steps = 0;
         unsigned long long n_issued = 0;   // FMAs per lane of this wave's dot products (wave-uniform)
@@ -3458,8 +3606,7 @@ tls_search_kernel(const SearchArgs a) {
             // The candidate's statistic only sets the threshold: its taps are summed in another order
             // than phase 3b uses, so it may differ from the reported value in the last bits.  The
             // cell itself survives the threshold and is evaluated again by 3b like any other.
-            Best trial;
-            trial.stat = INFINITY; trial.td = 0.0; trial.k = 0x7fffffff; trial.i = 0x7fffffff;
+            Lead trial = no_lead();
             if (ck < k_hi) {  // this wave has a candidate
                 const int d = widths_c[ck].width, L = widths_c[ck].q_len, xth = widths_c[ck].xth;
                 const int tiled = widths_c[ck].tiled, q_offset = widths_c[ck].q_offset;
@@ -3489,13 +3636,16 @@ tls_search_kernel(const SearchArgs a) {
                 if (lane < n_win) {
                     const int i = i0 + lane * xth;
                     unsigned int ignored = 0;
-                    consider(trial, c_base[i], c_base[i + d], i, inv_d, (double)d, rule, overshoot, sum_q2, Bmine, ck, ignored, undecided);
+                    consider<UNIFORM_W, !RESIDENT>(trial, c_base[i], c_base[i + d], i, inv_d, (double)d, rule, overshoot, sum_q2, Bmine, ck, ignored, undecided, widths_c, regB);
                 }
             }
             // (4) T = the best statistic any evaluated cell has reached (this and earlier tiles)
             // loosened by far more than the summation-order difference (1e-12 relative)
-            const double loose = trial.stat < 0.0 ? trial.stat * (1.0 - 1e-12) : trial.stat * (1.0 + 1e-12);
-            double mstat = fmin(best.stat, loose);   // best: cells evaluated by 3b in earlier tiles
+            // (both are ESTIMATES of the statistic, good to rule.reach / 4: consider)
+            const double slack = fmin(2.0 * rule.reach, 0.5);
+            const double loose = trial.stat < 0.0 ? trial.stat * (1.0 - slack) : trial.stat * (1.0 + slack);
+            const double mine = lead.stat < 0.0 ? lead.stat * (1.0 - slack) : lead.stat * (1.0 + slack);
+            double mstat = fmin(mine, loose);   // best: cells evaluated by 3b in earlier tiles
 #pragma unroll
             for (int delta = kWave / 2; delta > 0; delta >>= 1) mstat = fmin(mstat, __shfl_down(mstat, delta, kWave));
             if (lane == 0) wbest[wave].stat = mstat;   // wbest is idle until phase 4
@@ -3717,14 +3867,8 @@ tls_search_kernel(const SearchArgs a) {
                             default: dot_windows_weighted_rt<true>(e, wv, q, q2, Lr, xth, Bv, Av); break;
                         }
                     }
-                    if (have) {
-                        double cl[kR], ch[kR];
-#pragma unroll
-                        for (int r = 0; r < kR; ++r) { cl[r] = c_base[b + r * xth]; ch[r] = c_base[b + r * xth + d]; }
-#pragma unroll
-                        for (int r = 0; r < kR; ++r)
-                            consider(best, cl[r], ch[r], b + r * xth, inv_d, dd, rule, overshoot, Av[r], Bv[r], k, n_eval, undecided);
-                    }
+                    if (have)
+                        consider_cells<UNIFORM_W, !RESIDENT, kR>(lead, c_base, b, xth, d, inv_d, dd, rule, overshoot, Av, Bv, k, n_eval, undecided, widths_c, regB);
                 } else {
                     // wide T0 strides and re-listed sparse rows: one window per lane
                     if (!RESIDENT && widths_c[k].oversize) {
@@ -3755,7 +3899,7 @@ tls_search_kernel(const SearchArgs a) {
                         }
                         if (have) {
                             const int i = unit * xth;
-                            consider(best, regB[i], regB[i + d], i, inv_d, dd, rule, overshoot, myA, myB, k, n_eval, undecided);
+                            consider<UNIFORM_W, !RESIDENT>(lead, regB[i], regB[i + d], i, inv_d, dd, rule, overshoot, myA, myB, k, n_eval, undecided, widths_c, regB);
                         }
                         n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
                         continue;
@@ -3791,7 +3935,7 @@ tls_search_kernel(const SearchArgs a) {
                             for (int u = 0; u < kU; ++u) { B0 = fma(qs[u], x[u], B0); A0 = fma(ps[u], z[u], A0); }
                         }
                     }
-                    if (have) consider(best, c_base[i], c_base[i + d], i, inv_d, dd, rule, overshoot, A0 + A1, B0 + B1, k, n_eval, undecided);
+                    if (have) consider<UNIFORM_W, !RESIDENT>(lead, c_base[i], c_base[i + d], i, inv_d, dd, rule, overshoot, A0 + A1, B0 + B1, k, n_eval, undecided, widths_c, regB);
                 }
                 n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
             }
@@ -3816,6 +3960,7 @@ tls_search_kernel(const SearchArgs a) {
         pc.mark(21);
 
         // ---- phase 4: argmin over the workgroup --------------------------------------
+        Best best = settle_best<UNIFORM_W, !RESIDENT>(lead, widths_c, regB);
 #pragma unroll
         for (int delta = kWave / 2; delta > 0; delta >>= 1) {
             Best o = shfl_down_best(best, delta);
