@@ -135,6 +135,10 @@ typedef const __attribute__((address_space(4))) WidthEntry* const_width_ptr;
 struct PeriodRows;
 typedef const __attribute__((address_space(4))) PeriodRows* const_rows_ptr;
 
+// The lanes of the wave for which `pred` holds, as the compare that produced it left them in a scalar register pair
+// (HIP's __ballot goes through a 0/1 select and a second compare).
+__device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 // kU consecutive doubles from the folded series.  In LDS the reads are issued as eight
 // ds_read_b64: hipcc would pair them into ds_read2_b64, which moves half the bytes per LDS
 // cycle (MI355X_MICROARCH.md, LDS table: 128 vs 256 B/clk) -- and this loop lives on the LDS.
@@ -1020,12 +1024,12 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
                 bad_exp = (es ? es - 1023 : -1022) != my_m;
                 bad_lim = !(keep_end < my_lim);
             }
-            const unsigned long long bad = __ballot(bad_exp || bad_lim);
+            const unsigned long long bad = ballot64(bad_exp || bad_lim);
             int ok = n_proc, n_written = n_proc, fail_k = kb;
             double fail_s = 0.0;
             if (bad) {
                 const int jf = __ffsll((long long)bad) - 1;   // everything behind the first failure is void
-                const bool exp_failed = (__ballot(bad_exp) >> jf) & 1ull;
+                const bool exp_failed = (ballot64(bad_exp) >> jf) & 1ull;
                 ok = jf;
                 if (exp_failed) { n_written = jf; fail_k = lane_value(my_c, jf); fail_s = lane_value(keep_prev, jf); }
                 else { n_written = jf + 1; fail_k = lane_value(my_c, jf) + 1; fail_s = lane_value(keep_new, jf); }
@@ -1294,7 +1298,7 @@ __device__ __forceinline__ double exact_cumsum_block_inline(const double* f, dou
         for (int v = 0; v <= wave; ++v) {
             if (v == wave) S_wave = S;
             while (r < n_sp) {
-                const unsigned long long sel = __ballot(rank == r && lane < n_sp);
+                const unsigned long long sel = ballot64(rank == r && lane < n_sp);
                 const int j = __ffsll((long long)sel) - 1;
                 const unsigned int key = (unsigned int)lane_value((int)h_key, j);
                 if ((int)(key >> 11) != v) break;                              // key / (32 * 64): the owner wave
@@ -1337,7 +1341,7 @@ __device__ __forceinline__ double exact_cumsum_block_inline(const double* f, dou
     bool bad = lane < kWave - 1 && !(S_run == next_start);
     if (tid == 0) bad |= !(S_start == s0);
     if (lane == kWave - 1) cs->wendv[wave] = S_run;
-    const unsigned long long bad_lanes = __ballot(bad);
+    const unsigned long long bad_lanes = ballot64(bad);
     if (bad_lanes != 0ull && lane == 0) cs->fail = 1;
     cpc.mark(17);
     lds_barrier();                                                                          // 3 (LDS only: C in
@@ -1712,7 +1716,7 @@ __device__ __forceinline__ Best settle_best(const Lead& lead, const_width_ptr wi
 // append the live lanes' units to the row's list (order inside a list is irrelevant)
 __device__ __forceinline__ void push_live(bool live, unsigned int unit, unsigned int* live_count,
                                           unsigned int* list, int lane) {
-    const unsigned long long mask = __ballot(live);
+    const unsigned long long mask = ballot64(live);
     if (mask) {
         unsigned int base = 0;
         if (lane == 0) base = atomicAdd(live_count, (unsigned int)__popcll(mask));
@@ -2354,7 +2358,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 #pragma unroll
             for (int e = 0; e < kE; ++e) longest = len[e] > longest ? len[e] : longest;
             constexpr int kHalf = kE / 2;   // the batch of a step in two halves: fewer registers in flight
-            for (int sidx = 0; __ballot(sidx < longest) != 0ull; ++sidx) {
+            for (int sidx = 0; ballot64(sidx < longest) != 0ull; ++sidx) {
 #pragma unroll
                 for (int h = 0; h < kE; h += kHalf) {
                     if (h < e_used) {
@@ -2369,7 +2373,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                             rank[h + e] += (in && !same_key && rec2[e] < rec[h + e]) ? 1 : 0;
                             tie |= in && same_key && rec2[e] != rec[h + e];   // (its own entry aside)
                         }
-                        if (__ballot(tie) != 0ull) {
+                        if (ballot64(tie) != 0ull) {
                             // equal 32-bit keys (rare): the exact phases decide, then the index -- a stable sort
 #pragma unroll
                             for (int e = 0; e < kHalf; ++e) {
@@ -3244,6 +3248,8 @@ tls_search_kernel(const SearchArgs a) {
         // dense rows: a lane owns kR consecutive T0 positions and walks all durations with
         // C[u0..u0+kR) held in registers; the chunk is live if its smallest window sum passes
         // (the mean is monotone in the window sum, so min() decides exactly).
+        const bool exact_u = __builtin_amdgcn_readfirstlane((int)exact_mode) != 0;
+        const double thr_hi = rule.dmin + rule.eps, thr_lo = rule.dmin - rule.eps;
         if (k_x > k_lo) {
             const int units0 = widths_c[k_lo].n_chunks;  // the shortest width has the most positions
             const int unit_lo = p_lo / kR;               // tile bounds are multiples of kR * 64
@@ -3261,6 +3267,7 @@ tls_search_kernel(const SearchArgs a) {
                 // ALL rows are then reserved with one LDS atomic instruction (one lane per row) instead
                 // of one dependent atomic round trip per row.
                 unsigned long long row_mask = 0ull;
+                bool in_band = false;
                 // kRowBatch durations per step: all LDS reads of the step are in flight together
 #ifndef TLS_ROW_BATCH
 #define TLS_ROW_BATCH 2
@@ -3275,7 +3282,7 @@ tls_search_kernel(const SearchArgs a) {
                         const int kk = k + j < k_x ? k + j : k_x - 1;  // the tail repeats the last row
                         dv[j] = widths_c[kk].width;
                         inv[j] = widths_c[kk].inv_d;
-                        const int hi0 = u0 + dv[j] < M + 1 ? u0 + dv[j] : M + 1;  // past the grid: sentinels
+                        const int hi0 = min(u0 + dv[j], M + 1);  // past the grid: sentinels
                         TLS_CHECK(a, hi0 + kR - 1 <= M + region_pad && (RESIDENT || unit >= unit_hi || hi0 + kR - 1 < p_lo + a.tile_len + a.tile_halo), kChkPredicateRead);
 #pragma unroll
                         for (int r = 0; r < kR; ++r) c_hi[j][r] = c_base[hi0 + r];
@@ -3292,11 +3299,17 @@ tls_search_kernel(const SearchArgs a) {
                         if (k + j < k_x) {
                             // (a lane past the row's units reads sentinels or foreign cells: it is masked below and
                             // must not raise `undecided`)
-                            bool und_j = false;
-                            const bool live = depth_pass(dC[j], inv[j], (double)dv[j], dmin, rule.eps, exact_mode, und_j);
-                            undecided |= und_j && unit < unit_hi;
+                            bool live;
+                            if (exact_u) {   // (a scalar branch: the whole workgroup is in one mode)
+                                bool und_j = false;
+                                live = depth_pass(dC[j], inv[j], (double)dv[j], dmin, rule.eps, true, und_j);
+                            } else {         // fast mode: no branch per row; a chunk inside the band is noted for the tile
+                                const double m_fast = dC[j] * inv[j];
+                                live = m_fast > thr_hi;
+                                in_band |= !live && m_fast >= thr_lo;
+                            }
                             if (n_dense <= kWave) {
-                                const unsigned long long mask = __ballot(live && unit < unit_hi);
+                                const unsigned long long mask = ballot64(live && unit < unit_hi);
                                 if (lane == k + j - k_lo) row_mask = mask;
                             } else {   // more dense rows than lanes (never with the default duration grid)
                                 push_live(live && unit < unit_hi, (unsigned int)unit, &rt.live[k + j - k_lo],
@@ -3305,11 +3318,12 @@ tls_search_kernel(const SearchArgs a) {
                         }
                     }
                 }
+                undecided |= in_band && unit < unit_hi;
                 if (n_dense <= kWave) {
                     unsigned int base = 0;
                     const unsigned int mine = (unsigned int)__popcll(row_mask);
                     if (mine) base = atomicAdd(&rt.live[lane], mine);      // lane j: row k_lo + j
-                    const unsigned long long rows_hit = __ballot(mine != 0u);
+                    const unsigned long long rows_hit = ballot64(mine != 0u);
                     const unsigned long long below = (1ull << lane) - 1ull;
                     for (unsigned long long left = rows_hit; left; left &= left - 1ull) {
                         const int j = __ffsll((long long)left) - 1;
@@ -3354,11 +3368,17 @@ tls_search_kernel(const SearchArgs a) {
                     double dC = c_hi[0] - c_lo[0];
 #pragma unroll
                     for (int r = 1; r < kR; ++r) dC = fmax(dC, c_hi[r] - c_lo[r]);
-                    bool und_u = false;
-                    bool live = depth_pass(dC, inv_d, (double)d, dmin, rule.eps, exact_mode, und_u);
-                    undecided |= und_u && unit < unit_hi;
+                    bool live;
+                    if (exact_u) {
+                        bool und_u = false;
+                        live = depth_pass(dC, inv_d, (double)d, dmin, rule.eps, true, und_u);
+                    } else {
+                        const double m_fast = dC * inv_d;
+                        live = m_fast > thr_hi;
+                        undecided |= !live && m_fast >= thr_lo && unit < unit_hi;
+                    }
                     live = live && unit < unit_hi;
-                    const unsigned long long mask = __ballot(live);
+                    const unsigned long long mask = ballot64(live);
                     if (live) list[n_listed + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
                     n_listed += (unsigned int)__popcll(mask);
                 }
@@ -3375,7 +3395,7 @@ tls_search_kernel(const SearchArgs a) {
                         else dC = c_base[i + d] - c_base[i];
                         live = depth_pass(dC, inv_d, (double)d, dmin, rule.eps, exact_mode, undecided);
                     }
-                    const unsigned long long mask = __ballot(live);
+                    const unsigned long long mask = ballot64(live);
                     if (live) list[n_listed + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
                     n_listed += (unsigned int)__popcll(mask);
                 }
@@ -3693,7 +3713,7 @@ tls_search_kernel(const SearchArgs a) {
                 const unsigned int unit = unit_a[j];
                 const float u = u_a[j];
                 const bool sel = (double)u >= T;   // invalid lanes hold -inf
-                const unsigned long long mask = __ballot(sel);
+                const unsigned long long mask = ballot64(sel);
                 if (mask) {
                     unsigned int base = 0;
                     if (lane == 0) base = atomicAdd(&rt.singles[row], (unsigned int)__popcll(mask));
@@ -3750,7 +3770,7 @@ tls_search_kernel(const SearchArgs a) {
                                                           coarse_e2(P2, i, i + d, a.p2_shift, p2_blocks)) >= T;
                         }
                     }
-                    const unsigned long long mask = __ballot(pass);
+                    const unsigned long long mask = ballot64(pass);
                     if (pass) list[first + count + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)u;
                     count += (unsigned int)__popcll(mask);
                 }
@@ -3877,7 +3897,7 @@ tls_search_kernel(const SearchArgs a) {
                         // (e = 1 - f with the patch mapping of stage_samples)
                         const double* qg = a.q + q_offset;
                         const double* q2g = UNIFORM_W ? nullptr : a.q2 + q_offset;
-                        const unsigned long long have_mask = __ballot(have);
+                        const unsigned long long have_mask = ballot64(have);
                         double myB = 0.0, myA = sum_q2;
                         for (int s2 = 0; s2 < kWave; ++s2) {
                             if (!((have_mask >> s2) & 1ull)) continue;
