@@ -139,6 +139,15 @@ typedef const __attribute__((address_space(4))) PeriodRows* const_rows_ptr;
 // (HIP's __ballot goes through a 0/1 select and a second compare).
 __device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 
+// v[lane `which`] = value (both wave-uniform).  The lane select travels in M0: before gfx10 one instruction reads one
+// scalar register besides it.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (m0 is a reserved register: the compiler never keeps a value of its own in it)
+__device__ __forceinline__ void set_lane(int& v, int value, int which) {
+    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(which) : "m0");
+}
+#pragma clang diagnostic pop
+
 // kU consecutive doubles from the folded series.  In LDS the reads are issued as eight
 // ds_read_b64: hipcc would pair them into ds_read2_b64, which moves half the bytes per LDS
 // cycle (MI355X_MICROARCH.md, LDS table: 128 vs 256 B/clk) -- and this loop lives on the LDS.
@@ -3266,8 +3275,9 @@ tls_search_kernel(const SearchArgs a) {
                 // Lane j collects the live mask of row k_lo + j of this 64-unit tile; the list slots of
                 // ALL rows are then reserved with one LDS atomic instruction (one lane per row) instead
                 // of one dependent atomic round trip per row.
-                unsigned long long row_mask = 0ull;
-                bool in_band = false;
+                int row_lo = 0, row_hi = 0;   // the two halves of the lane's (row's) live mask
+                unsigned long long band_mask = 0ull;
+                const unsigned long long valid_mask = ballot64(unit < unit_hi);
                 // kRowBatch durations per step: all LDS reads of the step are in flight together
 #ifndef TLS_ROW_BATCH
 #define TLS_ROW_BATCH 2
@@ -3299,26 +3309,35 @@ tls_search_kernel(const SearchArgs a) {
                         if (k + j < k_x) {
                             // (a lane past the row's units reads sentinels or foreign cells: it is masked below and
                             // must not raise `undecided`)
-                            bool live;
+                            // the row's live lanes as a wave-uniform mask, straight from the compare
+                            unsigned long long mask;
                             if (exact_u) {   // (a scalar branch: the whole workgroup is in one mode)
                                 bool und_j = false;
-                                live = depth_pass(dC[j], inv[j], (double)dv[j], dmin, rule.eps, true, und_j);
+                                mask = ballot64(depth_pass(dC[j], inv[j], (double)dv[j], dmin, rule.eps, true, und_j));
                             } else {         // fast mode: no branch per row; a chunk inside the band is noted for the tile
                                 const double m_fast = dC[j] * inv[j];
-                                live = m_fast > thr_hi;
-                                in_band |= !live && m_fast >= thr_lo;
+                                const bool deep = m_fast > thr_hi;
+                                mask = ballot64(deep);
+                                band_mask |= ballot64(!deep && m_fast >= thr_lo);
                             }
-                            if (n_dense <= kWave) {
-                                const unsigned long long mask = ballot64(live && unit < unit_hi);
-                                if (lane == k + j - k_lo) row_mask = mask;
+                            mask &= valid_mask;
+                            if (n_dense <= kWave) {   // lane (row) of row_mask := mask
+                                if constexpr (RESIDENT) {
+                                    set_lane(row_lo, (int)(unsigned int)mask, k + j - k_lo);
+                                    set_lane(row_hi, (int)(unsigned int)(mask >> 32), k + j - k_lo);
+                                } else if (lane == k + j - k_lo) {   // (the slab kernels keep M0 for their LDS transfers)
+                                    row_lo = (int)(unsigned int)mask;
+                                    row_hi = (int)(unsigned int)(mask >> 32);
+                                }
                             } else {   // more dense rows than lanes (never with the default duration grid)
-                                push_live(live && unit < unit_hi, (unsigned int)unit, &rt.live[k + j - k_lo],
+                                push_live(((mask >> lane) & 1ull) != 0ull, (unsigned int)unit, &rt.live[k + j - k_lo],
                                           chunk_list + widths_c[k + j].list_base, lane);
                             }
                         }
                     }
                 }
-                undecided |= in_band && unit < unit_hi;
+                undecided |= (band_mask & valid_mask) != 0ull;   // (any lane's sends the whole workgroup to exact mode)
+                const unsigned long long row_mask = ((unsigned long long)(unsigned int)row_hi << 32) | (unsigned int)row_lo;
                 if (n_dense <= kWave) {
                     unsigned int base = 0;
                     const unsigned int mine = (unsigned int)__popcll(row_mask);
@@ -3873,8 +3892,6 @@ tls_search_kernel(const SearchArgs a) {
                             case 5: dot_windows<true, 5>(e, q, Lr, Bv); break;
                             default: dot_windows_rt<true>(e, q, Lr, xth, Bv); break;
                         }
-#pragma unroll
-                        for (int r = 0; r < kR; ++r) Av[r] = sum_q2;
                     } else {
                         const double* wv = w_base + b;
                         const const_f64_ptr q2 = q2_all + q_offset;
@@ -3886,6 +3903,10 @@ tls_search_kernel(const SearchArgs a) {
                             case 5: dot_windows_weighted<true, 5>(e, wv, q, q2, Lr, Bv, Av); break;
                             default: dot_windows_weighted_rt<true>(e, wv, q, q2, Lr, xth, Bv, Av); break;
                         }
+                    }
+                    if constexpr (UNIFORM_W) {
+#pragma unroll
+                        for (int r = 0; r < kR; ++r) Av[r] = sum_q2;
                     }
                     if (have)
                         consider_cells<UNIFORM_W, !RESIDENT, kR>(lead, c_base, b, xth, d, inv_d, dd, rule, overshoot, Av, Bv, k, n_eval, undecided, widths_c, regB);
