@@ -2870,15 +2870,21 @@ __device__ __forceinline__ bool fold_sort_cumsum_tiled(const double* t, const do
     return true;
 }
 
+typedef const __attribute__((address_space(4))) SearchArgs* args_ptr;
 template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false>
 __global__ void __launch_bounds__(TLS_LAUNCH_THREADS, TLS_WAVES_PER_EU)
-tls_search_kernel(const SearchArgs a) {
+tls_search_kernel(const SearchArgs) {
+    // The arguments are read through a pointer to the kernel-argument segment, where they are used (scalar loads the
+    // compiler may repeat), not taken by value: ~100 values loaded at entry compete for 104 scalar registers for the
+    // whole kernel, and the losers live in spilled lanes of a vector register and come back one v_readlane -- a VALU
+    // instruction -- at a time (measured: config 2 -1.7 %; forcing a re-read per phase or per period: slower again).
+    args_ptr ap = (args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform by construction
-    const int n = a.n, W = a.W, M = a.M, nb = a.nb;
-    const int region_pad = a.region_pad;
+    const int n = ap->n, W = ap->W, M = ap->M, nb = ap->nb;
+    const int region_pad = ap->region_pad;
     // region stride in doubles; even in the slab so that every region starts on a 16-byte boundary
     const int RS = RESIDENT ? M + 1 + region_pad : ((M + 1 + region_pad + 1) & ~1);
 
@@ -2894,38 +2900,38 @@ tls_search_kernel(const SearchArgs a) {
     double* P2 = reinterpret_cast<double*>(cumsum_scratch);
     static_assert(kCumsumScratchBytes >= 8 * (kP2MaxBlocks + 1), "coarse prefix sum does not fit the cumsum scratch");
     // counting the evaluated cells (tls_execute(ctx, 1)) means evaluating all of them
-    const bool prune_on = PRUNE && a.counters == nullptr;
+    const bool prune_on = PRUNE && ap->counters == nullptr;
     static_assert(sizeof(CumsumScratch) <= kCumsumScratchBytes, "cumsum scratch does not fit its slot");
     RowTables rt;
     rt.live = reinterpret_cast<unsigned int*>(smem + kFixedHeader);
-    rt.singles = rt.live + a.n_widths;
-    rt.batch_start = rt.singles + a.n_widths;
-    rt.next_batch = rt.batch_start + (a.n_widths + 1);
+    rt.singles = rt.live + ap->n_widths;
+    rt.batch_start = rt.singles + ap->n_widths;
+    rt.next_batch = rt.batch_start + (ap->n_widths + 1);
     double *regA, *regB, *regW = nullptr;
     unsigned int* cnt;
     if constexpr (RESIDENT) {
-        regA = reinterpret_cast<double*>(smem + a.hdr_bytes);
+        regA = reinterpret_cast<double*>(smem + ap->hdr_bytes);
         regB = regA + RS;
         if constexpr (!UNIFORM_W) regW = regB + RS;
         cnt = reinterpret_cast<unsigned int*>(regB);
     } else {
-        double* slab = a.scratch + (long long)blockIdx.x * a.scratch_stride;
+        double* slab = ap->scratch + (long long)blockIdx.x * ap->scratch_stride;
         regA = slab;
         regB = regA + RS;
         if constexpr (!UNIFORM_W) regW = regB + RS;
-        cnt = reinterpret_cast<unsigned int*>(smem + a.hdr_bytes);
+        cnt = reinterpret_cast<unsigned int*>(smem + ap->hdr_bytes);
     }
-    unsigned int* chunk_list = a.chunk_lists + (long long)blockIdx.x * a.list_stride;
+    unsigned int* chunk_list = ap->chunk_lists + (long long)blockIdx.x * ap->list_stride;
     // sort scratch inside regB: [cnt (resident only)] idx_tmp[n] perm[n]
     IdxT* idx_tmp = RESIDENT ? reinterpret_cast<IdxT*>(cnt + nb) : reinterpret_cast<IdxT*>(regB);
     IdxT* perm = idx_tmp + n;
     double* ph_orig = regA;  // phase by ORIGINAL index during the sort
 
     if (tid == 0) {
-        [[maybe_unused]] const long long need = RESIDENT ? (long long)a.hdr_bytes + (UNIFORM_W ? 2 : 3) * 8LL * RS
-                                        : (long long)a.hdr_bytes + (UNIFORM_W ? (STAGE_C ? 2 : 1) : (STAGE_C ? 3 : 2)) * 8LL * (a.tile_len + a.tile_halo);
-        TLS_CHECK(a, need <= a.lds_bytes, kChkLdsCarve);
-        TLS_CHECK(a, (long long)kFixedHeader + 4LL * (3 * a.n_widths + 2) <= a.hdr_bytes, kChkLdsCarve);
+        [[maybe_unused]] const long long need = RESIDENT ? (long long)ap->hdr_bytes + (UNIFORM_W ? 2 : 3) * 8LL * RS
+                                        : (long long)ap->hdr_bytes + (UNIFORM_W ? (STAGE_C ? 2 : 1) : (STAGE_C ? 3 : 2)) * 8LL * (ap->tile_len + ap->tile_halo);
+        TLS_CHECK(*ap, need <= ap->lds_bytes, kChkLdsCarve);
+        TLS_CHECK(*ap, (long long)kFixedHeader + 4LL * (3 * ap->n_widths + 2) <= ap->hdr_bytes, kChkLdsCarve);
     }
     // the spare entries behind each region are only ever multiplied by zero: make them finite
     for (int k = tid; k < region_pad; k += nt) {
@@ -2933,19 +2939,19 @@ tls_search_kernel(const SearchArgs a) {
         if constexpr (!UNIFORM_W) regW[M + 1 + k] = 0.0;
     }
 
-    const const_width_ptr widths_c = (const_width_ptr)a.widths;  // read-only for the whole launch
-    const const_rows_ptr rows_c = (const_rows_ptr)a.rows;
-    const const_f64_ptr q_all = (const_f64_ptr)a.q;
-    const const_f64_ptr q2_all = (const_f64_ptr)a.q2;
-    const const_screen_ptr screens_c = (const_screen_ptr)a.screens;
-    const double dmin = a.depth_min;
+    const const_width_ptr widths_c = (const_width_ptr)ap->widths;  // read-only for the whole launch
+    const const_rows_ptr rows_c = (const_rows_ptr)ap->rows;
+    const const_f64_ptr q_all = (const_f64_ptr)ap->q;
+    const const_f64_ptr q2_all = (const_f64_ptr)ap->q2;
+    const const_screen_ptr screens_c = (const_screen_ptr)ap->screens;
+    const double dmin = ap->depth_min;
 
     bool retry_exact = false;   // the period just searched in fast mode left a window undecided: again, in exact mode
     int work = 0;
     for (;;) {
         // ---- fetch the next period from the queue ----------------------------------
         if (!retry_exact) {
-            if (tid == 0) { s_work[0] = (int)atomicAdd(a.queue, 1u); s_work[1] = 0; s_work[2] = 0; }
+            if (tid == 0) { s_work[0] = (int)atomicAdd(ap->queue, 1u); s_work[1] = 0; s_work[2] = 0; }
             __syncthreads();
             work = __builtin_amdgcn_readfirstlane(s_work[0]);
             __syncthreads();
@@ -2954,51 +2960,51 @@ tls_search_kernel(const SearchArgs a) {
         }
         int flag_slot = 1;   // the "undecided" flag of the attempt in flight: s_work[1] and s_work[2] take turns
         // exact mode: X = k - numpy.cumsum, bit for bit; fast mode: X = plain prefix sum of 1 - f (depth_pass)
-        const bool period_exact = (!RESIDENT && (a.fast_slab == 0 || a.sort3 != 0)) || retry_exact || a.exact_prefix != 0 ||
-                                  a.debug_prefix != nullptr;
+        const bool period_exact = (!RESIDENT && (ap->fast_slab == 0 || ap->sort3 != 0)) || retry_exact || ap->exact_prefix != 0 ||
+                                  ap->debug_prefix != nullptr;
         retry_exact = false;
         bool curve_exact = false;   // batches: this light curve again in exact mode (the permutation is kept: no new sort)
-        if (work >= a.n_periods) {
+        if (work >= ap->n_periods) {
             // the last workgroup to leave rewinds the queue for the next launch (no memset between
             // two searches of a prepared plan); queue[1] counts the workgroups that are done
             if (tid == 0) {
                 __threadfence();
-                if (atomicAdd(a.queue + 1, 1u) == gridDim.x - 1) { atomicExch(a.queue, 0u); atomicExch(a.queue + 1, 0u); }
+                if (atomicAdd(ap->queue + 1, 1u) == gridDim.x - 1) { atomicExch(ap->queue, 0u); atomicExch(ap->queue + 1, 0u); }
             }
             break;
         }
-        const int p = a.order[work];
-        TLS_CHECK(a, p >= 0 && p < a.n_periods, kChkWorkItem);
-        const double period = a.periods[p];
+        const int p = ap->order[work];
+        TLS_CHECK(*ap, p >= 0 && p < ap->n_periods, kChkWorkItem);
+        const double period = ap->periods[p];
         long long t_period = 0;
-        if (a.period_cycles && tid == 0) t_period = clock64();
+        if (ap->period_cycles && tid == 0) t_period = clock64();
         PhaseClock pc;
-        pc.start(a.phase_cycles);
+        pc.start(ap->phase_cycles);
 
         // ---- phase 1: fold + stable sort by phase ----------------------------------
         bool sorted = false;
         bool fused = false;   // fold, sort, gather AND prefix sum done by fold_sort_cumsum_tiled
         if constexpr (!RESIDENT) {
-            if (a.sort3 && a.n_curves == 1)
-                fused = fold_sort_cumsum_tiled<UNIFORM_W>(a.t, a.y, a.w, n, W, period, regA, regB, regW,
-                                                          a.sort3_scratch + (long long)blockIdx.x * sort3_scratch_doubles(n),
-                                                          smem + a.hdr_bytes, wsum,
-                                                          reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
-            if (a.sort3 && a.n_curves == 1) pc.start(a.phase_cycles);   // the call kept its own clock
+            if (ap->sort3 && ap->n_curves == 1)
+                fused = fold_sort_cumsum_tiled<UNIFORM_W>(ap->t, ap->y, ap->w, n, W, period, regA, regB, regW,
+                                                          ap->sort3_scratch + (long long)blockIdx.x * sort3_scratch_doubles(n),
+                                                          smem + ap->hdr_bytes, wsum,
+                                                          reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), ap->phase_cycles);
+            if (ap->sort3 && ap->n_curves == 1) pc.start(ap->phase_cycles);   // the call kept its own clock
             // series in HBM: the two-level sort with sequential HBM accesses, unless a phase bin overflows
-            if (!fused && a.sort2) {
+            if (!fused && ap->sort2) {
                 typedef global_ptr<const double> gcd;
                 typedef global_ptr<double> gd;
                 typedef global_ptr<unsigned int> gu;
                 typedef global_ptr<unsigned long long> gull;
                 // (one light curve: the flux is gathered on the way and no permutation is written)
                 // (one light curve: the flux is gathered on the way and no permutation is written)
-                sorted = fold_and_sort_tiled_call<!UNIFORM_W>((gcd)a.t, n, period, (gull) reinterpret_cast<unsigned long long*>(regA),
-                                                              (gu)(a.n_curves == 1 ? nullptr : reinterpret_cast<unsigned int*>(perm)),
-                                                              lds_address(smem + a.hdr_bytes), (gull)a.phase_cycles,
-                                                              (gcd)(a.n_curves == 1 ? a.y : nullptr), (gcd)(UNIFORM_W ? nullptr : a.w),
-                                                              (gd)regA, (gd)regW, (gull)a.check);
-                pc.start(a.phase_cycles);   // (the call kept its own clock)
+                sorted = fold_and_sort_tiled_call<!UNIFORM_W>((gcd)ap->t, n, period, (gull) reinterpret_cast<unsigned long long*>(regA),
+                                                              (gu)(ap->n_curves == 1 ? nullptr : reinterpret_cast<unsigned int*>(perm)),
+                                                              lds_address(smem + ap->hdr_bytes), (gull)ap->phase_cycles,
+                                                              (gcd)(ap->n_curves == 1 ? ap->y : nullptr), (gcd)(UNIFORM_W ? nullptr : ap->w),
+                                                              (gd)regA, (gd)regW, (gull)ap->check);
+                pc.start(ap->phase_cycles);   // (the call kept its own clock)
             }
         }
         if (!sorted && !fused) {
@@ -3007,39 +3013,39 @@ tls_search_kernel(const SearchArgs a) {
             unsigned int* big_list = reinterpret_cast<unsigned int*>(cumsum_scratch);
             constexpr int kBigCap = kCumsumScratchBytes / 4;
             if constexpr (RESIDENT) {
-                fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc, big_list, kBigCap);
+                fold_and_sort<IdxT>(ap->t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc, big_list, kBigCap);
             } else {
                 double* stage_key = reinterpret_cast<double*>(cnt + ((nb + 1) & ~1));
-                const long long room = a.lds_bytes - a.hdr_bytes - 4LL * ((nb + 1) & ~1);
+                const long long room = ap->lds_bytes - ap->hdr_bytes - 4LL * ((nb + 1) & ~1);
                 const int stage_cap = room > 0 ? (int)(room / 12) : 0;
                 unsigned int* stage_idx = reinterpret_cast<unsigned int*>(stage_key + stage_cap);
-                fold_and_sort<IdxT>(a.t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc, big_list, kBigCap,
+                fold_and_sort<IdxT>(ap->t, n, period, 0.0, ph_orig, cnt, nb, idx_tmp, perm, wsum, pc, big_list, kBigCap,
                                     stage_key, stage_idx, stage_cap);
             }
         }
         // survey mode: the permutation depends on (t, period) only, so every light curve of the
         // batch reuses it; it must outlive the prefix sum that overwrites its LDS home
         const IdxT* perm_use = perm;
-        if (a.n_curves > 1) {
-            IdxT* perm_g = reinterpret_cast<IdxT*>(a.perm_scratch + (long long)blockIdx.x * n);
+        if (ap->n_curves > 1) {
+            IdxT* perm_g = reinterpret_cast<IdxT*>(ap->perm_scratch + (long long)blockIdx.x * n);
             for (int k = tid; k < n; k += nt) perm_g[k] = perm[k];
             perm_use = perm_g;
             __syncthreads();
         }
-        for (int curve = 0; curve < a.n_curves; ++curve) {
+        for (int curve = 0; curve < ap->n_curves; ++curve) {
         const bool exact_mode = period_exact || curve_exact;
         curve_exact = false;
         DepthRule rule;
-        rule.dmin = a.depth_min; rule.eps = exact_mode ? 1e-15 : a.eps_fast; rule.exact_mode = exact_mode;
+        rule.dmin = ap->depth_min; rule.eps = exact_mode ? 1e-15 : ap->eps_fast; rule.exact_mode = exact_mode;
         // (the estimate's mean depth is off by ~1e-16 absolute: negligible against transit_depth_min = 1e-5, the whole
         // story for a transit_depth_min near zero -- then every cell takes the exact comparison)
         rule.reach = (rule.dmin - rule.eps > 4e-15) ? fmin(fmax(1e-9, 4e-15 / (rule.dmin - rule.eps)), 1.0) : 1.0;
         bool undecided = false;
-        const double* y_c = a.y + (long long)curve * n;
+        const double* y_c = ap->y + (long long)curve * n;
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  kG
         // elements per step: their global reads (L2 latency) are in flight together -- the compiler
         // cannot overlap them itself, the LDS store of one may alias the index read of the next
-        const bool gathered = !RESIDENT && (fused || (sorted && a.n_curves == 1));   // the sort did it on the way
+        const bool gathered = !RESIDENT && (fused || (sorted && ap->n_curves == 1));   // the sort did it on the way
         constexpr int kG = TLS_GATHER_DEPTH;
         for (int k0 = tid; k0 < (gathered ? 0 : n); k0 += kG * nt) {
             int idx[kG];
@@ -3049,7 +3055,7 @@ tls_search_kernel(const SearchArgs a) {
 #pragma unroll
             for (int g = 0; g < kG; ++g) v[g] = y_c[idx[g]];
             if constexpr (!UNIFORM_W) {
-                const double* w_c = a.w + (long long)curve * n;
+                const double* w_c = ap->w + (long long)curve * n;
                 double u[kG];
 #pragma unroll
                 for (int g = 0; g < kG; ++g) u[g] = w_c[idx[g]];
@@ -3060,8 +3066,8 @@ tls_search_kernel(const SearchArgs a) {
             for (int g = 0; g < kG; ++g) if (k0 + g * nt < n) regA[k0 + g * nt] = v[g];
         }
         __syncthreads();
-        if (a.debug_folded && curve == 0) {   // test entry: the folded flux as the sort left it (core.py:120-123)
-            for (int k = tid; k < n; k += nt) a.debug_folded[(long long)p * n + k] = regA[k];
+        if (ap->debug_folded && curve == 0) {   // test entry: the folded flux as the sort left it (core.py:120-123)
+            for (int k = tid; k < n; k += nt) ap->debug_folded[(long long)p * n + k] = regA[k];
             __syncthreads();
         }
         // ---- phase 2: patch (core.py:126-132) and sequential cumsum ----------------
@@ -3082,7 +3088,7 @@ tls_search_kernel(const SearchArgs a) {
         const int k_hi = __builtin_amdgcn_readfirstlane(rows_c[p].k_hi);
         const int k_x = __builtin_amdgcn_readfirstlane(rows_c[p].k_x);
         const int n_rows = k_hi - k_lo;
-        TLS_CHECK(a, 0 <= k_lo && k_lo <= k_x && k_x <= k_hi && k_hi <= a.n_widths, kChkWorkItem);
+        TLS_CHECK(*ap, 0 <= k_lo && k_lo <= k_x && k_x <= k_hi && k_hi <= ap->n_widths, kChkWorkItem);
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup -- or, in fast mode,
         // e = 1 - f and its plain prefix sum X in one pass (depth_pass explains why that decides the same cells)
@@ -3091,17 +3097,17 @@ tls_search_kernel(const SearchArgs a) {
                 prefix_sum_of_e<UNIFORM_W>(regA, regW, regB, M, reinterpret_cast<double*>(cumsum_scratch));
             } else {
 #if TLS_CUMSUM2
-            exact_cumsum<false, true, true>(regA, regB, M, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles);
+            exact_cumsum<false, true, true>(regA, regB, M, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), ap->phase_cycles);
 #else
-            exact_sequential_cumsum(regA, regB, M, cumsum_scratch, a.phase_cycles);
+            exact_sequential_cumsum(regA, regB, M, cumsum_scratch, ap->phase_cycles);
 #endif
             }
         } else if (!fused) {
             // the series is in the HBM slab: the scan runs through LDS, 16 K elements a round, in place
             // (C[k+1] over f[k]); the patch (core.py:126: the first W samples again) is an index mapping
             // of the copy-in; LDS-only barriers, so the prefix-sum stores of a round stay in flight
-            double* buf = reinterpret_cast<double*>(smem + a.hdr_bytes) + 1;   // C[0..len], f = buf + 1 (16-byte aligned)
-            const int kRound = a.cumsum_round;   // elements per LDS round (the host sizes it to the workgroup's LDS share)
+            double* buf = reinterpret_cast<double*>(smem + ap->hdr_bytes) + 1;   // C[0..len], f = buf + 1 (16-byte aligned)
+            const int kRound = ap->cumsum_round;   // elements per LDS round (the host sizes it to the workgroup's LDS share)
             double carry = 0.0;
             const bool dma = TLS_SLAB_DMA && (n & 1) == 0;   // pairs of samples never straddle the patch boundary
             for (int c0 = 0; c0 < M; c0 += kRound) {
@@ -3146,9 +3152,9 @@ tls_search_kernel(const SearchArgs a) {
                 } else {
                 if (len <= 16 * nt) {
                     carry = exact_cumsum_round_call(lds_address(buf), len, carry, lds_address(cumsum_scratch),
-                                                    (global_ptr<unsigned long long>)a.phase_cycles);
+                                                    (global_ptr<unsigned long long>)ap->phase_cycles);
                 } else {   // fewer than 1024 threads: several blocks per round
-                    carry = exact_cumsum<true>(buf + 1, buf, len, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), a.phase_cycles, carry);
+                    carry = exact_cumsum<true>(buf + 1, buf, len, reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), ap->phase_cycles, carry);
                 }
                 pc.mark(5);
                 copy_out_stream_x(regB + c0, buf, len + 1, tid, c0);   // the slab keeps X[k] = k - C[k]
@@ -3167,9 +3173,9 @@ tls_search_kernel(const SearchArgs a) {
         // sentinels (possible for widths below kR) still sees a huge negative sum.
         for (int k = tid; k < region_pad; k += nt) regB[M + 1 + k] = -(double)(k + 1) * 1.0e300;
         __syncthreads();
-        if (a.debug_prefix && curve == 0) {   // test entry: C as numpy.cumsum gives it (helpers.py:72); exact mode is forced
-            if constexpr (RESIDENT) { for (int k = tid; k <= M; k += nt) a.debug_prefix[(long long)p * (M + 1) + k] = regB[k]; }
-            else { for (int k = tid; k <= M; k += nt) a.debug_prefix[(long long)p * (M + 1) + k] = (double)k - regB[k]; }
+        if (ap->debug_prefix && curve == 0) {   // test entry: C as numpy.cumsum gives it (helpers.py:72); exact mode is forced
+            if constexpr (RESIDENT) { for (int k = tid; k <= M; k += nt) ap->debug_prefix[(long long)p * (M + 1) + k] = regB[k]; }
+            else { for (int k = tid; k <= M; k += nt) ap->debug_prefix[(long long)p * (M + 1) + k] = (double)k - regB[k]; }
             __syncthreads();
         }
         pc.mark(5);
@@ -3199,15 +3205,15 @@ tls_search_kernel(const SearchArgs a) {
         // tile that contains their first sample.
         // (the slab variant's tile length is the period's own: its halo covers the widest in-range window only)
         const int tile_len_p = RESIDENT ? 0 : __builtin_amdgcn_readfirstlane(rows_c[p].pad);
-        const int tile_len = RESIDENT ? (1 << 30) : (tile_len_p > 0 ? tile_len_p : a.tile_len);
+        const int tile_len = RESIDENT ? (1 << 30) : (tile_len_p > 0 ? tile_len_p : ap->tile_len);
         for (int p_lo = 0; p_lo < M; p_lo += tile_len) {
         const int p_hi = p_lo + tile_len;
         const double* e_base = regA;   // e_base[b] = sample b of e (or e*w)
         const double* w_base = regW;
         const double* c_base = regB;   // c_base[i] = C[i] (tiled: the tile's LDS copy while phase 3a runs)
         if constexpr (!RESIDENT) {
-            double* tile_e = reinterpret_cast<double*>(smem + a.hdr_bytes);
-            const int staged = a.tile_len + a.tile_halo;
+            double* tile_e = reinterpret_cast<double*>(smem + ap->hdr_bytes);
+            const int staged = ap->tile_len + ap->tile_halo;
             double* tile_w = tile_e + staged;
             double* tile_c = UNIFORM_W ? tile_w : tile_w + staged;
             __syncthreads();  // the previous tile (or the sort histogram) is no longer read
@@ -3269,7 +3275,7 @@ tls_search_kernel(const SearchArgs a) {
                 const int u0 = unit * kR;
                 const int u0c = u0 < M + 1 ? u0 : M + 1;  // lanes past the row read sentinels and are masked
                 double c_lo[kR];
-                TLS_CHECK(a, u0c >= p_lo && u0c + kR - 1 <= M + region_pad && (RESIDENT || u0c + kR - 1 < p_lo + a.tile_len + a.tile_halo), kChkPredicateRead);
+                TLS_CHECK(*ap, u0c >= p_lo && u0c + kR - 1 <= M + region_pad && (RESIDENT || u0c + kR - 1 < p_lo + ap->tile_len + ap->tile_halo), kChkPredicateRead);
 #pragma unroll
                 for (int r = 0; r < kR; ++r) c_lo[r] = c_base[u0c + r];
                 // Lane j collects the live mask of row k_lo + j of this 64-unit tile; the list slots of
@@ -3293,7 +3299,7 @@ tls_search_kernel(const SearchArgs a) {
                         dv[j] = widths_c[kk].width;
                         inv[j] = widths_c[kk].inv_d;
                         const int hi0 = min(u0 + dv[j], M + 1);  // past the grid: sentinels
-                        TLS_CHECK(a, hi0 + kR - 1 <= M + region_pad && (RESIDENT || unit >= unit_hi || hi0 + kR - 1 < p_lo + a.tile_len + a.tile_halo), kChkPredicateRead);
+                        TLS_CHECK(*ap, hi0 + kR - 1 <= M + region_pad && (RESIDENT || unit >= unit_hi || hi0 + kR - 1 < p_lo + ap->tile_len + ap->tile_halo), kChkPredicateRead);
 #pragma unroll
                         for (int r = 0; r < kR; ++r) c_hi[j][r] = c_base[hi0 + r];
                     }
@@ -3348,7 +3354,7 @@ tls_search_kernel(const SearchArgs a) {
                         const int j = __ffsll((long long)left) - 1;
                         const unsigned long long mask = (unsigned long long)lane_value((long long)row_mask, j);
                         const unsigned int b0 = (unsigned int)lane_value((int)base, j);
-                        TLS_CHECK(a, b0 + (unsigned int)__popcll(mask) <= (unsigned int)widths_c[k_lo + j].n_chunks, kChkListCap);
+                        TLS_CHECK(*ap, b0 + (unsigned int)__popcll(mask) <= (unsigned int)widths_c[k_lo + j].n_chunks, kChkListCap);
                         if ((mask >> lane) & 1ull)
                             chunk_list[widths_c[k_lo + j].list_base + b0 + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
                     }
@@ -3419,7 +3425,7 @@ tls_search_kernel(const SearchArgs a) {
                     n_listed += (unsigned int)__popcll(mask);
                 }
             }
-            TLS_CHECK(a, n_listed <= (unsigned int)widths_c[k].n_chunks, kChkListCap);
+            TLS_CHECK(*ap, n_listed <= (unsigned int)widths_c[k].n_chunks, kChkListCap);
             if (lane == 0) rt.live[k - k_lo] = n_listed;
         }
         __syncthreads();
@@ -3434,8 +3440,8 @@ tls_search_kernel(const SearchArgs a) {
         }
         if constexpr (!RESIDENT && !STAGE_C) {
             // the folded samples replace C in the tile; the few C values phase 3b needs come from the slab
-            double* tile_e = reinterpret_cast<double*>(smem + a.hdr_bytes);
-            const int staged = a.tile_len + a.tile_halo;
+            double* tile_e = reinterpret_cast<double*>(smem + ap->hdr_bytes);
+            const int staged = ap->tile_len + ap->tile_halo;
             double* tile_w = tile_e + staged;
             {
                 if (TLS_SLAB_DMA && (n & 1) == 0) {
@@ -3460,21 +3466,21 @@ tls_search_kernel(const SearchArgs a) {
         bool prune_now = false;
         // rounding allowance of window_bound per sample of a window: the sequential prefix sum is off by at most
         // half an ulp of its total per step
-        [[maybe_unused]] const double slack_unit = a.slack_unit;
+        [[maybe_unused]] const double slack_unit = ap->slack_unit;
         int p2_blocks = 0;
-        float* const ulist = reinterpret_cast<float*>(chunk_list + a.list_cap);   // bound of every live unit
+        float* const ulist = reinterpret_cast<float*>(chunk_list + ap->list_cap);   // bound of every live unit
         if (prune_on) {
             unsigned int total_live = 0;
 #pragma unroll 1
             for (int row = 0; row < n_rows; ++row) total_live += rt.live[row];
             total_live = (unsigned int)__builtin_amdgcn_readfirstlane((int)total_live);  // uniform: keep it scalar
-            prune_now = (long long)total_live >= a.prune_min_live;
+            prune_now = (long long)total_live >= ap->prune_min_live;
         }
-        if (a.phase_cycles && tid == 0) {   // developer statistics beside the phase clocks
+        if (ap->phase_cycles && tid == 0) {   // developer statistics beside the phase clocks
             unsigned int total_live = 0;
             for (int row = 0; row < n_rows; ++row) total_live += rt.live[row];
-            atomicAdd(&a.phase_cycles[32], (unsigned long long)total_live);
-            if (prune_now) atomicAdd(&a.phase_cycles[36], 1ull);
+            atomicAdd(&ap->phase_cycles[32], (unsigned long long)total_live);
+            if (prune_now) atomicAdd(&ap->phase_cycles[36], 1ull);
         }
         unsigned int* active_list = chunk_list;   // the lists phase 3b reads (the pruning pass writes a second set)
         int n_groups = 0;
@@ -3496,7 +3502,7 @@ tls_search_kernel(const SearchArgs a) {
             // (1) coarse prefix sum of e^2: P2[b] = sum of e_k^2 over k < b * 2^p2_shift
             if (!p2_ready) {   // once per period, by the first tile that prunes
                 p2_ready = true;
-                const int sh = a.p2_shift, G = 1 << sh;
+                const int sh = ap->p2_shift, G = 1 << sh;
                 p2_blocks = (M + G - 1) >> sh;
                 if (RESIDENT && G >= 8) {
                     // eight consecutive samples per thread, G/8 neighbouring lanes per block
@@ -3553,7 +3559,7 @@ tls_search_kernel(const SearchArgs a) {
                 }
             }
             __syncthreads();
-            p2_blocks = (M + (1 << a.p2_shift) - 1) >> a.p2_shift;
+            p2_blocks = (M + (1 << ap->p2_shift) - 1) >> ap->p2_shift;
             n_groups = __builtin_amdgcn_readfirstlane((int)rt.batch_start[n_rows]);
             pc.mark(22);
             // (2) the bound of every live unit, group by group; each wave remembers its most promising one
@@ -3600,7 +3606,7 @@ tls_search_kernel(const SearchArgs a) {
                         // tight bound, window by window; the unit keeps its best window's
                         // (an undecided window is listed again by phase 3b or the re-listing, which raise the flag)
                         bool und_b = false;
-                        u = unit_bound(c_base, b, tiled ? kR : 1, xth, d, dd, inv_d, ov, sum_q2, scr, P2, a.p2_shift, p2_blocks,
+                        u = unit_bound(c_base, b, tiled ? kR : 1, xth, d, dd, inv_d, ov, sum_q2, scr, P2, ap->p2_shift, p2_blocks,
                                        dmin, rule.eps, exact_mode, und_b, slack);
                         undecided |= und_b && valid;
                     } else if (prunable) {
@@ -3622,7 +3628,7 @@ tls_search_kernel(const SearchArgs a) {
                         }
                         undecided |= und_c && valid;
                         u = cell_bound(dX_max, dX_min, dd, inv_d, ov, k_mono, var_q,
-                                       coarse_e2(P2, b, b + reach, a.p2_shift, p2_blocks));
+                                       coarse_e2(P2, b, b + reach, ap->p2_shift, p2_blocks));
                     }
                     if (valid) {
                         if (prunable && u > cand_u) { cand_u = u; cand_k = k; cand_unit = unit; }
@@ -3653,7 +3659,7 @@ tls_search_kernel(const SearchArgs a) {
                 const double inv_d = widths_c[ck].inv_d;
                 const int n_win = tiled ? kR : 1;
                 const int i0 = tiled ? cu * kR * xth : cu * xth;   // first sample of the first window
-                const double* qv = a.q + q_offset;
+                const double* qv = ap->q + q_offset;
                 double Bc[kR];
 #pragma unroll
                 for (int r = 0; r < kR; ++r) Bc[r] = 0.0;
@@ -3698,7 +3704,7 @@ tls_search_kernel(const SearchArgs a) {
             // (5a) keep the units whose bound reaches T: group by group again, compacted into the workgroup's SECOND
             // set of lists (the slots of a row handed out by an LDS atomic per group; the order inside a list is
             // irrelevant).  The first set is still being read by the other waves, so nothing is compacted in place.
-            unsigned int* const kept_list = chunk_list + 2 * a.list_cap;
+            unsigned int* const kept_list = chunk_list + 2 * ap->list_cap;
             const unsigned long long below = (1ull << lane) - 1ull;
             // (all of a wave's entries are requested before the first is used: up to kAhead groups in flight)
             constexpr int kAhead = 4;
@@ -3782,11 +3788,11 @@ tls_search_kernel(const SearchArgs a) {
                         if (bound_row && pass) {
                             if ((RESIDENT || STAGE_C) && screened_row)
                                 pass = (double)window_bound(c_base, i, d, dd, inv_d, ov, widths_c[k].sum_q2, screens_c + k, P2,
-                                                            a.p2_shift, p2_blocks, dmin, rule.eps, exact_mode, undecided,
+                                                            ap->p2_shift, p2_blocks, dmin, rule.eps, exact_mode, undecided,
                                                             slack_unit * (double)(d + 64)) >= T;
                             else
                                 pass = (double)cell_bound(dX, dX, dd, inv_d, ov, k_mono, var_q,
-                                                          coarse_e2(P2, i, i + d, a.p2_shift, p2_blocks)) >= T;
+                                                          coarse_e2(P2, i, i + d, ap->p2_shift, p2_blocks)) >= T;
                         }
                     }
                     const unsigned long long mask = ballot64(pass);
@@ -3800,7 +3806,7 @@ tls_search_kernel(const SearchArgs a) {
                     count = 0;
                 }
             }
-            TLS_CHECK(a, (unsigned int)n_live + count <= (unsigned int)n_units, kChkSinglesCap);
+            TLS_CHECK(*ap, (unsigned int)n_live + count <= (unsigned int)n_units, kChkSinglesCap);
             if (lane == 0) { rt.live[row] = (unsigned int)n_live; rt.singles[row] = count; }
         }
         pc.mark(25);
@@ -3823,12 +3829,12 @@ tls_search_kernel(const SearchArgs a) {
                 carry += __shfl(incl, kWave - 1, kWave);
             }
             if (lane == 0) { rt.batch_start[n_rows] = carry; *rt.next_batch = 0; }
-            if (a.phase_cycles && lane == 0) {
+            if (ap->phase_cycles && lane == 0) {
                 unsigned int kept = 0, singles = 0;
                 for (int row = 0; row < n_rows; ++row) { kept += rt.live[row]; singles += rt.singles[row]; }
-                atomicAdd(&a.phase_cycles[33], (unsigned long long)kept);
-                atomicAdd(&a.phase_cycles[34], (unsigned long long)singles);
-                atomicAdd(&a.phase_cycles[35], (unsigned long long)carry);
+                atomicAdd(&ap->phase_cycles[33], (unsigned long long)kept);
+                atomicAdd(&ap->phase_cycles[34], (unsigned long long)singles);
+                atomicAdd(&ap->phase_cycles[35], (unsigned long long)carry);
             }
         }
         __syncthreads();
@@ -3868,7 +3874,7 @@ tls_search_kernel(const SearchArgs a) {
                 const int unit = have ? (int)active_list[list_base + (relisted ? n_live : 0) + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
                 const unsigned int evals_before = n_eval;
-                if (a.counters) {   // what the loops below issue per lane, padding and idle lanes included
+                if (ap->counters) {   // what the loops below issue per lane, padding and idle lanes included
                     const int reach = (tiled && !relisted) ? (kR - 1) * xth : 0;
                     n_issued += (unsigned long long)((L + reach + kU - 1) / kU * kU) * (reach ? kR : 1) * (UNIFORM_W ? 1 : 2);
                 }
@@ -3877,7 +3883,7 @@ tls_search_kernel(const SearchArgs a) {
                     const int u0 = unit * kR;
                     const int b = u0 * xth;
                     // the unrolled loop reads samples b .. b + ceil((L + (kR-1)*xth) / kU) * kU - 1
-                    TLS_CHECK(a, !have || (b >= p_lo && b + (L + (kR - 1) * xth + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + a.tile_len + a.tile_halo)), kChkDotWindow);
+                    TLS_CHECK(*ap, !have || (b >= p_lo && b + (L + (kR - 1) * xth + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + ap->tile_len + ap->tile_halo)), kChkDotWindow);
                     const double* e = e_base + b;
                     double Bv[kR], Av[kR];
 #pragma unroll
@@ -3916,8 +3922,8 @@ tls_search_kernel(const SearchArgs a) {
                         // the window does not fit an LDS tile: the wave takes the batch's windows one after
                         // the other, lanes over the template taps, samples straight from the slab
                         // (e = 1 - f with the patch mapping of stage_samples)
-                        const double* qg = a.q + q_offset;
-                        const double* q2g = UNIFORM_W ? nullptr : a.q2 + q_offset;
+                        const double* qg = ap->q + q_offset;
+                        const double* q2g = UNIFORM_W ? nullptr : ap->q2 + q_offset;
                         const unsigned long long have_mask = ballot64(have);
                         double myB = 0.0, myA = sum_q2;
                         for (int s2 = 0; s2 < kWave; ++s2) {
@@ -3946,7 +3952,7 @@ tls_search_kernel(const SearchArgs a) {
                         continue;
                     }
                     const int i = unit * xth;
-                    TLS_CHECK(a, !have || (i >= p_lo && i + (L + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + a.tile_len + a.tile_halo)), kChkDotWindow);
+                    TLS_CHECK(*ap, !have || (i >= p_lo && i + (L + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + ap->tile_len + ap->tile_halo)), kChkDotWindow);
                     const double* e = e_base + i;
                     double B0 = 0, B1 = 0, A0 = 0, A1 = 0;
                     if constexpr (UNIFORM_W) {
@@ -3993,8 +3999,8 @@ tls_search_kernel(const SearchArgs a) {
         if (tid == 0) s_work[3 - flag_slot] = 0;   // the next attempt's flag: nobody touches it before several barriers from now
         flag_slot = 3 - flag_slot;
         if (any_undecided != 0 && !exact_mode) {
-            if (a.phase_cycles && tid == 0) atomicAdd(&a.phase_cycles[37], 1ull);
-            if (a.n_curves > 1) { curve_exact = true; --curve; continue; }   // this curve again; the others are not touched
+            if (ap->phase_cycles && tid == 0) atomicAdd(&ap->phase_cycles[37], 1ull);
+            if (ap->n_curves > 1) { curve_exact = true; --curve; continue; }   // this curve again; the others are not touched
             retry_exact = true;   // one light curve: its permutation is gone (the prefix sum took its place) -- sort again
             break;
         }
@@ -4017,38 +4023,38 @@ tls_search_kernel(const SearchArgs a) {
             long long row = 0;
             if (n_rows > 0) {
                 // uniform weights: A,B were accumulated without the common factor w0
-                const double w0_c = a.n_curves > 1 ? a.curve_w0[curve] : a.w0;
-                const double S0_c = a.n_curves > 1 ? a.curve_S0[curve] : a.S0;
+                const double w0_c = ap->n_curves > 1 ? ap->curve_w0[curve] : ap->w0;
+                const double S0_c = ap->n_curves > 1 ? ap->curve_S0[curve] : ap->S0;
                 const double scale = UNIFORM_W ? w0_c : 1.0;
                 const double stat = (g.stat < INFINITY) ? S0_c + scale * g.stat : INFINITY;
                 if (stat < datapoints) {
-                    chi2 = stat; row = a.widths[g.k].row; depth = 1.0 - g.td;  // core.py:72-74
+                    chi2 = stat; row = ap->widths[g.k].row; depth = 1.0 - g.td;  // core.py:72-74
                 } else {
                     // nothing beat the straight line: first in-range width registers with
                     // chi2 = N and depth 0 (core.py:46-48,183-186)
-                    chi2 = datapoints; row = a.widths[k_lo].row; depth = 0.0;
+                    chi2 = datapoints; row = ap->widths[k_lo].row; depth = 0.0;
                 }
             }
-            const long long o = (long long)curve * a.n_periods + p;
-            a.out_chi2[o] = chi2;
-            a.out_row[o] = row;
-            a.out_depth[o] = depth;
+            const long long o = (long long)curve * ap->n_periods + p;
+            ap->out_chi2[o] = chi2;
+            ap->out_row[o] = row;
+            ap->out_depth[o] = depth;
         }
-        if (a.counters) {
+        if (ap->counters) {
 #pragma unroll
             for (int delta = kWave / 2; delta > 0; delta >>= 1) {
                 n_eval += __shfl_down(n_eval, delta, kWave);     // (a wave's cells of one period: far below 2^32)
                 n_steps += __shfl_down(n_steps, delta, kWave);
             }
             if (lane == 0 && n_eval) {
-                atomicAdd(&a.counters[0], (unsigned long long)n_eval);
-                atomicAdd(&a.counters[1], n_steps);
+                atomicAdd(&ap->counters[0], (unsigned long long)n_eval);
+                atomicAdd(&ap->counters[1], n_steps);
             }
-            if (lane == 0 && n_issued) atomicAdd(&a.counters[2], n_issued * kWave);
+            if (lane == 0 && n_issued) atomicAdd(&ap->counters[2], n_issued * kWave);
         }
         __syncthreads();
         }  // light curves of the batch
-        if (a.period_cycles && tid == 0) atomicAdd(&a.period_cycles[p], (unsigned long long)(clock64() - t_period));
+        if (ap->period_cycles && tid == 0) atomicAdd(&ap->period_cycles[p], (unsigned long long)(clock64() - t_period));
         // (a retry re-enters the period loop with the same work item)
     }
 }
