@@ -3322,9 +3322,8 @@ tls_search_kernel(const SearchArgs) {
                                 mask = ballot64(depth_pass(dC[j], inv[j], (double)dv[j], dmin, rule.eps, true, und_j));
                             } else {         // fast mode: no branch per row; a chunk inside the band is noted for the tile
                                 const double m_fast = dC[j] * inv[j];
-                                const bool deep = m_fast > thr_hi;
-                                mask = ballot64(deep);
-                                band_mask |= ballot64(!deep && m_fast >= thr_lo);
+                                mask = ballot64(m_fast > thr_hi);
+                                band_mask |= ballot64(m_fast >= thr_lo) & ~mask;   // (two compares, the rest on the scalar unit)
                             }
                             mask &= valid_mask;
                             if (n_dense <= kWave) {   // lane (row) of row_mask := mask
