@@ -400,9 +400,16 @@ __device__ __forceinline__ void finish_samples(double* tile_e, double* tile_w, i
 }
 
 // developer instrumentation: thread 0 stamps the shader clock at phase boundaries
+// Per-phase shader clocks of the search kernel (tls_debug_phase_cycles, slots 0-31): built into the instrumented and the
+// checked library (make clocks / make debug), not into the shipped one -- the marks cost 0.4-1.1 % of the kernel even when
+// nobody asks for them (the statistics slots 32-39 are kept everywhere).
+#ifndef TLS_PHASE_CLOCKS
+#define TLS_PHASE_CLOCKS 0
+#endif
 struct PhaseClock {
     unsigned long long* out;
     long long last;
+#if TLS_PHASE_CLOCKS
     __device__ __forceinline__ void start(unsigned long long* o) { out = o; if (out && threadIdx.x == 0) last = clock64(); }
     __device__ __forceinline__ void mark(int phase) {
         if (out && threadIdx.x == 0) {
@@ -411,6 +418,10 @@ struct PhaseClock {
             last = now;
         }
     }
+#else
+    __device__ __forceinline__ void start(unsigned long long*) {}
+    __device__ __forceinline__ void mark(int) {}
+#endif
 };
 
 // One entry per DISTINCT trial width, ascending (numpy.unique, core.py:113); `row` is the

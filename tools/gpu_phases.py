@@ -1,5 +1,7 @@
-"""Developer tool: per-phase cycle breakdown of the search kernel on a GPU box.
-    python tools/gpu_phases.py [config ...]      (default: k2_90d k2_90d@500 tutorial01 tess_27d kepler_4yr/64)"""
+"""Developer tool: per-phase cycle breakdown of the search kernel on a GPU box.  Needs the instrumented library:
+    make -C tls_amd/csrc clocks
+    TLS_AMD_DEBUG=1 TLS_AMD_LIB=$PWD/tls_amd/libtls_amd_clocks.so python tools/gpu_phases.py [config ...]
+(default: k2_90d k2_90d@500 tutorial01 tess_27d kepler_4yr/64; the shipped library carries no phase clocks)"""
 import os
 import sys
 
@@ -24,6 +26,9 @@ for case in cases:
     blocks, fails = ph.pop("cumsum_blocks"), ph.pop("cumsum_fallbacks")
     stats = {k: ph.pop(k) for k in list(ph) if k.startswith("stat_")}
     tot = sum(ph.values())
+    if tot == 0:
+        sys.exit("no phase clocks in this library: build `make -C tls_amd/csrc clocks` and select it with "
+                 "TLS_AMD_DEBUG=1 TLS_AMD_LIB=.../libtls_amd_clocks.so")
     info = ctx.plan_info()
     print(case, "%.3f ms" % ms, "cells/s %.3e" % (info["grid_cells"] / ms * 1e3),
           "cyc/period/wg %.0f" % (tot / len(periods)), "cumsum blocks %d fallbacks %d |" % (blocks, fails),

@@ -8,5 +8,5 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 timeout 900 python -m pytest tests -m gpu -q -x > "$OUT/pytest.txt" 2>&1; grep -E "passed|failed|Error|error" "$OUT/pytest.txt" | tail -5
-timeout 300 python tools/gpu_phases.py $CFGS > "$OUT/phases.txt" 2>&1
+TLS_AMD_DEBUG=1 TLS_AMD_LIB=$ROOT/tls_amd/libtls_amd_clocks.so timeout 300 python tools/gpu_phases.py $CFGS > "$OUT/phases.txt" 2>&1
 cut -c1-900 "$OUT/phases.txt"
