@@ -579,9 +579,9 @@ void order_by_cost(const std::vector<int64_t>& cost, std::vector<int>& order) {
     for (size_t p = 0; p < np; ++p) order[p] = (int)(key[p] & 0x7fffffffull);
 }
 
-template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false>
+template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false, bool COUNTING = false>
 hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
-    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING>;
+    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING, COUNTING>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
@@ -663,18 +663,17 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     // pruning variant: uniform weights, noisy enough that most trial cells pass the depth predicate,
     // and not while the evaluated cells are being counted (counting means evaluating all of them)
     const bool prune = ctx->uniform_w && ctx->prune_kernel && !count_work;
-    if (ctx->resident)
-        e = !ctx->uniform_w ? launch_variant<true, false, false, unsigned short>(ctx, a)
-            : prune ? launch_variant<true, true, false, unsigned short, true>(ctx, a)
-                    : launch_variant<true, true, false, unsigned short>(ctx, a);
-    else if (ctx->stage_c)
-        e = !ctx->uniform_w ? launch_variant<false, false, true, unsigned int>(ctx, a)
-            : prune ? launch_variant<false, true, true, unsigned int, true>(ctx, a)
-                    : launch_variant<false, true, true, unsigned int>(ctx, a);
-    else
-        e = !ctx->uniform_w ? launch_variant<false, false, false, unsigned int>(ctx, a)
-            : prune ? launch_variant<false, true, false, unsigned int, true>(ctx, a)
-                    : launch_variant<false, true, false, unsigned int>(ctx, a);
+    // (counting has an instantiation of its own: the plain kernels do not keep the counters)
+#define TLS_LAUNCH(RES, STAGE, IDX)                                                                               \
+    (!ctx->uniform_w ? (count_work ? launch_variant<RES, false, STAGE, IDX, false, true>(ctx, a)                    \
+                                   : launch_variant<RES, false, STAGE, IDX, false, false>(ctx, a))                   \
+     : prune         ? launch_variant<RES, true, STAGE, IDX, true, false>(ctx, a)                                    \
+     : count_work    ? launch_variant<RES, true, STAGE, IDX, false, true>(ctx, a)                                    \
+                     : launch_variant<RES, true, STAGE, IDX, false, false>(ctx, a))
+    if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short);
+    else if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int);
+    else e = TLS_LAUNCH(false, false, unsigned int);
+#undef TLS_LAUNCH
     if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     ctx->executed = true;
     ctx->counted = count_work;

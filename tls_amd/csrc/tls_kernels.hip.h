@@ -1675,7 +1675,7 @@ __device__ __forceinline__ void consider(Lead& best, double x_lo, double x_hi, i
 // by the reference's values whenever the estimates are close), and a cell that meets itself there ties and stays.
 // (X is read here, x[i0 + r*step] and x[i0 + r*step + d], and read AGAIN by a pending lane: nothing but the dot products
 // stays in registers for the rare case)
-template <bool UNIFORM_W, bool KEEP_DX, int R>
+template <bool UNIFORM_W, bool KEEP_DX, int R, bool COUNTING>
 __device__ __forceinline__ void consider_cells(Lead& best, const double* x, int i0, int step, int d,
                                                double inv_d, double dd, const DepthRule& rule, double overshoot,
                                                const double (&A)[R], const double (&B)[R], int k, unsigned int& n_eval,
@@ -1692,7 +1692,7 @@ __device__ __forceinline__ void consider_cells(Lead& best, const double* x, int 
         const double m_fast = dX * inv_d;
         const bool live = m_fast > hi;
         pending |= !live && m_fast >= lo;
-        n_fast += live ? 1u : 0u;
+        if constexpr (COUNTING) n_fast += live ? 1u : 0u;
         const double rs_f = 2.0 * (m_fast * overshoot);            // (the same expressions as consider)
         const double stat_f = rs_f * (rs_f * A[r] - 2.0 * B[r]);
         const double reach = rule.reach * fabs(best.stat);
@@ -2882,7 +2882,10 @@ __device__ __forceinline__ bool fold_sort_cumsum_tiled(const double* t, const do
 }
 
 typedef const __attribute__((address_space(4))) SearchArgs* args_ptr;
-template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false>
+// COUNTING: the instantiation that can report evaluated cells, template taps and issued FMAs (tls_execute(ctx, 1)); the
+// plain one does not keep the counters at all (-1.4 % on config 2: two VALU instructions per window and a 64-bit
+// multiply per batch that nobody reads).
+template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false, bool COUNTING = true>
 __global__ void __launch_bounds__(TLS_LAUNCH_THREADS, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs) {
     // The arguments are read through a pointer to the kernel-argument segment, where they are used (scalar loads the
@@ -3884,7 +3887,7 @@ tls_search_kernel(const SearchArgs) {
                 const int unit = have ? (int)active_list[list_base + (relisted ? n_live : 0) + slot] : 0;
                 const const_f64_ptr q = q_all + q_offset;
                 const unsigned int evals_before = n_eval;
-                if (ap->counters) {   // what the loops below issue per lane, padding and idle lanes included
+                if (COUNTING && ap->counters) {   // what the loops below issue per lane, padding and idle lanes included
                     const int reach = (tiled && !relisted) ? (kR - 1) * xth : 0;
                     n_issued += (unsigned long long)((L + reach + kU - 1) / kU * kU) * (reach ? kR : 1) * (UNIFORM_W ? 1 : 2);
                 }
@@ -3925,7 +3928,7 @@ tls_search_kernel(const SearchArgs) {
                         for (int r = 0; r < kR; ++r) Av[r] = sum_q2;
                     }
                     if (have)
-                        consider_cells<UNIFORM_W, !RESIDENT, kR>(lead, c_base, b, xth, d, inv_d, dd, rule, overshoot, Av, Bv, k, n_eval, undecided, widths_c, regB);
+                        consider_cells<UNIFORM_W, !RESIDENT, kR, COUNTING>(lead, c_base, b, xth, d, inv_d, dd, rule, overshoot, Av, Bv, k, n_eval, undecided, widths_c, regB);
                 } else {
                     // wide T0 strides and re-listed sparse rows: one window per lane
                     if (!RESIDENT && widths_c[k].oversize) {
@@ -3994,7 +3997,7 @@ tls_search_kernel(const SearchArgs) {
                     }
                     if (have) consider<UNIFORM_W, !RESIDENT>(lead, c_base[i], c_base[i + d], i, inv_d, dd, rule, overshoot, A0 + A1, B0 + B1, k, n_eval, undecided, widths_c, regB);
                 }
-                n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
+                if constexpr (COUNTING) n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
             }
         }
         pc.mark(7);
@@ -4050,7 +4053,7 @@ tls_search_kernel(const SearchArgs) {
             ap->out_row[o] = row;
             ap->out_depth[o] = depth;
         }
-        if (ap->counters) {
+        if (COUNTING && ap->counters) {
 #pragma unroll
             for (int delta = kWave / 2; delta > 0; delta >>= 1) {
                 n_eval += __shfl_down(n_eval, delta, kWave);     // (a wave's cells of one period: far below 2^32)
