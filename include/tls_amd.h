@@ -113,11 +113,14 @@ int tls_prepare(tls_ctx *ctx, const double *t, const double *y, const double *dy
  * survey mode streams many light curves through one prepared plan. */
 int tls_update_flux(tls_ctx *ctx, const double *y, const double *dy);
 /* execute: enqueue the search kernels on the context's stream (asynchronous).
- * count_work & 1 also accumulates evaluated_cells/inner_steps (slower: counting means evaluating
- * every cell that passes the depth predicate, so the pruning kernel variant is not used). */
+ * count_work & 1 also accumulates evaluated_cells/inner_steps (slower: a kernel instantiation of its own keeps
+ * the counters -- the plain one does not carry them --, and counting means evaluating every cell that passes
+ * the depth predicate, so the pruning kernel variant is not used). */
 int tls_execute(tls_ctx *ctx, int count_work);
 /* developer instrumentation: tls_execute(ctx, 2) makes thread 0 of every workgroup stamp
- * the shader clock at phase boundaries; this returns the per-phase cycle sums (up to 26 slots:
+ * the shader clock at phase boundaries -- in the instrumented and the checked library (make clocks / make debug;
+ * the shipped library compiles the clock marks out and reports zeros for them, the statistics slots stay);
+ * this returns the per-phase cycle sums (up to 26 slots:
  * fold+count, scan, scatter, rank, gather+patch, cumsum, batch prefix, chi2, e-convert,
  * strided predicate, two event counters (cumsum blocks, cumsum fallbacks), tile staging,
  * dense predicate, six cumsum sub-phases, two barrier waits, four pruning steps; names in
