@@ -317,7 +317,7 @@ def noisy_variant(ctx, name, sigma, reps):
             "evaluated_fraction": c["evaluated_cells"] / c["grid_cells"], "inner_steps": c["inner_steps"]}
 
 
-def large_config(ctx, name, reps):
+def large_config(ctx, name, reps, warm=0):
     """Kernel time of one of the HBM-staged configurations (Kepler 4 yr, TESS 27 d) at its full
     grid, with its own HBM roofline: algorithmic bytes = periods x (24 N + 24) B."""
     t, flux, kw = synthetic.config(name, seed=0)
@@ -334,6 +334,8 @@ def large_config(ctx, name, reps):
     info = ctx.plan_info()
     ctx.execute()
     chi2 = ctx.fetch()[0]
+    for _ in range(warm):   # (a short kernel right after host planning finds the clocks down: same ramp as the headline's)
+        ctx.execute()
     ms = ctx.execute_timed(reps)
     n, n_per = len(inp["t"]), len(inp["periods"])
     algo = n_per * (24 * n + 24)
@@ -522,9 +524,9 @@ def main():
 
         other = {}
         if extras and args.config == "k2_90d":
-            for name, reps, noisy_sigma in (("tess_27d", 5, 1000e-6), ("kepler_4yr", 2, 500e-6)):
+            for name, reps, noisy_sigma in (("tess_27d", 30, 1000e-6), ("kepler_4yr", 2, 500e-6)):
                 try:
-                    other[name] = large_config(ctx, name, reps)
+                    other[name] = large_config(ctx, name, reps, warm=10 if name == "tess_27d" else 0)
                     other[name]["noisy_variant"] = noisy_variant(ctx, name, noisy_sigma, 1 if name == "kepler_4yr" else 3)
                 except Exception as exc:
                     other.setdefault(name, {})["error"] = str(exc)[:300]
