@@ -173,6 +173,19 @@ def test_period_order_invariance_and_determinism(gpu):
         numpy.testing.assert_array_equal(x[lo:hi], y)
 
 
+@pytest.mark.parametrize("name,stride", [("k2_90d", 1), ("tess_27d", 8), ("kepler_4yr", 900)])
+def test_plain_and_counting_kernels_agree_bit_for_bit(gpu, name, stride):
+    """A search that counts its work (count_work: evaluated cells, template taps) runs an instantiation of the kernel of
+    its own; what it reports is what the plain instantiation reports, bit for bit (LDS-resident and HBM-slab variants)."""
+    inp = _inputs(name)
+    p = inp["periods"][::stride]
+    counted = gpu.search(inp["t"], inp["y"], inp["dy"], p, inp["table"], inp["params"], count_work=True)
+    plain = gpu.search(inp["t"], inp["y"], inp["dy"], p, inp["table"], inp["params"])
+    for x, y in zip(counted[:3], plain[:3]):
+        numpy.testing.assert_array_equal(x, y)
+    assert counted[3]["evaluated_cells"] > 0 and counted[3]["inner_steps"] > counted[3]["evaluated_cells"]
+
+
 def test_chi2_bounds_and_flat_light_curve(gpu):
     """chi2 <= N everywhere; a light curve with nothing deeper than transit_depth_min
     returns exactly N, depth 0 (core.py:46-48; tests/test_transit_depth_min.py:62-70)."""
