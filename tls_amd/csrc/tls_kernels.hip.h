@@ -289,6 +289,9 @@ __device__ __forceinline__ void vmem_wait_all() {
 #ifndef TLS_SLAB_DMA
 #define TLS_SLAB_DMA 1
 #endif
+#ifndef TLS_STRIDED_TICKETS
+#define TLS_STRIDED_TICKETS 1   // strided rows of the depth predicate go to the waves through a ticket counter
+#endif
 #ifndef TLS_FOLD_DEPTH
 #define TLS_FOLD_DEPTH 3     // time stamps a thread folds per step
 #endif
@@ -3104,6 +3107,7 @@ tls_search_kernel(const SearchArgs) {
         const int n_rows = k_hi - k_lo;
         TLS_CHECK(*ap, 0 <= k_lo && k_lo <= k_x && k_x <= k_hi && k_hi <= ap->n_widths, kChkWorkItem);
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
+        if (tid == 0) s_work[3] = 0;   // ticket counter of the strided rows (phase 3a), published the same way
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup -- or, in fast mode,
         // e = 1 - f and its plain prefix sum X in one pass (depth_pass explains why that decides the same cells)
         if constexpr (RESIDENT) {
@@ -3269,6 +3273,7 @@ tls_search_kernel(const SearchArgs) {
                 c_base = tile_e - p_lo;
             }
             for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;
+            if (tid == 0) s_work[3] = 0;
             __syncthreads();
             pc.mark(12);
         }
@@ -3379,7 +3384,17 @@ tls_search_kernel(const SearchArgs) {
         // stride allows the tiled dot product, else one position per lane
         // (one row per wave: rows are independent, and a row of a few hundred units would leave
         // most waves idle if all of them walked it together)
+#if TLS_STRIDED_TICKETS
+        // (rows are handed out through a ticket counter, most positions first: a wave that is done with its dense tiles
+        // or with a short row takes the next one)
+        for (;;) {
+            int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(&s_work[3], 1);
+            const int k = (k_x > k_lo ? k_x : k_lo) + __builtin_amdgcn_readfirstlane(ticket);
+            if (k >= k_hi) break;
+#else
         for (int k = (k_x > k_lo ? k_x : k_lo) + wave; k < k_hi; k += nw) {
+#endif
             const int d = widths_c[k].width, xth = widths_c[k].xth, n_pos = widths_c[k].n_pos;
             const int n_units = widths_c[k].n_chunks;
             const double inv_d = widths_c[k].inv_d;
