@@ -76,7 +76,7 @@ struct View {
 // parameters and developer switches only replaces the flux (the search call of a survey, or of repeated power()
 // calls).  Compared byte for byte (memcmp runs at ~10 GB/s; a cfg2 key is 120 KB).
 struct PlanLayout {   // byte offsets of the plan arrays inside d_plan / h_stage (256-byte aligned)
-    size_t t = 0, y = 0, w = 0, periods = 0, order = 0, rows = 0, widths = 0, screens = 0, q = 0, q2 = 0, total = 0;
+    size_t t = 0, y = 0, w = 0, periods = 0, order = 0, rows = 0, widths = 0, screens = 0, q = 0, q2 = 0, tile_prefix = 0, total = 0;
 };
 
 struct PlanKey {
@@ -142,6 +142,15 @@ struct tls_ctx {
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
     DevBuf<double> d_spec;                                         // SDE spectra: SR | power_raw | power | sde[2] | chi2 copy
     size_t list_stride = 0;
+    // two-kernel slab path (series in HBM, one light curve): fold kernel + search kernel per batch of periods
+    bool split = false;                      // the plan supports it (enqueue uses it for single-curve launches)
+    int split_blocks = 0;                    // workgroups of its launches (not capped by the number of periods: tiles are items too)
+    int split_batch = 0;                     // periods per batch: as many slabs are held in HBM
+    int64_t split_max_items = 0;             // most (period, tile) items of any batch
+    View<unsigned int> d_tile_prefix;        // [n_periods + 1] tiles in front of work item w (queue order)
+    std::vector<unsigned int> host_tile_prefix;
+    DevBuf<double> d_partials;               // [split_max_items][3] a tile's winner
+    DevBuf<unsigned int> d_tiles_done;       // [split_batch] tiles of the period that are done (zero between launches)
     int hdr_bytes = 0, tile_len = 0, tile_halo = 0, region_pad = 0, p2_shift = 4;
     bool prune_kernel = false;        // launch the pruning variant (pruning_pays)
     std::vector<tlsdev::WidthEntry> host_widths;  // kept for tls_update_flux's pruning decision
@@ -210,7 +219,7 @@ int stage_reserve(tls_ctx* ctx, size_t bytes) {
 
 std::string plan_env() {   // developer switches that change the plan
     std::string e;
-    for (const char* name : {"TLS_PRUNE", "TLS_PRUNE_MIN_LIVE", "TLS_SORT2", "TLS_SORT3", "TLS_THREADS", "TLS_BLOCKS", "TLS_STAGE_C", "TLS_SLAB_WGS"}) {
+    for (const char* name : {"TLS_PRUNE", "TLS_PRUNE_MIN_LIVE", "TLS_SORT2", "TLS_SORT3", "TLS_THREADS", "TLS_BLOCKS", "TLS_STAGE_C", "TLS_SLAB_WGS", "TLS_SPLIT", "TLS_SPLIT_BATCH"}) {
         const char* v = std::getenv(name);
         e += v ? v : "-";
         e += '|';
@@ -579,23 +588,28 @@ void order_by_cost(const std::vector<int64_t>& cost, std::vector<int>& order) {
     for (size_t p = 0; p < np; ++p) order[p] = (int)(key[p] & 0x7fffffffull);
 }
 
-template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false, bool COUNTING = false>
-hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args) {
-    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING, COUNTING>;
+template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false, bool COUNTING = false, int ROLE = tlsdev::kRoleAll>
+hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args, int blocks) {
+    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING, COUNTING, ROLE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)ctx->threads), ctx->lds_bytes,
+                       ctx->stream, args);
+    return hipGetLastError();
+}
+
+// the event pair around one search (tls_kernel_timing adds them up): one kernel, or the fold + search kernels of all
+// batches of the two-kernel slab path
+hipError_t timing_pair(tls_ctx* ctx, std::pair<hipEvent_t, hipEvent_t>** out) {
     if (ctx->ev_pool.size() < kEventRing) {   // a ring: a long-lived survey process never grows it
         hipEvent_t a, b;
+        hipError_t e;
         if ((e = hipEventCreate(&a)) != hipSuccess || (e = hipEventCreate(&b)) != hipSuccess) return e;
         ctx->ev_pool.emplace_back(a, b);
     }
-    auto& evp = ctx->ev_pool[ctx->ev_used++ % kEventRing];
-    if ((e = hipEventRecord(evp.first, ctx->stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->blocks), dim3((unsigned)ctx->threads), ctx->lds_bytes,
-                       ctx->stream, args);
-    if ((e = hipEventRecord(evp.second, ctx->stream)) != hipSuccess) return e;
-    return hipGetLastError();
+    *out = &ctx->ev_pool[ctx->ev_used++ % kEventRing];
+    return hipSuccess;
 }
 
 int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* debug_folded = nullptr, double* debug_prefix = nullptr,
@@ -659,22 +673,53 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.perm_scratch = ctx->d_perm.ptr;
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
+    a.batch_lo = 0; a.batch_n = 0; a.tile_prefix = ctx->d_tile_prefix.ptr;
+    a.partials = ctx->d_partials.ptr; a.tiles_done = ctx->d_tiles_done.ptr;
     hipError_t e;
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    if ((e = timing_pair(ctx, &evp)) != hipSuccess || (e = hipEventRecord(evp->first, ctx->stream)) != hipSuccess)
+        return fail(ctx, TLS_E_HIP, std::string("timing events: ") + hipGetErrorString(e));
     // pruning variant: uniform weights, noisy enough that most trial cells pass the depth predicate,
     // and not while the evaluated cells are being counted (counting means evaluating all of them)
     const bool prune = ctx->uniform_w && ctx->prune_kernel && !count_work;
     // (counting has an instantiation of its own: the plain kernels do not keep the counters)
-#define TLS_LAUNCH(RES, STAGE, IDX)                                                                               \
-    (!ctx->uniform_w ? (count_work ? launch_variant<RES, false, STAGE, IDX, false, true>(ctx, a)                    \
-                                   : launch_variant<RES, false, STAGE, IDX, false, false>(ctx, a))                   \
-     : prune         ? launch_variant<RES, true, STAGE, IDX, true, false>(ctx, a)                                    \
-     : count_work    ? launch_variant<RES, true, STAGE, IDX, false, true>(ctx, a)                                    \
-                     : launch_variant<RES, true, STAGE, IDX, false, false>(ctx, a))
-    if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short);
-    else if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int);
-    else e = TLS_LAUNCH(false, false, unsigned int);
+#define TLS_LAUNCH(RES, STAGE, IDX, ROLE, BLOCKS)                                                                   \
+    (!ctx->uniform_w ? (count_work ? launch_variant<RES, false, STAGE, IDX, false, true, ROLE>(ctx, a, BLOCKS)              \
+                                   : launch_variant<RES, false, STAGE, IDX, false, false, ROLE>(ctx, a, BLOCKS))             \
+     : prune         ? launch_variant<RES, true, STAGE, IDX, true, false, ROLE>(ctx, a, BLOCKS)                              \
+     : count_work    ? launch_variant<RES, true, STAGE, IDX, false, true, ROLE>(ctx, a, BLOCKS)                              \
+                     : launch_variant<RES, true, STAGE, IDX, false, false, ROLE>(ctx, a, BLOCKS))
+    const bool split = !ctx->resident && ctx->split && ctx->batch_curves == 1;
+    if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short, tlsdev::kRoleAll, ctx->blocks);
+    else if (!split) {
+        if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int, tlsdev::kRoleAll, ctx->blocks);
+        else e = TLS_LAUNCH(false, false, unsigned int, tlsdev::kRoleAll, ctx->blocks);
+    } else {
+        // series in the HBM slab, one light curve: per batch of periods the fold kernel (fold, stable sort, exact prefix
+        // sum -> one slab per period) and the search kernel over the (period, tile) items of those slabs
+        e = hipSuccess;
+        int only = 0;   // developer switch: 1 = fold kernels only, 2 = search kernels only (on whatever the slabs hold)
+        if (const char* env = std::getenv("TLS_SPLIT_ONLY")) only = std::atoi(env);
+        for (int lo = 0; lo < ctx->n_periods && e == hipSuccess; lo += ctx->split_batch) {
+            a.batch_lo = lo; a.batch_n = std::min(ctx->split_batch, ctx->n_periods - lo);
+            a.queue = ctx->d_squeue.ptr;
+            const int fold_blocks = std::min(ctx->split_blocks, a.batch_n);
+            if (only != 2)
+                e = ctx->uniform_w ? launch_variant<false, true, false, unsigned int, false, false, tlsdev::kRoleFold>(ctx, a, fold_blocks)
+                                   : launch_variant<false, false, false, unsigned int, false, false, tlsdev::kRoleFold>(ctx, a, fold_blocks);
+            if (e != hipSuccess) break;
+            if (only == 1) continue;
+            a.queue = ctx->d_squeue.ptr + 2;
+            const int64_t items = (int64_t)ctx->host_tile_prefix[(size_t)(lo + a.batch_n)] - (int64_t)ctx->host_tile_prefix[(size_t)lo];
+            const int search_blocks = (int)std::min<int64_t>(ctx->split_blocks, std::max<int64_t>(items, 1));
+            if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int, tlsdev::kRoleSearch, search_blocks);
+            else e = TLS_LAUNCH(false, false, unsigned int, tlsdev::kRoleSearch, search_blocks);
+        }
+    }
 #undef TLS_LAUNCH
     if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if ((e = hipEventRecord(evp->second, ctx->stream)) != hipSuccess)
+        return fail(ctx, TLS_E_HIP, std::string("timing events: ") + hipGetErrorString(e));
     ctx->executed = true;
     ctx->counted = count_work;
     return TLS_OK;
@@ -780,7 +825,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     if (ctx->ev_stage) (void)hipEventDestroy(ctx->ev_stage);
     ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release();
-    ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
+    ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     for (auto& sl : ctx->slot) {
         sl.d_y.release(); sl.d_w.release(); sl.d_S0.release(); sl.d_w0.release(); sl.d_chi2.release(); sl.d_depth.release(); sl.d_row.release();
@@ -1009,11 +1054,45 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // TLS_SORT3=1 selects this path; both are tested.)
         ctx->sort3 = sort3_bytes <= lds_budget && tlsdev::sort3_bins((int)n) <= tlsdev::kSort3MaxBins && (int64_t)W <= n &&
                      (env_sort3 ? std::atoi(env_sort3) != 0 : false);
+        // Two-kernel slab path: the periods go through the fold kernel and the search kernel in batches;
+        // a batch holds one slab per period in HBM.  Batch size: as many periods as fit `kSplitSlabBytes` (at least four
+        // rounds of workgroups), all of them when the grid is small.  TLS_SPLIT=0 keeps the one-kernel path (A/B, tests).
+        ctx->split_blocks = ctx->n_cu * slab_wgs;
+        if (const char* env = std::getenv("TLS_BLOCKS")) ctx->split_blocks = std::max(1, std::min(ctx->split_blocks, std::atoi(env)));
+        {
+            const char* env_split = std::getenv("TLS_SPLIT");
+            ctx->split = !(env_split && std::atoi(env_split) == 0) && n_periods > 0;
+            const size_t slab_bytes = regions * ((region_doubles + 1) & ~(size_t)1) * 8;
+            constexpr size_t kSplitSlabBytes = (size_t)12 << 30;
+            int64_t batch = std::max<int64_t>((int64_t)(kSplitSlabBytes / slab_bytes), (int64_t)4 * ctx->split_blocks);
+            if (const char* env = std::getenv("TLS_SPLIT_BATCH")) batch = std::max<int64_t>(1, std::atoll(env));
+            ctx->split_batch = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), batch);
+            ctx->host_tile_prefix.assign((size_t)n_periods + 1, 0u);
+            ctx->split_max_items = 0;
+            if (ctx->split) {
+                for (int64_t wk = 0; wk < n_periods; ++wk) {
+                    const tlsdev::PeriodRows& pr = prow[(size_t)order[(size_t)wk]];
+                    const size_t tl = pr.pad > 0 ? (size_t)pr.pad : tile;      // the kernel's tile length of this period
+                    ctx->host_tile_prefix[(size_t)wk + 1] = ctx->host_tile_prefix[(size_t)wk] + (unsigned int)(((size_t)M + tl - 1) / tl);
+                }
+                for (int64_t lo = 0; lo < n_periods; lo += ctx->split_batch) {
+                    const int64_t hi = std::min<int64_t>(n_periods, lo + ctx->split_batch);
+                    ctx->split_max_items = std::max<int64_t>(ctx->split_max_items, (int64_t)ctx->host_tile_prefix[(size_t)hi] - (int64_t)ctx->host_tile_prefix[(size_t)lo]);
+                }
+                TLS_HIP(ctx, ctx->d_partials.reserve(3 * (size_t)ctx->split_max_items + 3));
+                if (ctx->d_tiles_done.cap < (size_t)ctx->split_batch) {
+                    TLS_HIP(ctx, ctx->d_tiles_done.reserve((size_t)ctx->split_batch));
+                    TLS_HIP(ctx, hipMemsetAsync(ctx->d_tiles_done.ptr, 0, ctx->d_tiles_done.cap * sizeof(unsigned int), ctx->stream));
+                }
+            }
+        }
+        const size_t scratch_blocks = std::max<size_t>((size_t)ctx->blocks, ctx->split ? (size_t)ctx->split_batch : 0);
+        const size_t wg_blocks = std::max<size_t>((size_t)ctx->blocks, ctx->split ? (size_t)ctx->split_blocks : 0);
         if (ctx->sort3) {
             ctx->lds_bytes = std::max(ctx->lds_bytes, sort3_bytes);
-            TLS_HIP(ctx, ctx->d_sort3.reserve((size_t)ctx->blocks * (size_t)tlsdev::sort3_scratch_doubles((int)n)));
+            TLS_HIP(ctx, ctx->d_sort3.reserve(wg_blocks * (size_t)tlsdev::sort3_scratch_doubles((int)n)));
         }
-        TLS_HIP(ctx, ctx->d_scratch.reserve((size_t)ctx->blocks * regions * (region_doubles + 1) + 16));
+        TLS_HIP(ctx, ctx->d_scratch.reserve(scratch_blocks * regions * (region_doubles + 1) + 16));
     }
     // per-width work units of phase 3 (M is fixed for the plan, so these are period independent)
     // and the layout of one workgroup's live-unit lists: every unit of every width has a slot
@@ -1029,7 +1108,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     }
     ctx->list_stride = (list_cap + 63) / 64 * 64;
     // three arrays per workgroup: the live units, (pruning) the bound of each, and the units the bound keeps
-    TLS_HIP(ctx, ctx->d_lists.reserve((size_t)ctx->blocks * 3 * ctx->list_stride));
+    TLS_HIP(ctx, ctx->d_lists.reserve((size_t)std::max(ctx->blocks, (!ctx->resident && ctx->split) ? ctx->split_blocks : 0) * 3 * ctx->list_stride));
     if (const char* env = std::getenv("TLS_PRUNE_MIN_LIVE")) ctx->prune_min_live = std::atoll(env);
     ctx->p2_shift = 4;  // block length of the coarse prefix sum of e^2: at most kP2MaxBlocks blocks
     while ((((size_t)M + ((size_t)1 << ctx->p2_shift) - 1) >> ctx->p2_shift) > (size_t)tlsdev::kP2MaxBlocks) ++ctx->p2_shift;
@@ -1054,6 +1133,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         L.periods = place(np * 8); L.order = place(np * sizeof(int)); L.rows = place(np * sizeof(tlsdev::PeriodRows));
         L.widths = place(nw * sizeof(tlsdev::WidthEntry)); L.screens = place(nw * sizeof(tlsdev::RowScreen));
         L.q = place(nq * 8); L.q2 = place(uniform ? 0 : nq * 8);
+        const bool with_tiles = !ctx->resident && ctx->split;
+        L.tile_prefix = place(with_tiles ? (np + 1) * sizeof(unsigned int) : 0);
         L.total = off;
         int rcs = stage_reserve(ctx, L.total);
         if (rcs) return rcs;
@@ -1074,7 +1155,9 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             double* q2 = reinterpret_cast<double*>(h + L.q2);
             for (size_t j = 0; j < nq; ++j) q2[j] = q[j] * q[j];
         }
+        if (with_tiles) std::memcpy(h + L.tile_prefix, ctx->host_tile_prefix.data(), (np + 1) * sizeof(unsigned int));
         unsigned char* d = ctx->d_plan.ptr;
+        ctx->d_tile_prefix.ptr = reinterpret_cast<unsigned int*>(d + L.tile_prefix);
         ctx->d_t.ptr = reinterpret_cast<double*>(d + L.t); ctx->d_y.ptr = reinterpret_cast<double*>(d + L.y);
         ctx->d_w.ptr = reinterpret_cast<double*>(d + L.w); ctx->d_periods.ptr = reinterpret_cast<double*>(d + L.periods);
         ctx->d_order.ptr = reinterpret_cast<int*>(d + L.order); ctx->d_rows.ptr = reinterpret_cast<tlsdev::PeriodRows*>(d + L.rows);
@@ -1092,8 +1175,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     }
     TLS_HIP(ctx, ctx->d_queue.reserve(1));
     if (!ctx->d_squeue.ptr) {   // zero once per context: the kernel rewinds its queue itself
-        TLS_HIP(ctx, ctx->d_squeue.reserve(2));
-        TLS_HIP(ctx, hipMemsetAsync(ctx->d_squeue.ptr, 0, 2 * sizeof(unsigned int), ctx->stream));
+        TLS_HIP(ctx, ctx->d_squeue.reserve(4));   // [0..1] the search (or fold) kernel's queue, [2..3] the split path's search kernel
+        TLS_HIP(ctx, hipMemsetAsync(ctx->d_squeue.ptr, 0, 4 * sizeof(unsigned int), ctx->stream));
     }
     key_store(ctx->key, t, n, periods, n_periods, tmpl, params);
     ctx->prepared = true;

@@ -528,6 +528,15 @@ struct SearchArgs {
     int tile_len;           // non-resident: window-start positions per LDS tile (multiple of 320)
     int tile_halo;          // non-resident: samples staged behind a tile (widest window + slack)
     int region_pad;         // spare entries behind every folded-series region (region_pad_for)
+    // two-kernel slab path (kRoleFold / kRoleSearch): the periods order[batch_lo .. batch_lo + batch_n) of one batch; the
+    // folded series of work item w lives in slab w - batch_lo.  The search kernel's items are (period, position tile)
+    // pairs: tile_prefix[w] = tiles of all work items in front of w (in queue order), item g of the batch is tile
+    // tile_prefix[batch_lo] + g.  A tile's winner goes to partials[g]; the workgroup that finishes a period's last tile
+    // (tiles_done[slot]) compares them and writes the period's result.
+    int batch_lo, batch_n;
+    const unsigned int* tile_prefix;   // [n_periods + 1]
+    double* partials;                  // [items of the largest batch][3]: stat | td | (k, i)
+    unsigned int* tiles_done;          // [periods of the largest batch], zero between launches
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period, double epoch) {
@@ -2888,9 +2897,18 @@ typedef const __attribute__((address_space(4))) SearchArgs* args_ptr;
 // COUNTING: the instantiation that can report evaluated cells, template taps and issued FMAs (tls_execute(ctx, 1)); the
 // plain one does not keep the counters at all (-1.4 % on config 2: two VALU instructions per window and a 64-bit
 // multiply per batch that nobody reads).
-template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false, bool COUNTING = true>
+// ROLE (series in the HBM slab, one light curve): kRoleAll = one workgroup takes a period from the fold to the argmin (the
+// LDS-resident kernel; survey batches on long series).  kRoleFold = phases 1-2 only, one period per work item, the slab
+// of every period of the batch left in HBM; kRoleSearch = phases 3-4 over (period, position tile) work items of those
+// slabs.  Two kernels instead of one: each gets its own register allocation (the fold's sort and exact prefix sum no
+// longer share 128 registers with the dot products), and a period is searched by as many workgroups as it has tiles --
+// a rank of an 8-GPU job that holds 300 periods still fills 256 CUs.  The cells, their values and the comparison are
+// the same code, so the results are the same bits.
+enum { kRoleAll = 0, kRoleFold = 1, kRoleSearch = 2 };
+template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false, bool COUNTING = true, int ROLE = kRoleAll>
 __global__ void __launch_bounds__(TLS_LAUNCH_THREADS, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs) {
+    static_assert(ROLE == kRoleAll || !RESIDENT, "the LDS-resident series is searched by one workgroup per period");
     // The arguments are read through a pointer to the kernel-argument segment, where they are used (scalar loads the
     // compiler may repeat), not taken by value: ~100 values loaded at entry compete for 104 scalar registers for the
     // whole kernel, and the losers live in spilled lanes of a vector register and come back one v_readlane -- a VALU
@@ -2932,7 +2950,7 @@ tls_search_kernel(const SearchArgs) {
         if constexpr (!UNIFORM_W) regW = regB + RS;
         cnt = reinterpret_cast<unsigned int*>(regB);
     } else {
-        double* slab = ap->scratch + (long long)blockIdx.x * ap->scratch_stride;
+        double* slab = ap->scratch + (long long)blockIdx.x * ap->scratch_stride;   // (split roles: the work item's slab, below)
         regA = slab;
         regB = regA + RS;
         if constexpr (!UNIFORM_W) regW = regB + RS;
@@ -2951,9 +2969,11 @@ tls_search_kernel(const SearchArgs) {
         TLS_CHECK(*ap, (long long)kFixedHeader + 4LL * (3 * ap->n_widths + 2) <= ap->hdr_bytes, kChkLdsCarve);
     }
     // the spare entries behind each region are only ever multiplied by zero: make them finite
-    for (int k = tid; k < region_pad; k += nt) {
-        regA[M + 1 + k] = 0.0;
-        if constexpr (!UNIFORM_W) regW[M + 1 + k] = 0.0;
+    if constexpr (ROLE == kRoleAll) {
+        for (int k = tid; k < region_pad; k += nt) {
+            regA[M + 1 + k] = 0.0;
+            if constexpr (!UNIFORM_W) regW[M + 1 + k] = 0.0;
+        }
     }
 
     const const_width_ptr widths_c = (const_width_ptr)ap->widths;  // read-only for the whole launch
@@ -2977,11 +2997,17 @@ tls_search_kernel(const SearchArgs) {
         }
         int flag_slot = 1;   // the "undecided" flag of the attempt in flight: s_work[1] and s_work[2] take turns
         // exact mode: X = k - numpy.cumsum, bit for bit; fast mode: X = plain prefix sum of 1 - f (depth_pass)
-        const bool period_exact = (!RESIDENT && (ap->fast_slab == 0 || ap->sort3 != 0)) || retry_exact || ap->exact_prefix != 0 ||
-                                  ap->debug_prefix != nullptr;
+        // (the two-kernel slab path has no second attempt: its fold kernel always leaves X = k - numpy.cumsum)
+        const bool period_exact = (!RESIDENT && (ROLE != kRoleAll || ap->fast_slab == 0 || ap->sort3 != 0)) || retry_exact ||
+                                  ap->exact_prefix != 0 || ap->debug_prefix != nullptr;
         retry_exact = false;
         bool curve_exact = false;   // batches: this light curve again in exact mode (the permutation is kept: no new sort)
-        if (work >= ap->n_periods) {
+        // split roles: `work` counts the items of this launch -- the periods of the batch (fold), their tiles (search)
+        int n_work = ap->n_periods;
+        [[maybe_unused]] int item = 0, item_tile = 0;
+        if constexpr (ROLE == kRoleFold) n_work = ap->batch_n;
+        if constexpr (ROLE == kRoleSearch) n_work = (int)(ap->tile_prefix[ap->batch_lo + ap->batch_n] - ap->tile_prefix[ap->batch_lo]);
+        if (work >= n_work) {
             // the last workgroup to leave rewinds the queue for the next launch (no memset between
             // two searches of a prepared plan); queue[1] counts the workgroups that are done
             if (tid == 0) {
@@ -2989,6 +3015,28 @@ tls_search_kernel(const SearchArgs) {
                 if (atomicAdd(ap->queue + 1, 1u) == gridDim.x - 1) { atomicExch(ap->queue, 0u); atomicExch(ap->queue + 1, 0u); }
             }
             break;
+        }
+        if constexpr (ROLE == kRoleFold) {
+            regA = ap->scratch + (long long)work * ap->scratch_stride;   // the slab of this period of the batch
+            regB = regA + RS;
+            if constexpr (!UNIFORM_W) regW = regB + RS;
+            idx_tmp = reinterpret_cast<IdxT*>(regB); perm = idx_tmp + n; ph_orig = regA;
+            work += ap->batch_lo;
+        }
+        if constexpr (ROLE == kRoleSearch) {
+            // item -> (period of the batch, tile): the last w with tile_prefix[w] <= G (scalar loads, ~log2(batch) steps)
+            item = work;
+            const unsigned int G = ap->tile_prefix[ap->batch_lo] + (unsigned int)work;
+            int lo_w = ap->batch_lo, hi_w = ap->batch_lo + ap->batch_n;   // tile_prefix[lo_w] <= G < tile_prefix[hi_w]
+            while (hi_w - lo_w > 1) {
+                const int mid = (lo_w + hi_w) >> 1;
+                if (ap->tile_prefix[mid] <= G) lo_w = mid; else hi_w = mid;
+            }
+            work = __builtin_amdgcn_readfirstlane(lo_w);
+            item_tile = (int)(G - ap->tile_prefix[work]);
+            regA = ap->scratch + (long long)(work - ap->batch_lo) * ap->scratch_stride;
+            regB = regA + RS;
+            if constexpr (!UNIFORM_W) regW = regB + RS;
         }
         const int p = ap->order[work];
         TLS_CHECK(*ap, p >= 0 && p < ap->n_periods, kChkWorkItem);
@@ -3001,7 +3049,7 @@ tls_search_kernel(const SearchArgs) {
         // ---- phase 1: fold + stable sort by phase ----------------------------------
         bool sorted = false;
         bool fused = false;   // fold, sort, gather AND prefix sum done by fold_sort_cumsum_tiled
-        if constexpr (!RESIDENT) {
+        if constexpr (!RESIDENT && ROLE != kRoleSearch) {
             if (ap->sort3 && ap->n_curves == 1)
                 fused = fold_sort_cumsum_tiled<UNIFORM_W>(ap->t, ap->y, ap->w, n, W, period, regA, regB, regW,
                                                           ap->sort3_scratch + (long long)blockIdx.x * sort3_scratch_doubles(n),
@@ -3024,7 +3072,7 @@ tls_search_kernel(const SearchArgs) {
                 pc.start(ap->phase_cycles);   // (the call kept its own clock)
             }
         }
-        if (!sorted && !fused) {
+        if (ROLE != kRoleSearch && !sorted && !fused) {
             // (piled-up buckets are sorted by the workgroup: their list lives in the idle prefix-sum scratch; the slab
             // variant stages them in the LDS behind its bucket counters, the resident one sorts through the index)
             unsigned int* big_list = reinterpret_cast<unsigned int*>(cumsum_scratch);
@@ -3043,7 +3091,7 @@ tls_search_kernel(const SearchArgs) {
         // survey mode: the permutation depends on (t, period) only, so every light curve of the
         // batch reuses it; it must outlive the prefix sum that overwrites its LDS home
         const IdxT* perm_use = perm;
-        if (ap->n_curves > 1) {
+        if (ROLE == kRoleAll && ap->n_curves > 1) {
             IdxT* perm_g = reinterpret_cast<IdxT*>(ap->perm_scratch + (long long)blockIdx.x * n);
             for (int k = tid; k < n; k += nt) perm_g[k] = perm[k];
             perm_use = perm_g;
@@ -3059,6 +3107,7 @@ tls_search_kernel(const SearchArgs) {
         rule.reach = (rule.dmin - rule.eps > 4e-15) ? fmin(fmax(1e-9, 4e-15 / (rule.dmin - rule.eps)), 1.0) : 1.0;
         bool undecided = false;
         const double* y_c = ap->y + (long long)curve * n;
+        if constexpr (ROLE != kRoleSearch) {
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  kG
         // elements per step: their global reads (L2 latency) are in flight together -- the compiler
         // cannot overlap them itself, the LDS store of one may alias the index read of the next
@@ -3098,6 +3147,7 @@ tls_search_kernel(const SearchArgs) {
         __syncthreads();
         pc.mark(4);
 
+        }   // (search role: the fold kernel has done it)
         // in-range widths of this period: a contiguous range [k_lo, k_hi) of the ascending
         // width table (core.py:148-156); widths below k_x have the dense T0 grid (stride 1).
         // Wave-uniform by construction; say so, or the template taps stop being scalar loads.
@@ -3108,6 +3158,7 @@ tls_search_kernel(const SearchArgs) {
         TLS_CHECK(*ap, 0 <= k_lo && k_lo <= k_x && k_x <= k_hi && k_hi <= ap->n_widths, kChkWorkItem);
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
         if (tid == 0) s_work[3] = 0;   // ticket counter of the strided rows (phase 3a), published the same way
+        if constexpr (ROLE != kRoleSearch) {
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup -- or, in fast mode,
         // e = 1 - f and its plain prefix sum X in one pass (depth_pass explains why that decides the same cells)
         if constexpr (RESIDENT) {
@@ -3197,6 +3248,8 @@ tls_search_kernel(const SearchArgs) {
             __syncthreads();
         }
         pc.mark(5);
+        }   // (search role: X is in the period's slab)
+        if constexpr (ROLE == kRoleFold) continue;   // the slab is complete (one light curve: this leaves the curve loop)
         // exact mode, resident: regB holds C -- now X[k] = k - C[k] (an exact subtraction); e = 1 - f in place (uniform
         // weights) or e*w (general weights).  Fast mode has done both; the tiled variant chunk by chunk above.
         if constexpr (RESIDENT) {
@@ -3224,7 +3277,10 @@ tls_search_kernel(const SearchArgs) {
         // (the slab variant's tile length is the period's own: its halo covers the widest in-range window only)
         const int tile_len_p = RESIDENT ? 0 : __builtin_amdgcn_readfirstlane(rows_c[p].pad);
         const int tile_len = RESIDENT ? (1 << 30) : (tile_len_p > 0 ? tile_len_p : ap->tile_len);
-        for (int p_lo = 0; p_lo < M; p_lo += tile_len) {
+        // (search role: the one tile of this work item)
+        const int p_first = ROLE == kRoleSearch ? item_tile * tile_len : 0;
+        const int p_end = ROLE == kRoleSearch ? p_first + 1 : M;
+        for (int p_lo = p_first; p_lo < p_end; p_lo += tile_len) {
         const int p_hi = p_lo + tile_len;
         const double* e_base = regA;   // e_base[b] = sample b of e (or e*w)
         const double* w_base = regW;
@@ -3454,7 +3510,10 @@ tls_search_kernel(const SearchArgs) {
                 }
             }
             TLS_CHECK(*ap, n_listed <= (unsigned int)widths_c[k].n_chunks, kChkListCap);
-            if (lane == 0) rt.live[k - k_lo] = n_listed;
+            // (every lane stores the same value: a store under `lane == 0` here and the ticket fetch under `lane == 0`
+            // at the loop head were threaded together by the compiler in the search-role instantiation -- lane 0 left
+            // for the next ticket, the other 63 lanes took the row again, for ever)
+            rt.live[k - k_lo] = n_listed;
         }
         __syncthreads();
         pc.mark(9);
@@ -4046,6 +4105,36 @@ tls_search_kernel(const SearchArgs) {
         if (tid == 0) {
             Best g = wbest[0];
             for (int v = 1; v < nw; ++v) if (better(wbest[v], g)) g = wbest[v];
+            bool write_out = true;
+            if constexpr (ROLE == kRoleSearch) {
+                // this tile's winner is published; whoever finishes the period's LAST tile compares the winners of all
+                // of them (the comparison is the reference's total order on (value, width, T0): any order of arrival
+                // gives the same cell).  Agent-scope atomics: the tiles of a period run on different XCDs.
+                typedef unsigned long long u64;
+                const unsigned int tiles_p = ap->tile_prefix[work + 1] - ap->tile_prefix[work];
+                if (tiles_p > 1u) {
+                    u64* mine = reinterpret_cast<u64*>(ap->partials) + 3LL * item;
+                    __hip_atomic_store(mine + 0, (u64)__double_as_longlong(g.stat), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(mine + 1, (u64)__double_as_longlong(g.td), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(mine + 2, ((u64)(unsigned int)g.k << 32) | (u64)(unsigned int)g.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned int* done = ap->tiles_done + (work - ap->batch_lo);
+                    const unsigned int before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    write_out = before == tiles_p - 1u;
+                    if (write_out) {
+                        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next batch
+                        const u64* first = reinterpret_cast<const u64*>(ap->partials) + 3LL * ((long long)item - item_tile);
+                        for (unsigned int j = 0; j < tiles_p; ++j) {
+                            Best o;
+                            o.stat = __longlong_as_double((long long)__hip_atomic_load(first + 3 * j + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            o.td = __longlong_as_double((long long)__hip_atomic_load(first + 3 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            const u64 ki = __hip_atomic_load(first + 3 * j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            o.k = (int)(unsigned int)(ki >> 32); o.i = (int)(unsigned int)ki;
+                            if (better(o, g)) g = o;
+                        }
+                    }
+                }
+            }
+            if (write_out) {
             const double datapoints = (double)n;          // core.py:46 baseline
             double chi2 = INFINITY, depth = 0.0;
             long long row = 0;
@@ -4067,6 +4156,7 @@ tls_search_kernel(const SearchArgs) {
             ap->out_chi2[o] = chi2;
             ap->out_row[o] = row;
             ap->out_depth[o] = depth;
+            }
         }
         if (COUNTING && ap->counters) {
 #pragma unroll
