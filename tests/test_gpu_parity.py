@@ -683,6 +683,44 @@ def test_both_slab_sort_paths_vs_oracle(gpu, oracle_lib, monkeypatch, name, stri
     assert got[3]["inner_steps"] == int(want[3][2])
 
 
+@pytest.mark.parametrize("name,stride,per_point,batch", [("tess_27d", 3, False, None), ("tess_27d", 7, True, "97"),
+                                                         ("kepler_4yr", 300, False, "200"), ("kepler_4yr", 1500, True, None)])
+def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle_lib, monkeypatch, name, stride, per_point, batch):
+    """Series in the HBM slab: the two-role kernel (every workgroup folds periods into per-period slabs, then searches
+    (period, position tile) items; a tile's winner is published and the last tile of a period compares them) against the
+    one-workgroup-per-period kernel -- the same cells, values and tie rule, so chi2, row and depth must be the same BITS and
+    the evaluated-cell and tap counts equal; more rounds than workgroups, several batches of slabs (TLS_SPLIT_BATCH), uniform
+    and per-point weights; and both against the oracle.  (The plan picks the two-role kernel for up to 1.5 rounds of periods;
+    TLS_SPLIT forces either.)"""
+    t, f, kw = synthetic.config(name)
+    dy = None
+    if per_point:
+        dy = numpy.random.RandomState(23).uniform(0.7, 1.6, len(f)) * synthetic.CONFIGS[name][2]
+    inp = synthetic.search_inputs(t, f, dy, **kw)
+    sel = inp["periods"][::stride]
+    if batch:
+        monkeypatch.setenv("TLS_SPLIT_BATCH", batch)
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TLS_SPLIT", mode)
+        counted = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+        assert not gpu.plan_info()["resident"]
+        plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+        again = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])   # flags and queues rewound
+        for a, b in zip(plain[:3], again[:3]):
+            numpy.testing.assert_array_equal(a, b)
+        for a, b in zip(plain[:3], counted[:3]):
+            numpy.testing.assert_array_equal(a, b)
+        results[mode] = counted
+    for a, b in zip(results["0"][:3], results["1"][:3]):
+        numpy.testing.assert_array_equal(a, b)
+    assert results["0"][3]["evaluated_cells"] == results["1"][3]["evaluated_cells"]
+    assert results["0"][3]["inner_steps"] == results["1"][3]["inner_steps"]
+    want = oracle_search(oracle_lib, inp, periods=sel)
+    assert_parity(results["1"], want, len(inp["t"]))
+    assert results["1"][3]["evaluated_cells"] == int(want[3][1])
+
+
 @pytest.mark.parametrize("per_point", [False, True])
 def test_quarter_million_points_vs_oracle(gpu, oracle_lib, per_point):
     """N = 250 560 (174 d at 1-min cadence): the widest trial windows (30 068 samples) are longer than an LDS

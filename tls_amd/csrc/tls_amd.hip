@@ -588,9 +588,21 @@ void order_by_cost(const std::vector<int64_t>& cost, std::vector<int>& order) {
     for (size_t p = 0; p < np; ++p) order[p] = (int)(key[p] & 0x7fffffffull);
 }
 
-template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false, bool COUNTING = false, int ROLE = tlsdev::kRoleAll>
+// the two-role kernel of the slab path (fold role, then search role over (period, tile) items)
+template <bool UNI, bool STAGE_C, bool PRUNING = false, bool COUNTING = false>
+hipError_t launch_split(tls_ctx* ctx, const tlsdev::SearchArgs& args, int blocks) {
+    auto kernel = tlsdev::tls_fold_search_kernel<UNI, STAGE_C, PRUNING, COUNTING>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)ctx->threads), ctx->lds_bytes,
+                       ctx->stream, args);
+    return hipGetLastError();
+}
+
+template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false, bool COUNTING = false>
 hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args, int blocks) {
-    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING, COUNTING, ROLE>;
+    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING, COUNTING>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
@@ -674,7 +686,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
     a.batch_lo = 0; a.batch_n = 0; a.tile_prefix = ctx->d_tile_prefix.ptr;
-    a.partials = ctx->d_partials.ptr; a.tiles_done = ctx->d_tiles_done.ptr;
+    a.partials = ctx->d_partials.ptr; a.tiles_done = ctx->d_tiles_done.ptr; a.fold_ready = ctx->d_tiles_done.ptr + ctx->split_batch;
     hipError_t e;
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
     if ((e = timing_pair(ctx, &evp)) != hipSuccess || (e = hipEventRecord(evp->first, ctx->stream)) != hipSuccess)
@@ -683,39 +695,37 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     // and not while the evaluated cells are being counted (counting means evaluating all of them)
     const bool prune = ctx->uniform_w && ctx->prune_kernel && !count_work;
     // (counting has an instantiation of its own: the plain kernels do not keep the counters)
-#define TLS_LAUNCH(RES, STAGE, IDX, ROLE, BLOCKS)                                                                   \
-    (!ctx->uniform_w ? (count_work ? launch_variant<RES, false, STAGE, IDX, false, true, ROLE>(ctx, a, BLOCKS)              \
-                                   : launch_variant<RES, false, STAGE, IDX, false, false, ROLE>(ctx, a, BLOCKS))             \
-     : prune         ? launch_variant<RES, true, STAGE, IDX, true, false, ROLE>(ctx, a, BLOCKS)                              \
-     : count_work    ? launch_variant<RES, true, STAGE, IDX, false, true, ROLE>(ctx, a, BLOCKS)                              \
-                     : launch_variant<RES, true, STAGE, IDX, false, false, ROLE>(ctx, a, BLOCKS))
+#define TLS_LAUNCH(RES, STAGE, IDX, BLOCKS)                                                                         \
+    (!ctx->uniform_w ? (count_work ? launch_variant<RES, false, STAGE, IDX, false, true>(ctx, a, BLOCKS)                    \
+                                   : launch_variant<RES, false, STAGE, IDX, false, false>(ctx, a, BLOCKS))                   \
+     : prune         ? launch_variant<RES, true, STAGE, IDX, true, false>(ctx, a, BLOCKS)                                    \
+     : count_work    ? launch_variant<RES, true, STAGE, IDX, false, true>(ctx, a, BLOCKS)                                    \
+                     : launch_variant<RES, true, STAGE, IDX, false, false>(ctx, a, BLOCKS))
+#define TLS_LAUNCH_SPLIT(STAGE, BLOCKS)                                                                             \
+    (!ctx->uniform_w ? (count_work ? launch_split<false, STAGE, false, true>(ctx, a, BLOCKS)                                \
+                                   : launch_split<false, STAGE, false, false>(ctx, a, BLOCKS))                               \
+     : prune         ? launch_split<true, STAGE, true, false>(ctx, a, BLOCKS)                                                \
+     : count_work    ? launch_split<true, STAGE, false, true>(ctx, a, BLOCKS)                                                \
+                     : launch_split<true, STAGE, false, false>(ctx, a, BLOCKS))
     const bool split = !ctx->resident && ctx->split && ctx->batch_curves == 1;
-    if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short, tlsdev::kRoleAll, ctx->blocks);
+    if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short, ctx->blocks);
     else if (!split) {
-        if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int, tlsdev::kRoleAll, ctx->blocks);
-        else e = TLS_LAUNCH(false, false, unsigned int, tlsdev::kRoleAll, ctx->blocks);
+        if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int, ctx->blocks);
+        else e = TLS_LAUNCH(false, false, unsigned int, ctx->blocks);
     } else {
-        // series in the HBM slab, one light curve: per batch of periods the fold kernel (fold, stable sort, exact prefix
-        // sum -> one slab per period) and the search kernel over the (period, tile) items of those slabs
+        // series in the HBM slab, one light curve: per batch of periods ONE launch of the two-role kernel -- every
+        // workgroup folds periods of the batch until none is left (one slab per period), then searches (period, tile) items
         e = hipSuccess;
-        int only = 0;   // developer switch: 1 = fold kernels only, 2 = search kernels only (on whatever the slabs hold)
-        if (const char* env = std::getenv("TLS_SPLIT_ONLY")) only = std::atoi(env);
         for (int lo = 0; lo < ctx->n_periods && e == hipSuccess; lo += ctx->split_batch) {
             a.batch_lo = lo; a.batch_n = std::min(ctx->split_batch, ctx->n_periods - lo);
-            a.queue = ctx->d_squeue.ptr;
-            const int fold_blocks = std::min(ctx->split_blocks, a.batch_n);
-            if (only != 2)
-                e = ctx->uniform_w ? launch_variant<false, true, false, unsigned int, false, false, tlsdev::kRoleFold>(ctx, a, fold_blocks)
-                                   : launch_variant<false, false, false, unsigned int, false, false, tlsdev::kRoleFold>(ctx, a, fold_blocks);
-            if (e != hipSuccess) break;
-            if (only == 1) continue;
-            a.queue = ctx->d_squeue.ptr + 2;
+            a.queue = ctx->d_squeue.ptr;   // [0..1] the fold role's queue, [2..3] the search role's
             const int64_t items = (int64_t)ctx->host_tile_prefix[(size_t)(lo + a.batch_n)] - (int64_t)ctx->host_tile_prefix[(size_t)lo];
-            const int search_blocks = (int)std::min<int64_t>(ctx->split_blocks, std::max<int64_t>(items, 1));
-            if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int, tlsdev::kRoleSearch, search_blocks);
-            else e = TLS_LAUNCH(false, false, unsigned int, tlsdev::kRoleSearch, search_blocks);
+            const int blocks = (int)std::min<int64_t>(ctx->split_blocks, std::max<int64_t>(items, 1));
+            if (ctx->stage_c) e = TLS_LAUNCH_SPLIT(true, blocks);
+            else e = TLS_LAUNCH_SPLIT(false, blocks);
         }
     }
+#undef TLS_LAUNCH_SPLIT
 #undef TLS_LAUNCH
     if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if ((e = hipEventRecord(evp->second, ctx->stream)) != hipSuccess)
@@ -1054,14 +1064,23 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // TLS_SORT3=1 selects this path; both are tested.)
         ctx->sort3 = sort3_bytes <= lds_budget && tlsdev::sort3_bins((int)n) <= tlsdev::kSort3MaxBins && (int64_t)W <= n &&
                      (env_sort3 ? std::atoi(env_sort3) != 0 : false);
-        // Two-kernel slab path: the periods go through the fold kernel and the search kernel in batches;
-        // a batch holds one slab per period in HBM.  Batch size: as many periods as fit `kSplitSlabBytes` (at least four
-        // rounds of workgroups), all of them when the grid is small.  TLS_SPLIT=0 keeps the one-kernel path (A/B, tests).
+        // Two-role slab kernel: every workgroup folds periods into per-period slabs, then searches
+        // (period, tile) items; the periods go through it in batches that hold one slab per period in HBM (as many periods as
+        // fit `kSplitSlabBytes`, at least four rounds of workgroups; all of them when the grid is small).
+        // WHEN it is used (measured on one MI355X, same box, against the one-workgroup-per-period kernel): it wins where a
+        // GPU holds few periods of a long series -- the shard of a multi-GPU job -- because a period is then searched by
+        // several workgroups (260 periods of N = 70 128: 0.61 vs 0.79 ms); on a full grid the one-kernel path keeps every
+        // CU in a different phase and needs no hand-off (TESS 2.99 vs 3.50 ms, Kepler sample 5.37 vs 5.43 ms; 713 periods of
+        // N = 70 128, 2.8 rounds: 1.37 vs 1.63 ms; 308 periods of the TESS-size series: 0.53 ms both ways).  Hence: up to one
+        // and a half rounds of periods -> two-role kernel.  TLS_SPLIT=0/1 forces the choice (A/B, tests).
         ctx->split_blocks = ctx->n_cu * slab_wgs;
         if (const char* env = std::getenv("TLS_BLOCKS")) ctx->split_blocks = std::max(1, std::min(ctx->split_blocks, std::atoi(env)));
         {
             const char* env_split = std::getenv("TLS_SPLIT");
-            ctx->split = !(env_split && std::atoi(env_split) == 0) && n_periods > 0;
+            ctx->split = n_periods > 0 && (env_split ? std::atoi(env_split) != 0 : 2 * n_periods <= 3 * (int64_t)ctx->split_blocks);
+            // (Cutting the positions finer than the LDS requires -- more items per workgroup when the periods are few -- was
+            // measured and is not done: every tile stages its halo, waits for its slab and walks every row; 307 periods of the
+            // TESS-size series 0.53 ms with two tiles per period, 0.62 / 0.75 / 1.00 ms with 4 / 8 / 16 items per workgroup.)
             const size_t slab_bytes = regions * ((region_doubles + 1) & ~(size_t)1) * 8;
             constexpr size_t kSplitSlabBytes = (size_t)12 << 30;
             int64_t batch = std::max<int64_t>((int64_t)(kSplitSlabBytes / slab_bytes), (int64_t)4 * ctx->split_blocks);
@@ -1080,8 +1099,9 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
                     ctx->split_max_items = std::max<int64_t>(ctx->split_max_items, (int64_t)ctx->host_tile_prefix[(size_t)hi] - (int64_t)ctx->host_tile_prefix[(size_t)lo]);
                 }
                 TLS_HIP(ctx, ctx->d_partials.reserve(3 * (size_t)ctx->split_max_items + 3));
-                if (ctx->d_tiles_done.cap < (size_t)ctx->split_batch) {
-                    TLS_HIP(ctx, ctx->d_tiles_done.reserve((size_t)ctx->split_batch));
+                // [split_batch] tiles done | [split_batch] fold ready: all zero between launches (the kernel resets them)
+                if (ctx->d_tiles_done.cap < 2 * (size_t)ctx->split_batch) {
+                    TLS_HIP(ctx, ctx->d_tiles_done.reserve(2 * (size_t)ctx->split_batch));
                     TLS_HIP(ctx, hipMemsetAsync(ctx->d_tiles_done.ptr, 0, ctx->d_tiles_done.cap * sizeof(unsigned int), ctx->stream));
                 }
             }
