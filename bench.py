@@ -163,6 +163,7 @@ class Harness(object):
         n_dev = _lib.device_count()
         self.ctx = _lib.Context(local_rank % max(n_dev, 1))
         self.channel = None
+        self.devices = [local_rank % max(n_dev, 1)]
         self.collective = "none"
         if self.world > 1:
             # rank 0's RCCL unique id travels over the host channel; every rank then tries to join the
@@ -171,10 +172,23 @@ class Harness(object):
             self.channel = rendezvous.HostChannel(self.rank, self.world, addr, port)
             uid = self.channel.allgather_bytes(self.ctx.comm_unique_id() if self.rank == 0 else b"")[0]
             ok, why = _comm_init_with_deadline(self.ctx, self.world, self.rank, uid, RCCL_INIT_DEADLINE_S)
+            import struct
+            self.devices = [struct.unpack("<i", b)[0] for b in
+                            self.channel.allgather_bytes(struct.pack("<i", local_rank % max(n_dev, 1)))]
             if self.channel.all_true(ok):
                 self.collective = "rccl"
+            elif len(set(self.devices)) == self.world and not args.allow_host_fallback:
+                # every rank has a GPU of its own and RCCL still did not come up: that is a broken job, not a
+                # configuration to time over TCP (the reference's pool silently running on one core would be a bug
+                # there too, main.py:140-163).  All ranks leave with a non-zero status.
+                sys.stderr.write("rank %d: RCCL communicator over %d distinct devices %s failed: %s\n"
+                                 % (self.rank, self.world, self.devices, why or "on another rank"))
+                sys.stderr.flush()
+                self.channel.barrier()
+                os._exit(3)
             else:
-                self.collective = "host-tcp fallback (RCCL init failed: %s)" % (why or "on another rank")
+                # ranks share a device (a one-GPU box running the N-rank flow): RCCL refuses that by design
+                self.collective = "host-tcp fallback (ranks share a device, RCCL init: %s)" % (why or "failed on another rank")
                 if ok:
                     self.ctx.comm_destroy()
         elif args.force_collective:
@@ -192,7 +206,7 @@ class Harness(object):
             return self.ctx.comm_max(v)
         return self.channel.max(v) if self.channel is not None else v
 
-    def timed(self, step, finish, steps, warmup, prefill=0):
+    def timed(self, step, finish, steps, warmup, prefill=0, preroll=True):
         """W untimed + exactly K timed steps, barrier + device sync on both sides, max over ranks.
         Returns (seconds, mean search-kernel ms per launch from HIP events on the search stream)."""
         ctx = self.ctx
@@ -202,6 +216,19 @@ class Harness(object):
             step(i)
         finish()
         ctx.synchronize()
+        # Untimed pre-roll: the shader clocks of a box that has just been handed over ramp for tens of launches (the
+        # same kernel reads 2-3 % slower over the first ~25).  Plain searches, no collective (every rank on its own),
+        # until two consecutive 10-launch means agree to 0.5 % -- so that K = 20 timed steps measure the steady state.
+        self.preroll = {"batches": 0, "last_ms": None}
+        if preroll:
+            prev = None
+            for b in range(40):
+                ms = ctx.execute_timed(10)
+                self.preroll = {"batches": b + 1, "last_ms": ms}
+                if prev is not None and abs(ms - prev) <= 0.005 * prev:
+                    break
+                prev = ms
+            ctx.synchronize()
         ctx.kernel_timing(reset=True)
         self.barrier()
         ctx.synchronize()
@@ -261,6 +288,10 @@ def run_shard(h, args, config, steps=None):
     inp = synthetic.search_inputs(t, flux, **kw)
     job = shard.ShardedSearch(h.rank, h.world)
     lo, hi = job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"])
+    if h.channel is not None:   # every rank derived the boundaries itself: they must be the same boundaries
+        digests = h.channel.allgather_bytes(shard.bounds_digest(job.bounds))
+        if any(d != digests[0] for d in digests):
+            raise RuntimeError("rank %d: the ranks disagree on the period blocks of %s" % (h.rank, config))
     ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"][lo:hi], inp["table"], inp["params"])
     c = job.count_per_rank
 
@@ -432,6 +463,9 @@ def main():
                     help="skip the untimed extras (other configurations, 500 ppm variant, power() wall clock, "
                          "counted pass) so that a profiler sees only the timed workload's launches")
     ap.add_argument("--survey-curves", type=int, default=1024)
+    ap.add_argument("--allow-host-fallback", action="store_true",
+                    help="N > 1 with one device per rank: time over the host channel when RCCL does not come up "
+                         "(default: fail with a non-zero status)")
     ap.add_argument("--force-collective", action="store_true",
                     help="1-GPU runs: go through the RCCL code path with a one-rank communicator")
     args = ap.parse_args()
@@ -567,6 +601,12 @@ def main():
                                        "all-gather of all steps' results at the end" if survey_ran else
                                        "period grid sharded over the GPUs + RCCL all-gather"),
                        "mode": "survey" if survey_ran else "shard", "collective": h.collective,
+                       "devices_per_rank": h.devices, "rccl_ranks": ctx.comm_ranks() if h.collective == "rccl" else 0,
+                       "clock_preroll": getattr(h, "preroll", None),
+                       "value_definition": "cells of the K timed steps / wall, inputs resident in HBM (tls_execute; the "
+                                           "bench contract); value_one_shot is the search call from host buffers of "
+                                           "SURVEY 8(d)(i) (tls_prepare + tls_execute + tls_fetch, plan reused), "
+                                           "config.one_shot.cold_ms the same with host planning from scratch",
                        "sigma_ppm": 1e6 * (args.sigma or synthetic.CONFIGS[args.config][2]),
                        "light_curves_per_step": world if survey_ran else 1,
                        "search_ms_per_light_curve": ms_per_step / (world if survey_ran else 1),

@@ -226,6 +226,9 @@ int tls_period_costs(const double *t, int64_t n, const double *periods, int64_t 
 int tls_comm_unique_id(char id_out[128]);
 int tls_comm_init(tls_ctx *ctx, int n_ranks, int rank, const char id[128]);
 int tls_comm_destroy(tls_ctx *ctx);
+/* What RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): an N-rank job
+ * prints these, so that a run that silently used one rank cannot pass for an N-GPU run.  No communicator: 0, -1, -1. */
+int tls_comm_info(tls_ctx *ctx, int *n_ranks, int *rank, int *device);
 /* All-gather of the prepared search's device-resident results: every rank contributes its
  * shard (count_per_rank entries, zero padded) and receives n_ranks*count_per_rank entries of
  * chi2/row/depth in rank order.  One ncclAllGather over a packed 24 B/period buffer. */

@@ -227,6 +227,47 @@ def test_update_flux_equals_fresh_prepare(gpu):
         numpy.testing.assert_array_equal(x, y)
 
 
+def test_resident_chi2_is_only_trusted_while_the_device_still_holds_it(gpu):
+    """spectra(resident=True) reads the chi2 the search left in HBM -- only while that is still what the device holds.
+    Every call that launches a search, swaps the flux or reuses the result buffers ends that (Context.holds), and so does
+    an in-place edit of the fetched array; the spectra then come from the uploaded array and equal a fresh upload."""
+    from tls_amd import search as search_mod
+    t, f0, kw = synthetic.config("k2_90d", seed=0)
+    _, f1, _ = synthetic.config("k2_90d", seed=1)
+    i0 = synthetic.search_inputs(t, f0, **kw)
+    i1 = synthetic.search_inputs(t, f1, **kw)
+    sel = i0["periods"][::5]
+
+    def fresh():
+        gpu.prepare(i0["t"], i0["y"], i0["dy"], sel, i0["table"], i0["params"])
+        gpu.execute()
+        return gpu.fetch()[0]
+
+    chi2 = fresh()
+    assert gpu.holds(chi2)
+    want = search_mod.spectra(chi2.copy(), 3, context=gpu)                  # uploaded copy
+    got = search_mod.spectra(chi2, 3, context=gpu, resident=True)          # read in place
+    for a, b in zip(want, got):
+        numpy.testing.assert_array_equal(a, b)
+    chi2 = fresh()
+    gpu.update_flux(i1["y"], i1["dy"])
+    assert not gpu.holds(chi2)
+    gpu.execute_timed(1)                                                    # the device now holds seed 1's chi2
+    assert not gpu.holds(chi2)
+    got = search_mod.spectra(chi2, 3, context=gpu, resident=True)          # ... and seed 0's array is uploaded
+    for a, b in zip(want, got):
+        numpy.testing.assert_array_equal(a, b)
+    chi2 = fresh()
+    gpu.search_batch(i0["t"], numpy.stack([i0["y"], i1["y"]]), numpy.stack([i0["dy"], i1["dy"]]), sel, i0["table"], i0["params"])
+    assert not gpu.holds(chi2)
+    got = search_mod.spectra(chi2, 3, context=gpu, resident=True)          # (used to fail: "needs a finished search")
+    for a, b in zip(want, got):
+        numpy.testing.assert_array_equal(a, b)
+    chi2 = fresh()
+    chi2[3] += 1.0                                                          # an in-place edit
+    assert not gpu.holds(chi2)
+
+
 # ---- edge cases ---------------------------------------------------------------------------
 def test_edge_cases(gpu, oracle_lib):
     inp = _inputs("k2_90d")

@@ -162,3 +162,27 @@ def test_partition_by_makespan_fills_whole_rounds():
         worst_m = max(shard.block_makespan(ramp[bm[r]:bm[r + 1]], 512) for r in range(ranks))
         worst_s = max(shard.block_makespan(ramp[bs[r]:bs[r + 1]], 512) for r in range(ranks))
         assert worst_m <= worst_s * (1 + 1e-12)
+
+
+def test_block_makespan_never_shrinks_with_one_more_period_and_every_partition_covers_the_grid():
+    """The advisor's counter-example ([10, 1, 1, 1] on four slots takes 10; one more cheap period must not make it 3.35),
+    random blocks with spikes, and the partition on such times: non-decreasing bounds that end at n, equal digests."""
+    from tls_amd import shard
+    assert shard.block_makespan([10, 1, 1, 1], 4) == 10.0
+    assert shard.block_makespan([10, 1, 1, 1, 0.1], 4) >= 10.0
+    rng = numpy.random.RandomState(5)
+    for trial in range(40):
+        slots = int(rng.choice([2, 4, 16, 256]))
+        n = int(rng.randint(1, 6 * slots))
+        times = rng.uniform(0.5, 1.5, n)
+        times[rng.randint(0, n, max(1, n // 20))] *= rng.uniform(5, 60)     # commensurate-period spikes
+        prev = 0.0
+        for k in range(1, n + 1):
+            now = shard.block_makespan(times[:k], slots)
+            assert now >= prev - 1e-12, (trial, slots, k, prev, now)
+            prev = now
+        for ranks in (2, 3, 8):
+            b = shard.partition_by_makespan(times, ranks, slots)
+            assert len(b) == ranks + 1 and b[0] == 0 and b[-1] == n and numpy.all(numpy.diff(b) >= 0)
+            assert shard.bounds_digest(b) == shard.bounds_digest(b.copy())
+            assert shard.bounds_digest(b) != shard.bounds_digest(b + 1)

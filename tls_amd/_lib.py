@@ -24,7 +24,7 @@ SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version", "tls_abi_version",
     "tls_device_name", "tls_search", "tls_search_batch", "tls_power_batch", "tls_prepare", "tls_update_flux", "tls_execute",
     "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_period_cycles",
-    "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
+    "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_info", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
     "tls_comm_barrier", "tls_comm_max",
 )
@@ -150,6 +150,8 @@ def load():
     lib.tls_comm_init.argtypes = [vp, ci, ci, ctypes.c_char_p]
     lib.tls_comm_destroy.restype = ci
     lib.tls_comm_destroy.argtypes = [vp]
+    lib.tls_comm_info.restype = ci
+    lib.tls_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.tls_comm_allgather_results.restype = ci
     lib.tls_comm_allgather_results.argtypes = [vp, i64, _c_double_p, _c_int64_p, _c_double_p]
     lib.tls_comm_allgather_device.restype = ci
@@ -197,7 +199,8 @@ class Context(object):
                                + self._lib.tls_last_error(None).decode())
         self.device = int(device)
         self._n_periods = 0
-        self._resident_chi2 = None   # weak reference to the chi2 array the last fetch returned (see spectra)
+        self._resident_chi2 = None   # (weak reference to the chi2 array the last fetch returned, generation): see holds
+        self._generation = 0         # bumped by every call that launches a search or touches its inputs / result buffers
 
     # -- plumbing
     def close(self):
@@ -256,6 +259,7 @@ class Context(object):
         chi2 = numpy.empty((n_c, n_p), dtype=numpy.float64)
         row = numpy.empty((n_c, n_p), dtype=numpy.int64)
         depth = numpy.empty((n_c, n_p), dtype=numpy.float64)
+        self._invalidate_results()
         self._check(self._lib.tls_search_batch(self._h, _dp(t), _dp(y_batch), _dp(dy_batch), len(t), n_c,
                                                _dp(periods), n_p, ctypes.byref(tm), ctypes.byref(pr),
                                                _dp(chi2), _ip(row), _dp(depth)))
@@ -283,6 +287,7 @@ class Context(object):
             depth = numpy.empty((n_c, n_p), dtype=numpy.float64)
         if with_power:
             power = numpy.empty((n_c, n_p), dtype=numpy.float64)
+        self._invalidate_results()
         self._check(self._lib.tls_power_batch(
             self._h, _dp(t), _dp(y_batch), _dp(dy_batch), len(t), n_c, _dp(periods), n_p, ctypes.byref(tm),
             ctypes.byref(pr), int(median_kernel), summary.ctypes.data_as(ctypes.c_void_p),
@@ -291,8 +296,14 @@ class Context(object):
         self._n_periods = n_p
         return summary, chi2, row, depth, power
 
-    def prepare(self, t, y, dy, periods, table, params):
+    def _invalidate_results(self):
+        """Every call that launches a search, replaces its inputs or reuses the result buffers: the chi2 array an
+        earlier fetch returned is no longer what the device holds (see holds)."""
         self._resident_chi2 = None
+        self._generation += 1
+
+    def prepare(self, t, y, dy, periods, table, params):
+        self._invalidate_results()
         t, y, dy, periods = _f8(t), _f8(y), _f8(dy), _f8(periods)
         if not (t.ndim == y.ndim == dy.ndim == 1 and len(t) == len(y) == len(dy)):
             raise ValueError("t, y, dy must be 1-dimensional and of equal length")
@@ -302,11 +313,12 @@ class Context(object):
         self._n_periods = len(periods)
 
     def update_flux(self, y, dy):
+        self._invalidate_results()
         y, dy = _f8(y), _f8(dy)
         self._check(self._lib.tls_update_flux(self._h, _dp(y), _dp(dy)))
 
     def execute(self, count_work=False, phase_clock=False):
-        self._resident_chi2 = None
+        self._invalidate_results()
         self._check(self._lib.tls_execute(self._h, (1 if count_work else 0) | (2 if phase_clock else 0)))
 
     def t0_fit_residuals(self, t, y, period, signal, epochs, roll):
@@ -317,11 +329,21 @@ class Context(object):
                                          len(signal), _dp(epochs), len(epochs), int(roll), _dp(out)))
         return out
 
+    @staticmethod
+    def _fingerprint(chi2):
+        """Cheap value check of a fetched array (one pass): catches an in-place edit between fetch and spectra."""
+        if len(chi2) == 0:
+            return (0, 0.0)
+        return (len(chi2), float(numpy.sum(chi2)), float(chi2[0]), float(chi2[-1]), float(chi2[len(chi2) // 2]))
+
     def holds(self, chi2):
-        """True if `chi2` is the very array the last fetch of this context returned and no search has run since:
-        the device then still holds the same values and tls_spectra may read them in place."""
+        """True if `chi2` is the very array the last fetch of this context returned, no call has launched a search,
+        replaced the flux or reused the result buffers since (every such method bumps the context's generation), and
+        the array still has the values it was handed out with: the device then holds the same values and tls_spectra
+        may read them in place.  Anything else is uploaded."""
         ref = self._resident_chi2
-        return ref is not None and ref() is chi2 and len(chi2) == self._n_periods
+        return (ref is not None and ref[0]() is chi2 and ref[1] == self._generation and len(chi2) == self._n_periods
+                and ref[2] == self._fingerprint(chi2))
 
     def spectra(self, kernel, chi2=None):
         """SR, power_raw, power, SDE_raw, SDE (stats.py:105-132) on the device; chi2=None takes the
@@ -344,12 +366,14 @@ class Context(object):
     def folded(self, n_periods, n):
         """Developer/test entry: the folded flux of every period of the prepared plan, (n_periods, n), as the
         kernel's sort left it."""
+        self._invalidate_results()
         out = numpy.empty((int(n_periods), int(n)), dtype=numpy.float64)
         self._check(self._lib.tls_debug_folded(self._h, _dp(out), out.size))
         return out
 
     def prefix_sums(self, n_periods):
         """Developer/test entry: the prefix sum C[0..M] of the patched folded flux of every period, (n_periods, M + 1)."""
+        self._invalidate_results()
         row = ctypes.c_int64(0)
         self._check(self._lib.tls_debug_prefix(self._h, None, 0, ctypes.byref(row)))
         out = numpy.empty((int(n_periods), int(row.value)), dtype=numpy.float64)
@@ -372,6 +396,7 @@ class Context(object):
 
     def period_cycles(self):
         """Developer instrumentation: shader cycles per period of the prepared plan (one more search)."""
+        self._invalidate_results()
         out = numpy.zeros(self._n_periods, dtype=numpy.uint64)
         self._check(self._lib.tls_debug_period_cycles(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                                                       len(out)))
@@ -391,6 +416,7 @@ class Context(object):
         self._check(self._lib.tls_synchronize(self._h))
 
     def execute_timed(self, reps=1):
+        self._invalidate_results()
         ms = ctypes.c_double(0.0)
         self._check(self._lib.tls_execute_timed(self._h, int(reps), ctypes.byref(ms)))
         return ms.value
@@ -402,7 +428,8 @@ class Context(object):
         depth = numpy.empty(n, dtype=numpy.float64)
         c = Counters()
         self._check(self._lib.tls_fetch(self._h, _dp(chi2), _ip(row), _dp(depth), ctypes.byref(c)))
-        self._resident_chi2 = weakref.ref(chi2)   # exactly this array is what the device still holds
+        # exactly this array, at this generation of the context, with these values is what the device still holds
+        self._resident_chi2 = (weakref.ref(chi2), self._generation, self._fingerprint(chi2))
         if with_counters:
             return chi2, row, depth, c.as_dict()
         return chi2, row, depth
@@ -438,6 +465,15 @@ class Context(object):
 
     def comm_destroy(self):
         self._check(self._lib.tls_comm_destroy(self._h))
+
+    def comm_info(self):
+        """(ranks, this rank, device) as RCCL reports them for the communicator; (0, -1, -1) without one."""
+        n, r, d = ctypes.c_int(0), ctypes.c_int(-1), ctypes.c_int(-1)
+        self._check(self._lib.tls_comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)))
+        return n.value, r.value, d.value
+
+    def comm_ranks(self):
+        return self.comm_info()[0]
 
     def comm_allgather_results(self, count_per_rank, n_ranks):
         total = int(count_per_rank) * int(n_ranks)

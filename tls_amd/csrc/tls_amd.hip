@@ -120,7 +120,7 @@ struct tls_ctx {
     int64_t plan_reuses = 0;   // tls_prepare calls answered from the held plan
     DevBuf<double> d_scratch, d_pack, d_gather, d_scalar, d_stage;
     DevBuf<unsigned long long> d_phase, d_check;
-    DevBuf<unsigned int> d_queue, d_squeue, d_lists, d_perm;   // d_squeue: the search kernel's self-rewinding queue
+    DevBuf<unsigned int> d_queue, d_squeue, d_lists, d_perm, d_pqueues;   // d_pqueues: tls_power_batch's T0-fit queues   // d_squeue: the search kernel's self-rewinding queue
     DevBuf<double> d_curve_S0, d_curve_w0;   // survey batches
     // survey batches: two slots of device + pinned host buffers, a second stream for the transfers
     struct BatchSlot {
@@ -774,6 +774,17 @@ int launch_t0_fit(tls_ctx* ctx, const double* d_t, const double* d_y, const doub
     return TLS_OK;
 }
 
+// compute units of the first visible device; 256 (MI355X) where no device can be asked (host-only planning)
+int visible_compute_units() {
+    static int cached = 0;
+    if (cached > 0) return cached;
+    int count = 0, cus = 0;
+    if (hipGetDeviceCount(&count) == hipSuccess && count > 0 &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess && cus > 0) cached = cus;
+    else { (void)hipGetLastError(); cached = 256; }
+    return cached;
+}
+
 }  // namespace
 
 extern "C" {
@@ -835,7 +846,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     if (ctx->ev_stage) (void)hipEventDestroy(ctx->ev_stage);
     ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release();
-    ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
+    ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_pqueues.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     for (auto& sl : ctx->slot) {
         sl.d_y.release(); sl.d_w.release(); sl.d_S0.release(); sl.d_w0.release(); sl.d_chi2.release(); sl.d_depth.release(); sl.d_row.release();
@@ -1663,10 +1674,34 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
     return rc;
 }
 
+static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n, int64_t n_curves,
+                            const double* periods, int64_t n_periods, const tls_template* tmpl, const tls_params* params,
+                            int64_t median_kernel, tls_power_summary* out_summary, double* out_chi2, int64_t* out_row,
+                            double* out_depth, double* out_power);
+
 int tls_power_batch(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n, int64_t n_curves,
                     const double* periods, int64_t n_periods, const tls_template* tmpl, const tls_params* params,
                     int64_t median_kernel, tls_power_summary* out_summary, double* out_chi2, int64_t* out_row,
                     double* out_depth, double* out_power) {
+    const int rc = power_batch_impl(ctx, t, y, dy, n, n_curves, periods, n_periods, tmpl, params, median_kernel, out_summary,
+                                    out_chi2, out_row, out_depth, out_power);
+    if (ctx && rc != TLS_OK) {
+        // EVERY failure leaves through here: nothing is still copying into or out of the pinned staging buffers or the
+        // caller's arrays, and the context does not keep pointing at a batch slot
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+        ctx->batch_curves = 1;
+        ctx->over_y = ctx->over_w = ctx->over_S0 = ctx->over_w0 = nullptr;
+        ctx->over_chi2 = nullptr; ctx->over_row = nullptr; ctx->over_depth = nullptr;
+        ctx->executed = false;
+    }
+    return rc;
+}
+
+static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n, int64_t n_curves,
+                            const double* periods, int64_t n_periods, const tls_template* tmpl, const tls_params* params,
+                            int64_t median_kernel, tls_power_summary* out_summary, double* out_chi2, int64_t* out_row,
+                            double* out_depth, double* out_power) {
     if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
     if (n_curves < 0) return fail(ctx, TLS_E_ARG, "negative number of light curves");
     if (n_curves == 0) return TLS_OK;
@@ -1706,7 +1741,7 @@ int tls_power_batch(tls_ctx* ctx, const double* t, const double* y, const double
     TLS_HIP(ctx, ctx->d_fep.reserve((size_t)group * fit_stride));
     TLS_HIP(ctx, ctx->d_fres.reserve((size_t)group * fit_stride));
     TLS_HIP(ctx, ctx->d_fsig.reserve((size_t)group * (size_t)max_len + (size_t)group));   // signals | n_epochs (as int, behind)
-    DevBuf<unsigned int> d_queues;
+    DevBuf<unsigned int>& d_queues = ctx->d_pqueues;   // (a member: released with the context, whatever path leaves this call)
     TLS_HIP(ctx, d_queues.reserve((size_t)group));
     // pinned staging: flux in; summaries, T0 and (on request) the per-period arrays out; epochs + signals in
     const size_t in_doubles = (size_t)group * nn * (uni ? 1 : 2) + 2 * (size_t)group;
@@ -1870,8 +1905,6 @@ int tls_power_batch(tls_ctx* ctx, const double* t, const double* y, const double
         }
         if (out_power) std::memcpy(out_power + c0 * n_periods, h_power, (size_t)gc * np * 8);
     }
-    if (rc != TLS_OK) (void)hipStreamSynchronize(ctx->stream);
-    d_queues.release();
     ctx->executed = false;   // the search ran on the batch slot, see tls_search_batch
     return rc;
 }
@@ -1950,11 +1983,13 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         else { a0 = 56564.0; aN = 0.0; b = 0.3189; c = 0.1267; }                        // LDS-resident, one 1024-thread workgroup per CU (100 d)
         for (int64_t p = 0; p < n_periods; ++p)
             time_per_period[p] = a0 + aN * (double)n + b * (double)cells_per_period[p] + c * taps_per_period[p];
-        // periods searched side by side on one GPU (one workgroup each): 256 CUs, two workgroups per CU when two
-        // folded series fit its LDS.  A block of n periods takes ceil(n / this) rounds, not n / this.
-        if (workgroups_in_flight) *workgroups_in_flight = two_per_cu ? 512 : 256;
+        // periods searched side by side on one GPU (one workgroup each): its CUs (256 on an MI355X; the first visible
+        // device is asked, a process without one plans for an MI355X), two workgroups per CU when two folded series fit
+        // its LDS.  A block of n periods takes ceil(n / this) rounds, not n / this.  (The cycle coefficients above are
+        // MI355X measurements; only their ratios matter.)
+        if (workgroups_in_flight) *workgroups_in_flight = (two_per_cu ? 2 : 1) * visible_compute_units();
     } else if (workgroups_in_flight) {
-        *workgroups_in_flight = 256;
+        *workgroups_in_flight = visible_compute_units();
     }
     return TLS_OK;
 }
@@ -1986,6 +2021,20 @@ int tls_comm_destroy(tls_ctx* ctx) {
     if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
     if (ctx->comm) { TLS_NCCL(ctx, ncclCommDestroy(ctx->comm)); ctx->comm = nullptr; }
     ctx->n_ranks = 1; ctx->rank = 0;
+    return TLS_OK;
+}
+
+int tls_comm_info(tls_ctx* ctx, int* n_ranks, int* rank, int* device) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    int n = 0, r = -1, d = -1;
+    if (ctx->comm) {
+        TLS_NCCL(ctx, ncclCommCount(ctx->comm, &n));
+        TLS_NCCL(ctx, ncclCommUserRank(ctx->comm, &r));
+        TLS_NCCL(ctx, ncclCommCuDevice(ctx->comm, &d));
+    }
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
+    if (device) *device = d;
     return TLS_OK;
 }
 

@@ -46,7 +46,14 @@ def block_makespan(times, slots):
     c = numpy.sort(numpy.asarray(times, dtype=numpy.float64))[::-1]
     rounds = -(-n // slots)
     full = (rounds - 1) * slots
-    return float(numpy.sum(c[:full]) / slots + c[full])
+    value = float(numpy.sum(c[:full]) / slots + c[full])
+    # No schedule beats its longest period, and one more (cheap) period never shortens a block: without these two the
+    # model is not monotone in the block length where a round boundary is crossed ([10, 1, 1, 1] on four slots takes
+    # 10, and [10, 1, 1, 1, 0.1] does not take 3.35) -- and the bisection of partition_by_makespan relies on monotony.
+    value = max(value, float(c[0]))
+    if full >= slots and n > full:      # the block as it was when its last round was still empty
+        value = max(value, float(numpy.sum(c[:full - slots]) / slots + c[full - slots]))
+    return value
 
 
 def partition_by_makespan(times, n_ranks, slots):
@@ -82,8 +89,22 @@ def partition_by_makespan(times, n_ranks, slots):
         else:
             lo_t = mid_t
     bounds = fill(hi_t)
+    if bounds[-1] < n:
+        # the greedy fill did not reach the end at the bisection's upper bracket (the model is only nearly monotone):
+        # spread what is left over the ranks instead of handing all of it to the last one
+        rest = n - bounds[-1]
+        for r in range(1, n_ranks + 1):
+            bounds[r] += (rest * r) // n_ranks
     bounds[-1] = n
-    return numpy.asarray(bounds, dtype=numpy.int64)
+    bounds = numpy.maximum.accumulate(numpy.asarray(bounds, dtype=numpy.int64))
+    return numpy.minimum(bounds, n)
+
+
+def bounds_digest(bounds):
+    """What the ranks compare before they search: every rank derives the block boundaries itself (floating-point
+    bisection on modelled times), and two ranks that disagreed would assemble mismatched blocks without any error."""
+    import hashlib
+    return hashlib.sha256(numpy.asarray(bounds, dtype=numpy.int64).tobytes()).digest()
 
 
 def assemble(gathered, bounds, count_per_rank):
