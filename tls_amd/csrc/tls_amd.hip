@@ -219,7 +219,7 @@ int stage_reserve(tls_ctx* ctx, size_t bytes) {
 
 std::string plan_env() {   // developer switches that change the plan
     std::string e;
-    for (const char* name : {"TLS_PRUNE", "TLS_PRUNE_MIN_LIVE", "TLS_SORT2", "TLS_SORT3", "TLS_THREADS", "TLS_BLOCKS", "TLS_STAGE_C", "TLS_SLAB_WGS", "TLS_SPLIT", "TLS_SPLIT_BATCH"}) {
+    for (const char* name : {"TLS_PRUNE", "TLS_PRUNE_MIN_LIVE", "TLS_SORT2", "TLS_SORT3", "TLS_THREADS", "TLS_BLOCKS", "TLS_STAGE_C", "TLS_SLAB_WGS", "TLS_SPLIT", "TLS_SPLIT_BATCH", "TLS_NO_SCREEN"}) {
         const char* v = std::getenv(name);
         e += v ? v : "-";
         e += '|';
@@ -442,7 +442,7 @@ void build_screens(const std::vector<tlsdev::WidthEntry>& widths, const std::vec
         // q~' within 1 ulp of levd -- absorbed by inflating the remainder; |dsum| * mean enters the same way)
         sc.sq = (double)sq;
         sc.r2 = (double)(r2 * (1.0L + 1e-9L)) + 1e-24 + 1e-12 * (double)fabsl(dsum);
-        sc.valid = 1;
+        sc.valid = std::getenv("TLS_NO_SCREEN") ? 0 : 1;   // developer switch: the one-segment bound (cell_bound) for every row
     }
 }
 

@@ -2919,7 +2919,8 @@ tls_search_kernel(const SearchArgs) {
 // alive in the search and the other way round -- the register allocation of two kernels in one launch, without a
 // second launch's idle tail.  No deadlock: a workgroup asks for a search item only after it has seen the fold queue
 // empty, so the fold it may wait for is running on a workgroup that holds a CU and waits for nothing.
-// (The roles as called functions were measured: 30 % slower, the callee-saved registers and the scratch of a function.)
+// (The roles as called `__noinline__` functions were measured too: no different in time -- and a called function cannot
+// reach the kernel-argument segment through the builtin, which is null there.  PERF_LOG.md, round 4.)
 template <bool UNI_, bool STAGE_, bool PRUNE_ = false, bool COUNT_ = true>
 __global__ void __launch_bounds__(TLS_LAUNCH_THREADS, TLS_WAVES_PER_EU)
 tls_fold_search_kernel(const SearchArgs) {
