@@ -686,7 +686,8 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.n = ctx->n; a.W = ctx->W; a.M = ctx->M;
     a.n_periods = ctx->n_periods; a.n_widths = ctx->n_widths; a.nb = ctx->nb;
     a.batch_lo = 0; a.batch_n = 0; a.tile_prefix = ctx->d_tile_prefix.ptr;
-    a.partials = ctx->d_partials.ptr; a.tiles_done = ctx->d_tiles_done.ptr; a.fold_ready = ctx->d_tiles_done.ptr + ctx->split_batch;
+    a.partials = ctx->d_partials.ptr; a.tiles_done = ctx->d_tiles_done.ptr;
+    a.fold_ready = ctx->d_tiles_done.ptr ? ctx->d_tiles_done.ptr + ctx->split_batch : nullptr;   // (only the two-role plan has them)
     hipError_t e;
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
     if ((e = timing_pair(ctx, &evp)) != hipSuccess || (e = hipEventRecord(evp->first, ctx->stream)) != hipSuccess)
