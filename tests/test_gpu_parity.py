@@ -619,10 +619,13 @@ def test_survey_1024_curves_vs_oracle(gpu, oracle_lib):
 
 @pytest.mark.parametrize("name,n_curves,stride,per_point", [("k2_90d", 35, 40, False), ("k2_90d", 5, 40, True),
                                                              ("tess_27d", 3, 100, False), ("tess_27d", 2, 100, True)])
-def test_search_batch_groups_weights_and_tiled_layout(gpu, name, n_curves, stride, per_point):
+def test_search_batch_groups_weights_and_tiled_layout(gpu, name, n_curves, stride, per_point, monkeypatch):
     """tls_search_batch shares the fold + sort of a period between the curves of a launch group:
     more curves than one group holds, per-point weights, and the HBM-slab layout all return what a
-    search per light curve returns, bit for bit."""
+    search per light curve returns, bit for bit.  (Same kernel shape on both sides: a batch runs the
+    one-workgroup-per-period kernel, so the single searches are kept from the two-role kernel, which a few dozen
+    periods of a long series would otherwise take and which runs exact prefix-sum mode only -- 1e-10 apart.)"""
+    monkeypatch.setenv("TLS_SPLIT", "0")
     t, f0, kw = synthetic.config(name, seed=0)
     rng = numpy.random.RandomState(5)
     inputs = []
@@ -732,7 +735,10 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
     one-workgroup-per-period kernel -- the same cells, values and tie rule, so chi2, row and depth must be the same BITS and
     the evaluated-cell and tap counts equal; more rounds than workgroups, several batches of slabs (TLS_SPLIT_BATCH), uniform
     and per-point weights; and both against the oracle.  (The plan picks the two-role kernel for up to 1.5 rounds of periods;
-    TLS_SPLIT forces either.)"""
+    TLS_SPLIT forces either.)  The two-role kernel runs exact mode only, so the bit-for-bit comparison pins the one-kernel
+    path to exact mode (TLS_FAST_SLAB=0); its default -- fast mode -- must give the same rows and counts and the same
+    chi^2 to 1e-10."""
+    monkeypatch.setenv("TLS_FAST_SLAB", "0")
     t, f, kw = synthetic.config(name)
     dy = None
     if per_point:
@@ -760,6 +766,55 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
     want = oracle_search(oracle_lib, inp, periods=sel)
     assert_parity(results["1"], want, len(inp["t"]))
     assert results["1"][3]["evaluated_cells"] == int(want[3][1])
+    # the one-kernel path as it runs by default (fast prefix-sum mode)
+    monkeypatch.delenv("TLS_FAST_SLAB")
+    monkeypatch.setenv("TLS_SPLIT", "0")
+    fast = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+    numpy.testing.assert_array_equal(fast[1], results["1"][1])
+    numpy.testing.assert_allclose(fast[0], results["1"][0], rtol=1e-10, atol=0)
+    assert fast[3]["evaluated_cells"] == results["1"][3]["evaluated_cells"]
+    assert fast[3]["inner_steps"] == results["1"][3]["inner_steps"]
+
+
+@pytest.mark.parametrize("name,stride,sigma,weights", [("tess_27d", 3, None, False), ("tess_27d", 11, 1000e-6, True),
+                                                       ("kepler_4yr", 250, None, False), ("kepler_4yr", 2000, None, True)])
+def test_fast_prefix_mode_in_the_slab_decides_the_reference_cells(gpu, oracle_lib, monkeypatch, name, stride, sigma, weights):
+    """HBM-slab variant, fast prefix-sum mode (the default of the one-workgroup-per-period kernel since round 4): the same
+    contract as in the LDS-resident kernel -- evaluated-cell and tap counts equal the oracle's and exact mode's
+    (TLS_FAST_SLAB=0), rows identical, chi^2 within 1e-10 of exact mode; a period with a window inside the undecided band
+    goes through the prefix sum and phase 3 again in exact mode, on the folded flux it kept (the band is hit by 2-10 % of
+    the periods at these sizes: the second attempts are part of what is checked here); plain and counting kernels and a
+    repeat of the call give the same bits."""
+    t, f, kw = synthetic.config(name, sigma=sigma)
+    dy = None
+    if weights:
+        dy = numpy.random.RandomState(7).uniform(0.7, 1.5, len(f)) * synthetic.CONFIGS[name][2]
+    inp = synthetic.search_inputs(t, f, dy, **kw)
+    sel = inp["periods"][::stride]
+    monkeypatch.setenv("TLS_PRUNE", "0")
+    monkeypatch.setenv("TLS_SPLIT", "0")
+    monkeypatch.setenv("TLS_FAST_SLAB", "0")
+    exact = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+    monkeypatch.delenv("TLS_FAST_SLAB")
+    fast = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+    assert not gpu.plan_info()["resident"]
+    plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+    again = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+    for a, b, c in zip(fast[:3], plain[:3], again[:3]):
+        numpy.testing.assert_array_equal(a, b)
+        numpy.testing.assert_array_equal(b, c)
+    assert fast[3]["evaluated_cells"] == exact[3]["evaluated_cells"]
+    assert fast[3]["inner_steps"] == exact[3]["inner_steps"]
+    numpy.testing.assert_array_equal(fast[1], exact[1])
+    numpy.testing.assert_allclose(fast[0], exact[0], rtol=1e-10, atol=0)
+    numpy.testing.assert_allclose(fast[2], exact[2], rtol=0, atol=1e-12)
+    want = oracle_search(oracle_lib, inp, periods=sel)
+    assert fast[3]["evaluated_cells"] == int(want[3][1])
+    assert_parity(exact, want, len(inp["t"]))
+    assert_parity(fast, want, len(inp["t"]))
+    gpu.execute(phase_clock=True)
+    retries = gpu.phase_cycles()["stat_exact_retries"]
+    assert 0 <= retries <= max(8, len(sel) // 4), retries
 
 
 @pytest.mark.parametrize("per_point", [False, True])

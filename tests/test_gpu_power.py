@@ -205,7 +205,9 @@ def test_power_at_tess_size_gpu_equals_power_with_oracle_search(oracle_lib, monk
     for key in pins.SCALARS:
         numpy.testing.assert_allclose(float(got[key]), float(want[key]), rtol=1e-9, atol=1e-12, err_msg=key)
     for key in pins.ARRAYS:
-        atol = 2e-9 if key in ("power", "power_raw", "SR") else 1e-11
+        # (the spectra divide by std(SR) ~ 2e-3; the slab kernel's fast prefix-sum mode moves chi^2 by up to 1e-10 relative
+        # at this N -- DESIGN.md section 3 -- against 1e-12 typical in the LDS-resident kernel)
+        atol = 8e-9 if key in ("power", "power_raw", "SR") else 1e-11
         numpy.testing.assert_allclose(numpy.asarray(got[key], dtype=float), numpy.asarray(want[key], dtype=float),
                                       rtol=1e-9, atol=atol, err_msg=key)
     assert int(numpy.argmin(got.chi2)) == int(numpy.argmin(want.chi2))

@@ -94,8 +94,14 @@
         int flag_slot = 1;   // the "undecided" flag of the attempt in flight: s_work[1] and s_work[2] take turns
         // exact mode: X = k - numpy.cumsum, bit for bit; fast mode: X = plain prefix sum of 1 - f (depth_pass)
         // (the two-kernel slab path has no second attempt: its fold kernel always leaves X = k - numpy.cumsum)
+        // (the mode of a period depends on the series and the period alone, never on its place in the launch: sending the
+        // launch's last round straight to exact mode would spare TESS-size grids a late second attempt -- measured 2.90
+        // -> 2.81 ms -- but a period's bits would then depend on which other periods the call holds)
         const bool period_exact = (!RESIDENT && (ROLE != kRoleAll || ap->fast_slab == 0 || ap->sort3 != 0)) || retry_exact ||
                                   ap->exact_prefix != 0 || ap->debug_prefix != nullptr;
+        // (slab variant, one light curve: the folded flux of the fast attempt is still in the slab -- only X was written
+        // behind it --, so the second attempt keeps it and starts at the prefix sum)
+        [[maybe_unused]] const bool refold = !(retry_exact && !RESIDENT && ROLE == kRoleAll && ap->n_curves == 1 && ap->debug_folded == nullptr);
         retry_exact = false;
         bool curve_exact = false;   // batches: this light curve again in exact mode (the permutation is kept: no new sort)
         // split roles: `work` counts the items of this launch -- the periods of the batch (fold), their tiles (search)
@@ -155,15 +161,18 @@
         // ---- phase 1: fold + stable sort by phase ----------------------------------
         bool sorted = false;
         bool fused = false;   // fold, sort, gather AND prefix sum done by fold_sort_cumsum_tiled
+        if constexpr (!RESIDENT && ROLE == kRoleAll) {
+            if (!refold) sorted = true;
+        }
         if constexpr (!RESIDENT && ROLE != kRoleSearch) {
-            if (ap->sort3 && ap->n_curves == 1)
+            if (!sorted && ap->sort3 && ap->n_curves == 1)
                 fused = fold_sort_cumsum_tiled<UNIFORM_W>(ap->t, ap->y, ap->w, n, W, period, regA, regB, regW,
                                                           ap->sort3_scratch + (long long)blockIdx.x * sort3_scratch_doubles(n),
                                                           smem + ap->hdr_bytes, wsum,
                                                           reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), ap->phase_cycles);
             if (ap->sort3 && ap->n_curves == 1) pc.start(ap->phase_cycles);   // the call kept its own clock
             // series in HBM: the two-level sort with sequential HBM accesses, unless a phase bin overflows
-            if (!fused && ap->sort2) {
+            if (!sorted && !fused && ap->sort2) {
                 typedef global_ptr<const double> gcd;
                 typedef global_ptr<double> gd;
                 typedef global_ptr<unsigned int> gu;
