@@ -877,6 +877,79 @@ def test_pruning_kernel_is_exact(gpu, name, sigma, stride, monkeypatch):
             numpy.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("name,sigma,stride", [("k2_90d", None, 2), ("k2_90d", 100e-6, 3), ("k2_90d", 500e-6, 5),
+                                               ("k2_90d", 3000e-6, 11), ("tutorial01", None, 3), ("tutorial01", 300e-6, 5)])
+def test_fp32_screen_kernel_is_exact(gpu, name, sigma, stride, monkeypatch):
+    """The fp32 screen (screen_cells in tls_kernels.hip.h: dot products of all cells in packed fp32 on the high halves of the
+    samples, fp64 valuation -- by the plain kernel's own additions -- of the cells whose error interval can still hold the
+    period's minimum) must return the plain kernel's bits, period by period, whatever the noise level; the host takes it
+    only where it pays (TLS_SCREEN32=1/0 forces it on/off, read at prepare time).  The statistics of the phase-clock
+    buffer say that the variant ran: every period values at least its winner."""
+    inp = _inputs(name, sigma=sigma)
+    sel = inp["periods"][::stride]
+    monkeypatch.setenv("TLS_PRUNE", "0")
+    monkeypatch.setenv("TLS_SCREEN32", "0")
+    plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+    monkeypatch.setenv("TLS_SCREEN32", "1")
+    screened = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+    assert gpu.plan_info()["resident"]
+    for x, y in zip(plain[:3], screened[:3]):
+        numpy.testing.assert_array_equal(x, y)
+    gpu.execute(phase_clock=True)
+    stats = gpu.phase_cycles()
+    assert stats["stat_screen_valued"] >= numpy.count_nonzero(plain[0] < len(inp["t"])) // 2, stats["stat_screen_valued"]
+    again = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+    for x, y in zip(screened[:3], again[:3]):
+        numpy.testing.assert_array_equal(x, y)
+
+
+def test_fp32_screen_on_ties_deep_transits_and_inadmissible_flux(gpu, monkeypatch):
+    """Edge cases of the fp32 screen against the plain kernel, bit for bit: (i) a light curve built from a few repeated
+    values -- thousands of trial cells with EQUAL statistics, so the workgroup's list of parked cells overflows and the
+    overflow path (a lane values the cell on the spot) decides, by the reference's tie rule; (ii) a 2.9 % deep transit
+    (|1 - flux| just below the 2^-5 the exact split allows: the error bound is at its widest); (iii) a 4 % deep one and
+    (iv) a flux outside [0.5, 2]: the screen is not admissible and the launch takes the plain kernel even when forced;
+    (v) a survey batch."""
+    rng = numpy.random.RandomState(3)
+    n = 2400
+    t = numpy.linspace(1.0, 51.0, n)
+    kw = dict(period_min=1.0, period_max=12.0, oversampling_factor=2)
+    cases = []
+    y = 1.0 - 1e-4 * ((numpy.arange(n) % 7 == 0).astype(float) + (numpy.arange(n) % 11 == 0))          # (i) ties
+    cases.append(("ties", y))
+    for depth, label in ((0.029, "deep"), (0.04, "too deep")):
+        y = 1.0 + rng.normal(0, 1e-4, n)
+        y[(t % 3.7) < 0.15] -= depth
+        cases.append((label, y))
+    y = 1.0 + rng.normal(0, 1e-4, n); y[100] = 2.5
+    cases.append(("outlier", y))
+    monkeypatch.setenv("TLS_PRUNE", "0")
+    for label, y in cases:
+        inp = synthetic.search_inputs(t, y, **kw)
+        monkeypatch.setenv("TLS_SCREEN32", "0")
+        plain = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+        monkeypatch.setenv("TLS_SCREEN32", "1")
+        screened = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+        for x, z in zip(plain[:3], screened[:3]):
+            numpy.testing.assert_array_equal(x, z, err_msg=label)
+        gpu.execute(phase_clock=True)
+        valued = gpu.phase_cycles()["stat_screen_valued"]
+        assert (valued > 0) == (label in ("ties", "deep")), (label, valued)
+    # (v) a batch: every curve of a launch group through the screen
+    ys = numpy.stack([1.0 + rng.normal(0, s, n) for s in (8e-5, 1.5e-4, 3e-4, 1e-4, 2e-4)])
+    for k in range(len(ys)):
+        ys[k][(t % (2.0 + k)) < 0.12] -= 0.002
+    inp = synthetic.search_inputs(t, ys[0], **kw)
+    assert len(inp["t"]) == n
+    dy = numpy.stack([numpy.full(n, numpy.std(v)) for v in ys])
+    monkeypatch.setenv("TLS_SCREEN32", "0")
+    plain = gpu.search_batch(inp["t"], ys, dy, inp["periods"], inp["table"], inp["params"])
+    monkeypatch.setenv("TLS_SCREEN32", "1")
+    screened = gpu.search_batch(inp["t"], ys, dy, inp["periods"], inp["table"], inp["params"])
+    for x, z in zip(plain, screened):
+        numpy.testing.assert_array_equal(x, z)
+
+
 @pytest.mark.parametrize("name,sigma,weights", [("k2_90d", None, False), ("k2_90d", 500e-6, False),
                                                 ("tutorial01", None, True)])
 def test_fast_prefix_mode_decides_the_reference_cells(gpu, oracle_lib, monkeypatch, name, sigma, weights):

@@ -387,11 +387,11 @@ class Context(object):
         self._check(self._lib.tls_debug_phase_cycles(self._h, arr, 40))
         names = ("fold_count", "scan", "scatter", "rank", "gather_patch", "cumsum", "batch_prefix",
                  "chi2", "e_convert", "predicate_strided", "cumsum_blocks", "cumsum_fallbacks",
-                 "tile_staging", "predicate_dense", "cs_A", "cs_B1", "cs_B2", "cs_scan", "cs_D", "cs_E",
+                 "tile_staging", "predicate_dense", "cs_A", "cs_B1", "cs_B2", "cs_scan", "screen_split", "screen_resolve",
                  "tile_wait", "chi2_wait", "prune_e2", "prune_bounds", "prune_incumbent", "select_relist",
                  "slab_copy_in", "slab_copy_out", "part_fold", "part_scan", "part_lds", "part_store",
                  "stat_live_units", "stat_kept_units", "stat_singles", "stat_batches", "stat_pruned_periods",
-                 "stat_exact_retries", "stat_38", "stat_39")
+                 "stat_exact_retries", "stat_screen_parked", "stat_screen_valued")
         return dict(zip(names, [int(v) for v in arr]))
 
     def period_cycles(self):
@@ -409,7 +409,7 @@ class Context(object):
         if rc < 0:
             self._check(rc)
         names = ("lds_carve", "list_capacity", "dot_window", "predicate_read", "sort_window", "work_item",
-                 "singles_capacity", "tile_stage")
+                 "singles_capacity", "tile_stage", "screen_split")
         return bool(rc), dict(zip(names, [int(v) for v in arr]))
 
     def synchronize(self):

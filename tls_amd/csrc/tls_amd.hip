@@ -166,6 +166,11 @@ struct tls_ctx {
     size_t lds_bytes = 0;
     double S0 = 0, w0 = 1, depth_min = 0;
     double y_abs_max = 1.0;   // largest |flux| of the light curve(s) of the next launch: bounds the prefix sum (fast mode's eps)
+    bool screen_kernel = false;   // the next launch takes the fp32-screen variant (screen_pays)
+    double e_abs_max = INFINITY;   // largest |1 - flux| of the same (inf: a sample outside [0.5, 2]): admits the fp32 screen
+    DevBuf<float> d_split;    // fp32 screen: low halves of the folded samples, one region per workgroup
+    DevBuf<double> d_park;    // fp32 screen: parked cells, kParkCap per workgroup
+    long long q_count = 0;    // elements of the padded template rows (the fp32 screen's second copy starts there)
     tls_counters plan_counters = {0, 0, 0, 0, 0};
     bool counted = false;
 
@@ -268,11 +273,17 @@ int upload(tls_ctx* ctx, DevBuf<T>& buf, const T* host, size_t count) {
 
 // weights and the period-independent constant S0 = sum (1-y)^2 / dy^2
 void weights_from(const double* y, const double* dy, int64_t n, bool& uniform, double& w0,
-                  std::vector<double>& w, double& S0, double* y_abs_max = nullptr) {
+                  std::vector<double>& w, double& S0, double* y_abs_max = nullptr, double* e_abs_max = nullptr) {
     if (y_abs_max) {
         double m = 0.0;
         for (int64_t i = 0; i < n; ++i) m = std::max(m, std::fabs(y[i]));
         *y_abs_max = std::max(*y_abs_max, m);
+    }
+    if (e_abs_max) {
+        // 1 - y is exact for y in [0.5, 2] (Sterbenz) and a multiple of 2^-53 there: what the fp32 screen's split needs
+        double m = 0.0;
+        for (int64_t i = 0; i < n; ++i) m = (y[i] >= 0.5 && y[i] <= 2.0) ? std::max(m, std::fabs(1 - y[i])) : INFINITY;
+        *e_abs_max = std::max(*e_abs_max, m);
     }
     uniform = true;
     for (int64_t i = 1; i < n; ++i)
@@ -329,13 +340,14 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
         const size_t back = (size_t)tlsdev::pad_back(we.tiled ? we.xth : 1);
         we.q_offset = (int)(q_count + front);
         we.overshoot = tmpl->overshoot[r];
-        double s2 = 0.0, s1 = 0.0;
+        double s2 = 0.0, s1 = 0.0, s_abs = 0.0;
         if (q) q->insert(q->end(), front, 0.0);
         for (int64_t j = 0; j < len; ++j) {
             const double qj = 1 - tmpl->values[tmpl->offset[r] + j];  // core.py:68
             if (q) q->push_back(qj);
             s2 += qj * qj;
             s1 += qj;
+            s_abs += std::fabs(qj);
         }
         // constants of the pruning bound (cell_bound in tls_kernels.hip.h), rounded outwards
         double vq = 0.0;
@@ -348,7 +360,10 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
         we.prunable = (len == wd && we.k_mono >= 0 && we.overshoot > 0 && params->transit_depth_min >= 0) ? 1 : 0;
         we.k_mono *= (1 + 1e-12);
         we.c_proxy = 4 * we.overshoot * we.k_mono;
-        we.reserved = 0.0;
+        {   // fp32 screen (tlsdev::screen_cells): |B32 - B| <= screen_c * max|e|, doubled for the statistic's 2 rs B
+            const int S = we.tiled ? (tlsdev::kR - 1) * we.xth : 0;
+            we.screen_c = 2.0 * (1 + 1e-6) * ((double)(len + S) / 2 + 8) * 5.9604644775390625e-08 * 1.001 * s_abs;
+        }
         size_t row_total = front + (size_t)len + back;
         row_total = (row_total + 7) / 8 * 8;
         if (q) q->resize(q_count + row_total, 0.0);
@@ -446,22 +461,40 @@ void build_screens(const std::vector<tlsdev::WidthEntry>& widths, const std::vec
     }
 }
 
-// Pruning pays when enough trial cells pass the depth predicate (core.py:58), i.e. when the noise of
-// a window mean, sigma/sqrt(d), is large against transit_depth_min.  Expected passing fraction of a
-// flat, white light curve, averaged over the trial widths.  Measured on the 90-day configuration with the
-// piecewise-constant bound of round 3 (tools/gpu_prune_sweep.py, plain -> pruning kernel): 50 ppm 1.48 -> 1.61 ms
-// (fraction ~0.10: the bound pass is LDS-bound and costs what it saves), 100 ppm 2.50 -> 2.32, 200 ppm 3.37 -> 2.64,
-// 500 ppm 4.07 -> 2.90; +10 % on the tiled large-N variant at every noise level.  So: LDS-resident series, fraction
-// >= 0.15.  TLS_PRUNE=0/1 forces the choice (tests run both).
-bool pruning_pays(const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool resident) {
+// Expected fraction of trial cells that pass the depth predicate (core.py:58) on a flat, white light curve, averaged
+// over the trial widths: large when the noise of a window mean, sigma/sqrt(d), is large against transit_depth_min.  It
+// says how much of a period is dot products -- what the pruning variant and the fp32 screen save (pick below).
+double passing_fraction(const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min) {
+    if (!(sigma > 0) || widths.empty()) return 0.0;
+    double acc = 0.0;
+    for (const auto& we : widths) acc += 0.5 * std::erfc(depth_min * std::sqrt((double)we.width) / sigma / std::sqrt(2.0));
+    return acc / (double)widths.size();
+}
+// fp32 screen of the dot products (tlsdev::screen_cells) admissible: LDS-resident series, uniform weights, every sample
+// e = 1 - flux the exact sum of two fp32 halves (flux in [0.5, 2] and |e| < 2^-5)
+bool screen_admissible(bool resident, bool uniform, double e_abs_max) {
+    return resident && uniform && e_abs_max < 0.03125;
+}
+// Which variant of the LDS-resident search kernel a launch takes, from the expected passing fraction f of the depth
+// predicate.  Round 4, 90-day configuration, same box, ms (plain / fp32 screen / pruning): 50 ppm (f = 0.09) 1.19 / 1.23 /
+// 1.61; 75 ppm (0.16) 1.67 / 1.62 / 1.87; 100 ppm (0.20) 2.10 / 1.94 / 2.14; 150 ppm (0.28) 2.62 / 2.34 / 2.37; 200 ppm
+// (0.32) 2.94 / 2.54 / 2.47; 300 ppm (0.38) 3.22 / 2.76 / 2.58; 500 ppm (0.42) 3.61 / 2.93 / 2.75.  The
+// screen halves the FMA instructions of the dot products but adds a split pass and a valuation pass per period (DESIGN
+// section 4): it pays where the dot products dominate and the pruning passes do not pay yet.
+// TLS_PRUNE=0/1 and TLS_SCREEN32=0/1 force either choice (tests run all three variants).
+constexpr double kScreenFromFraction = 0.13, kPruneFromFraction = 0.24, kPruneFromFractionBesideScreen = 0.30;
+bool pruning_pays(const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool resident,
+                  bool screen_ok = false) {
     if (const char* env = std::getenv("TLS_PRUNE")) return std::atoi(env) != 0;
     if (!resident || !(sigma > 0) || widths.empty()) return false;
-    double acc = 0.0;
-    for (const auto& we : widths) {
-        if (!we.prunable) return false;
-        acc += 0.5 * std::erfc(depth_min * std::sqrt((double)we.width) / sigma / std::sqrt(2.0));
-    }
-    return acc / (double)widths.size() >= 0.15;
+    for (const auto& we : widths) if (!we.prunable) return false;
+    if (const char* env = std::getenv("TLS_SCREEN32")) screen_ok = screen_ok && std::atoi(env) != 0;
+    return passing_fraction(widths, sigma, depth_min) >= (screen_ok ? kPruneFromFractionBesideScreen : kPruneFromFraction);
+}
+bool screen_pays(const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool admissible) {
+    if (!admissible) return false;
+    if (const char* env = std::getenv("TLS_SCREEN32")) return std::atoi(env) != 0;
+    return passing_fraction(widths, sigma, depth_min) >= kScreenFromFraction;
 }
 
 // scatter of the flux itself: the noise estimate behind pruning_pays (a caller's dy may be in
@@ -600,9 +633,9 @@ hipError_t launch_split(tls_ctx* ctx, const tlsdev::SearchArgs& args, int blocks
     return hipGetLastError();
 }
 
-template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false, bool COUNTING = false>
+template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false, bool COUNTING = false, bool SCREEN = false>
 hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args, int blocks) {
-    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING, COUNTING>;
+    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING, COUNTING, SCREEN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
@@ -633,6 +666,8 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.w = ctx->uniform_w ? nullptr : (ctx->over_w ? ctx->over_w : ctx->d_w.ptr);
     a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.rows = ctx->d_rows.ptr;
     a.widths = ctx->d_widths.ptr; a.q = ctx->d_q.ptr; a.q2 = ctx->uniform_w ? nullptr : ctx->d_q2.ptr;
+    a.q32 = ctx->uniform_w ? reinterpret_cast<const float*>(ctx->d_q2.ptr) : nullptr;
+    a.split_lo = nullptr; a.park_cells = nullptr; a.e_abs_max = ctx->e_abs_max; a.q32_shifted = ctx->q_count;
     a.screens = ctx->d_screens.ptr;
     a.out_chi2 = ctx->over_chi2 ? ctx->over_chi2 : ctx->d_chi2.ptr;
     a.out_row = ctx->over_row ? ctx->over_row : ctx->d_row.ptr;
@@ -710,7 +745,20 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
      : count_work    ? launch_split<true, STAGE, false, true>(ctx, a, BLOCKS)                                                \
                      : launch_split<true, STAGE, false, false>(ctx, a, BLOCKS))
     const bool split = !ctx->resident && ctx->split && ctx->batch_curves == 1;
-    if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short, ctx->blocks);
+    // fp32 screen of the dot products (tlsdev::screen_cells): where the host expects it to pay (screen_pays); counting the
+    // work and the debug entries run the plain variant, whose bits it returns anyway
+    const bool screen = ctx->screen_kernel && screen_admissible(ctx->resident, ctx->uniform_w, ctx->e_abs_max) && !prune &&
+                        !count_work && !debug_folded && !debug_prefix;
+    if (screen) {
+        const size_t region = (size_t)ctx->M + 1 + (size_t)ctx->region_pad;
+        hipError_t er = ctx->d_split.reserve((size_t)ctx->blocks * region);
+        if (er != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er));
+        a.split_lo = ctx->d_split.ptr;
+        er = ctx->d_park.reserve((size_t)ctx->blocks * tlsdev::kParkCap * 2);   // (a ParkedCell is two doubles wide)
+        if (er != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er));
+        a.park_cells = ctx->d_park.ptr;
+        e = launch_variant<true, true, false, unsigned short, false, false, true>(ctx, a, ctx->blocks);
+    } else if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short, ctx->blocks);
     else if (!split) {
         if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int, ctx->blocks);
         else e = TLS_LAUNCH(false, false, unsigned int, ctx->blocks);
@@ -850,6 +898,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release();
     ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_pqueues.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
+    ctx->d_split.release(); ctx->d_park.release();
     for (auto& sl : ctx->slot) {
         sl.d_y.release(); sl.d_w.release(); sl.d_S0.release(); sl.d_w0.release(); sl.d_chi2.release(); sl.d_depth.release(); sl.d_row.release();
         if (sl.h_in) (void)hipHostFree(sl.h_in);
@@ -938,9 +987,9 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     // weights
     std::vector<double> w;
     bool uniform; double w0, S0;
-    double y_abs_max = 0.0;
-    weights_from(y, dy, n, uniform, w0, w, S0, &y_abs_max);
-    ctx->y_abs_max = y_abs_max;
+    double y_abs_max = 0.0, e_abs_max = 0.0;
+    weights_from(y, dy, n, uniform, w0, w, S0, &y_abs_max, &e_abs_max);
+    ctx->y_abs_max = y_abs_max; ctx->e_abs_max = e_abs_max;
 
     // launch geometry
     const size_t regions = uniform ? 2 : 3;
@@ -1150,7 +1199,12 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->n_widths = (int)widths.size();
     ctx->uniform_w = uniform; ctx->w0 = w0; ctx->S0 = S0; ctx->depth_min = params->transit_depth_min;
     ctx->host_widths = widths;
-    ctx->prune_kernel = uniform && pruning_pays(widths, flux_scatter(y, n), params->transit_depth_min, ctx->resident);
+    {
+        const double sigma = flux_scatter(y, n);
+        const bool scr_ok = screen_admissible(ctx->resident, uniform, ctx->e_abs_max);
+        ctx->prune_kernel = uniform && pruning_pays(widths, sigma, params->transit_depth_min, ctx->resident, scr_ok);
+        ctx->screen_kernel = screen_pays(widths, sigma, params->transit_depth_min, scr_ok);
+    }
     ctx->plan_counters = pc;
 
     // ONE pinned staging buffer, ONE device allocation, ONE asynchronous copy; nothing is waited for here (the
@@ -1165,7 +1219,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         L.t = place(nn * 8); L.y = place(nn * 8); L.w = place(uniform ? 0 : nn * 8);
         L.periods = place(np * 8); L.order = place(np * sizeof(int)); L.rows = place(np * sizeof(tlsdev::PeriodRows));
         L.widths = place(nw * sizeof(tlsdev::WidthEntry)); L.screens = place(nw * sizeof(tlsdev::RowScreen));
-        L.q = place(nq * 8); L.q2 = place(uniform ? 0 : nq * 8);
+        L.q = place(nq * 8); L.q2 = place(nq * 8);   // (uniform weights: the fp32 rows of the screen instead of q^2)
         const bool with_tiles = !ctx->resident && ctx->split;
         L.tile_prefix = place(with_tiles ? (np + 1) * sizeof(unsigned int) : 0);
         L.total = off;
@@ -1184,9 +1238,13 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         std::memcpy(h + L.widths, widths.data(), nw * sizeof(tlsdev::WidthEntry));
         std::memcpy(h + L.screens, screens.data(), nw * sizeof(tlsdev::RowScreen));
         std::memcpy(h + L.q, q.data(), nq * 8);
+        ctx->q_count = (long long)nq;
         if (!uniform) {
             double* q2 = reinterpret_cast<double*>(h + L.q2);
             for (size_t j = 0; j < nq; ++j) q2[j] = q[j] * q[j];
+        } else {
+            float* q32 = reinterpret_cast<float*>(h + L.q2);   // [nq] the rows | [nq] the rows one element later
+            for (size_t j = 0; j < nq; ++j) { q32[j] = (float)q[j]; q32[nq + j] = j ? (float)q[j - 1] : 0.0f; }
         }
         if (with_tiles) std::memcpy(h + L.tile_prefix, ctx->host_tile_prefix.data(), (np + 1) * sizeof(unsigned int));
         unsigned char* d = ctx->d_plan.ptr;
@@ -1221,11 +1279,16 @@ namespace {
 int update_flux_impl(tls_ctx* ctx, const double* y, const double* dy) {
     std::vector<double> w;
     bool uniform; double w0, S0;
-    double y_abs_max = 0.0;
-    weights_from(y, dy, ctx->n, uniform, w0, w, S0, &y_abs_max);
+    double y_abs_max = 0.0, e_abs_max = 0.0;
+    weights_from(y, dy, ctx->n, uniform, w0, w, S0, &y_abs_max, &e_abs_max);
     if (uniform != ctx->uniform_w) return kWeightsDiffer;
-    ctx->w0 = w0; ctx->S0 = S0; ctx->y_abs_max = y_abs_max;
-    ctx->prune_kernel = uniform && pruning_pays(ctx->host_widths, flux_scatter(y, ctx->n), ctx->depth_min, ctx->resident);
+    ctx->w0 = w0; ctx->S0 = S0; ctx->y_abs_max = y_abs_max; ctx->e_abs_max = e_abs_max;
+    {
+        const double sigma = flux_scatter(y, ctx->n);
+        const bool scr_ok = screen_admissible(ctx->resident, uniform, ctx->e_abs_max);
+        ctx->prune_kernel = uniform && pruning_pays(ctx->host_widths, sigma, ctx->depth_min, ctx->resident, scr_ok);
+        ctx->screen_kernel = screen_pays(ctx->host_widths, sigma, ctx->depth_min, scr_ok);
+    }
     const PlanLayout& L = ctx->layout;
     const size_t nn = (size_t)ctx->n;
     int rcs = stage_reserve(ctx, L.total);   // (waits for the previous upload out of the staging buffer)
@@ -1625,10 +1688,10 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         double* h_S0 = sl.h_in + (size_t)group * nn * (uni ? 1 : 2);
         double* h_w0 = h_S0 + group;
         double sigma_sum = 0.0;
-        double group_y_max = 0.0;
+        double group_y_max = 0.0, group_e_max = 0.0;
         for (int64_t c = 0; c < gc; ++c) {
             bool uniform; double w0, S0;
-            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0, &group_y_max);
+            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0, &group_y_max, &group_e_max);
             if (uniform != uni) { rc = fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy"); break; }
             h_S0[c] = S0; h_w0[c] = w0;
             std::memcpy(h_y + (size_t)c * nn, y + (c0 + c) * n, nn * 8);
@@ -1642,8 +1705,12 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         TLS_HIP(ctx, hipMemcpyAsync(sl.d_w0.ptr, h_w0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->copy_stream));
         TLS_HIP(ctx, hipEventRecord(sl.ev_in, ctx->copy_stream));
         TLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ev_in, 0));
-        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = group_y_max;
-        ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident);
+        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = group_y_max; ctx->e_abs_max = group_e_max;
+        {
+            const bool scr_ok = screen_admissible(ctx->resident, uni, ctx->e_abs_max);
+            ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
+            ctx->screen_kernel = screen_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, scr_ok);
+        }
         ctx->batch_curves = (int)gc;
         ctx->over_y = sl.d_y.ptr; ctx->over_w = uni ? nullptr : sl.d_w.ptr; ctx->over_S0 = sl.d_S0.ptr; ctx->over_w0 = sl.d_w0.ptr;
         ctx->over_chi2 = sl.d_chi2.ptr; ctx->over_row = sl.d_row.ptr; ctx->over_depth = sl.d_depth.ptr;
@@ -1773,10 +1840,10 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         double* h_w = sl.h_in + (size_t)group * nn;
         double* h_S0 = sl.h_in + (size_t)group * nn * (uni ? 1 : 2);
         double* h_w0 = h_S0 + group;
-        double sigma_sum = 0.0, group_y_max = 0.0;
+        double sigma_sum = 0.0, group_y_max = 0.0, group_e_max = 0.0;
         for (int64_t c = 0; c < gc; ++c) {
             bool uniform; double w0, S0;
-            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0, &group_y_max);
+            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0, &group_y_max, &group_e_max);
             if (uniform != uni) { rc = fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy"); break; }
             h_S0[c] = S0; h_w0[c] = w0;
             std::memcpy(h_y + (size_t)c * nn, y + (c0 + c) * n, nn * 8);
@@ -1788,8 +1855,12 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         if (!uni) TLS_HIP(ctx, hipMemcpyAsync(sl.d_w.ptr, h_w, (size_t)gc * nn * 8, hipMemcpyHostToDevice, ctx->stream));
         TLS_HIP(ctx, hipMemcpyAsync(sl.d_S0.ptr, h_S0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->stream));
         TLS_HIP(ctx, hipMemcpyAsync(sl.d_w0.ptr, h_w0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->stream));
-        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = group_y_max;
-        ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident);
+        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = group_y_max; ctx->e_abs_max = group_e_max;
+        {
+            const bool scr_ok = screen_admissible(ctx->resident, uni, ctx->e_abs_max);
+            ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
+            ctx->screen_kernel = screen_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, scr_ok);
+        }
         ctx->batch_curves = (int)gc;
         ctx->over_y = sl.d_y.ptr; ctx->over_w = uni ? nullptr : sl.d_w.ptr; ctx->over_S0 = sl.d_S0.ptr; ctx->over_w0 = sl.d_w0.ptr;
         ctx->over_chi2 = sl.d_chi2.ptr; ctx->over_row = sl.d_row.ptr; ctx->over_depth = sl.d_depth.ptr;

@@ -86,6 +86,7 @@ enum CheckCode {
     kChkWorkItem = 5,      // period / row index out of range
     kChkSinglesCap = 6,    // re-listed positions outgrew the row's slots
     kChkTileStage = 7,     // a tile was staged beyond the LDS buffer
+    kChkSplit = 8,         // fp32 screen: a sample is not the exact sum of its two fp32 halves
 };
 
 constexpr int kWave = 64;
@@ -448,7 +449,7 @@ struct WidthEntry {
     double var_q;     // sum_j (q_j - mean q)^2
     double k_mono;    // sum_j q_j - overshoot * sum_j q_j^2
     double c_proxy;   // 4 * overshoot * k_mono: c_proxy * mean^2 ranks the cells of all rows by promise
-    double reserved;
+    double screen_c;  // fp32 screen: |B32 - B| <= screen_c * max|e| for every window of this row (screen_cells)
 };
 
 // In-range widths of one period (core.py:143-156): the contiguous range [k_lo, k_hi) of the
@@ -520,6 +521,11 @@ struct SearchArgs {
     int exact_prefix;           // != 0: every period in exact mode (developer switch TLS_EXACT_PREFIX=1, debug entries)
     int cumsum_round;           // slab variant: elements the prefix sum takes through LDS per round
     int fast_slab;              // != 0: fast mode also for a series in the HBM slab (the host's choice: few undecided windows)
+    const float* q32;           // fp32 screen: the template rows rounded to fp32, same layout as q (uniform weights)
+    long long q32_shifted;      // ... and, this many floats further, the same rows stored one element later
+    float* split_lo;            // fp32 screen: [blocks][region] low halves of the folded samples (e = hi + lo exactly)
+    void* park_cells;           // fp32 screen: [blocks][kParkCap] parked cells (tlsdev::ParkedCell)
+    double e_abs_max;           // fp32 screen: max |1 - flux| of the light curve(s) of this launch
     double S0;
     double w0;
     int n, W, M;            // points, patch length, n + W
@@ -1746,6 +1752,269 @@ __device__ __forceinline__ Best settle_best(const Lead& lead, const_width_ptr wi
     return b;
 }
 
+// ---------------------------------------------------------------------------------------
+// fp32 SCREEN of the sliding dot products (round 4; LDS-resident kernel, uniform weights, plain variant).
+//
+// The dot product B(i) = sum_j q_j e_{i+j} is what phase 3b spends its time on, and all but one of the ~1e4 cells of a
+// period only have to LOSE.  So the folded samples are kept as two fp32 halves, e = hi + lo EXACTLY (e = 1 - flux is a
+// multiple of 2^-53 and the host admits the screen only when max |e| < 2^-5: 48 significant bits at most), the dot
+// products of all cells are formed from the high halves in packed fp32 (v_pk_fma_f32: two taps per lane and instruction,
+// half the LDS bytes per sample), and a cell is valued in fp64 -- by the very additions the plain kernel performs, so
+// the same bits -- only when its fp32 estimate, widened by a rigorous error bound, can still be the period's minimum:
+//     |B32 - B| <= screen_c(row) * max|e|      (inputs rounded once, n <= (L + S)/2 + 8 fused accumulations per half)
+//     est = rs (rs A - 2 B32),  err = |rs| * 2 screen_c max|e| + |est| * (reach + 1e-13),  v in [est - err, est + err]
+// A lane keeps the cell with the smallest upper bound (`ScreenSlot`); a cell whose lower bound exceeds it cannot be the
+// minimum and is dropped; the others (near-ties, and the slot cells that survive the workgroup-wide minimum of the
+// upper bounds at the end of the period) go through exact_window_dot + consider().  The winner of the plain kernel is
+// always among them, consider() is the plain kernel's comparison, so chi2, row and depth are the plain kernel's bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) float* const_f32_ptr;
+typedef const __attribute__((address_space(3))) float* lds_f32_ptr;
+typedef const __attribute__((address_space(1))) float* glob_f32_ptr;
+typedef const __attribute__((address_space(1))) double* glob_f64_ptr;
+
+struct ScreenSlot {      // the lane's cell with the smallest upper bound so far
+    double hi, lo;       // est + err, est - err; hi = +inf: empty
+    int k, i;            // row (index into widths), T0 sample index
+};
+__device__ __forceinline__ ScreenSlot empty_slot() {
+    ScreenSlot s; s.hi = INFINITY; s.lo = INFINITY; s.k = 0x7fffffff; s.i = 0x7fffffff;
+    return s;
+}
+
+// four pairs of consecutive fp32 samples; the address is 8-byte aligned (an unaligned ds_read_b64 is served at an
+// eighth of the rate on gfx950: measured, tools/micro/pk_dot.hip)
+__device__ __forceinline__ void load_pairs32(unsigned addr, f32x2 (&x)[kU / 2]) {
+    static_assert(kU == 8, "the asm block reads 4 pairs");
+    asm volatile(
+        "ds_read_b64 %0, %4\n\t"
+        "ds_read_b64 %1, %4 offset:8\n\t"
+        "ds_read_b64 %2, %4 offset:16\n\t"
+        "ds_read_b64 %3, %4 offset:24\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(addr) : "memory");
+}
+
+// kR sliding fp32 dot products of one lane, windows XTH samples apart (dot_windows in packed fp32).  Sample-major like
+// dot_windows: the pair of samples (t, t+1) feeds window r with the pair of taps (t - r*XTH, t + 1 - r*XTH), which is an
+// even-aligned pair of the tap stream for even r*XTH and of the stream shifted by one tap otherwise -- both streams are
+// wave-uniform scalar loads (the shifted one from its own copy of the rows), so every v_pk_fma_f32 takes its taps from
+// an SGPR pair.
+template <int XTH>
+__device__ __forceinline__ void dot_windows32(unsigned addr, const_f32_ptr q, const_f32_ptr q_shifted, int L, float (&B)[kR]) {
+    constexpr int S = (kR - 1) * XTH;
+    constexpr int S0 = (S + 1) & ~1;
+    f32x2 acc[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) acc[r] = f32x2{0.0f, 0.0f};
+    for (int t0 = 0; t0 < L + S; t0 += kU) {
+        const const_f32_ptr qa = q + (t0 - S0);        // qa[m] = q_ext[t0 - S0 + m]
+        // the same stream one tap later, from a second copy of the rows stored one element further (q_shifted[j] =
+        // q[j - 1]): two aligned scalar loads instead of one load and a dozen s_mov to re-pair its registers
+        const const_f32_ptr qb = q_shifted + (t0 - S0);
+        float ta[kU + S0], tb[kU + S0 + 2];
+#pragma unroll
+        for (int m = 0; m < kU + S0; ++m) ta[m] = qa[m];
+#pragma unroll
+        for (int m = 0; m < kU + S0 + 2; ++m) tb[m] = qb[m];
+        f32x2 x[kU / 2];
+        load_pairs32(addr + 4u * (unsigned)t0, x);
+#pragma unroll
+        for (int k = 0; k < kU / 2; ++k)
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+                const int off = r * XTH;
+                f32x2 tap;
+                if ((off & 1) == 0) { const int m = 2 * k - off + S0; tap = f32x2{ta[m], ta[m + 1]}; }
+                else { const int m = 2 * k - off + S0 + 1; tap = f32x2{tb[m], tb[m + 1]}; }
+                acc[r] = __builtin_elementwise_fma(tap, x[k], acc[r]);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < kR; ++r) B[r] = acc[r].x + acc[r].y;
+}
+// one window per lane (wide T0 strides, re-listed positions)
+__device__ __forceinline__ float dot_window32(unsigned addr, const_f32_ptr q, int L) {
+    f32x2 acc = f32x2{0.0f, 0.0f};
+    for (int t0 = 0; t0 < L; t0 += kU) {
+        const const_f32_ptr qs = q + t0;
+        float ta[kU];
+#pragma unroll
+        for (int m = 0; m < kU; ++m) ta[m] = qs[m];
+        f32x2 x[kU / 2];
+        load_pairs32(addr + 4u * (unsigned)t0, x);
+#pragma unroll
+        for (int k = 0; k < kU / 2; ++k) acc = __builtin_elementwise_fma(f32x2{ta[2 * k], ta[2 * k + 1]}, x[k], acc);
+    }
+    return acc.x + acc.y;
+}
+
+// The dot product of ONE cell as the plain kernel forms it: one fp64 accumulator, taps in order (the zero taps of the
+// padded rows add nothing), samples rebuilt from their halves.  One wavefront works on the one cell (wave-uniform
+// arguments): lane j rebuilds sample j of a 64-sample stretch -- one memory round trip per stretch instead of one per
+// tap -- and puts it into the wavefront's staging buffer in LDS; the chain of additions then runs like the plain kernel's
+// one-window loop: taps from scalar loads, samples as broadcast LDS reads, eight at a time.  Every period needs this
+// once (its winner) and now and then for a near-tie.
+__device__ __forceinline__ double exact_window_dot(unsigned hi_addr, glob_f32_ptr lo, const_f64_ptr q_row, int L, int i, double* stage) {
+    const lds_f32_ptr hi = (lds_f32_ptr)(uintptr_t)hi_addr;
+    const int lane = (int)(threadIdx.x & (kWave - 1));
+    double B = 0.0;
+#pragma unroll 1
+    for (int base = 0; base < L; base += kWave) {
+        const int idx = base + lane;
+        stage[lane] = idx < L ? (double)hi[i + idx] + (double)lo[i + idx] : 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wavefront's own buffer: no barrier)
+        const int n = L - base < kWave ? L - base : kWave;
+#pragma unroll 1
+        for (int t0 = 0; t0 < n; t0 += kU) {
+            const const_f64_ptr qs = q_row + (base + t0);   // (rows are zero padded to a multiple of kU and beyond)
+            double taps[kU], x[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) taps[u] = qs[u];
+            load_taps<true>(stage + t0, x);
+#pragma unroll
+            for (int u = 0; u < kU; ++u) B = fma(taps[u], x[u], B);
+        }
+    }
+    return B;
+}
+
+// The same for ONE lane on its own (lane-divergent arguments, a memory round trip per tap): only when the workgroup's
+// list of parked cells is full (a light curve on which thousands of cells tie, e.g. a constant one).
+__device__ __forceinline__ double exact_window_dot_lane(unsigned hi_addr, glob_f32_ptr lo, glob_f64_ptr q, int q_offset, int L, int i) {
+    const lds_f32_ptr hi = (lds_f32_ptr)(uintptr_t)hi_addr;
+    double B = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < L; ++j) B = fma(q[q_offset + j], (double)hi[i + j] + (double)lo[i + j], B);
+    return B;
+}
+
+// Cells whose interval overlaps their lane's slot are PARKED in a list of the workgroup (its counter in LDS, the cells in
+// the workgroup's global scratch: a few per period on a quiet light curve, hundreds on a noisy one) and valued after the
+// last batch, by one wavefront, and only if their lower bound still reaches the workgroup's smallest upper bound by
+// then: most of them no longer do.
+struct ParkedCell { double lo; int k, i; };
+constexpr int kParkCap = 1024;    // cells per workgroup and period; beyond that a lane values its cell on the spot
+struct ParkList {                 // lives in the idle prefix-sum scratch (LDS)
+    unsigned int n; unsigned int pad_[3];
+    double stage[kWave];          // staging buffer of the wavefront that values the parked cells (exact_window_dot)
+};
+static_assert(sizeof(ParkList) <= kCumsumScratchBytes, "the list head of the parked cells does not fit the prefix-sum scratch");
+struct ScreenEnv {          // what the screen needs besides the cells
+    unsigned eh_addr;       // LDS address of the high halves
+    glob_f32_ptr lo_g;      // low halves (global scratch of the workgroup)
+    glob_f64_ptr q_g;       // template rows, fp64
+    ParkList* park;
+    ParkedCell* cells;      // [kParkCap] the parked cells of this workgroup (global scratch)
+    unsigned long long* stat;   // developer statistics (phase-clock buffer) or nullptr
+};
+
+// One cell valued as the plain kernel values it and met with a lane's lead (lane-divergent: the overflow path)
+__device__ __forceinline__ void screen_value_cell_lane(Lead& lead, int k_c, int i_c, const DepthRule& rule, const_width_ptr widths_c,
+                                                       const double* x_all, const ScreenEnv& env) {
+    const int d_c = widths_c[k_c].width;
+    const double B = exact_window_dot_lane(env.eh_addr, env.lo_g, env.q_g, widths_c[k_c].q_offset, widths_c[k_c].q_len, i_c);
+    unsigned int n_dummy = 0;
+    bool und_dummy = false;   // (the cell passed the depth predicate in screen_cells, by the same expressions)
+    consider<true, false>(lead, x_all[i_c], x_all[i_c + d_c], i_c, widths_c[k_c].inv_d, (double)d_c, rule, widths_c[k_c].overshoot,
+                          widths_c[k_c].sum_q2, B, k_c, n_dummy, und_dummy, widths_c, x_all);
+}
+// ... by the whole wavefront (wave-uniform k_c, i_c), met with the lead of lane `owner`
+__device__ __forceinline__ void screen_value_cell(Lead& lead, int owner, int k_c, int i_c, const DepthRule& rule,
+                                                  const_width_ptr widths_c, const double* x_all, const ScreenEnv& env) {
+    const int d_c = widths_c[k_c].width;
+    const double B = exact_window_dot(env.eh_addr, env.lo_g, (const_f64_ptr)(const double*)env.q_g + widths_c[k_c].q_offset,
+                                      widths_c[k_c].q_len, i_c, env.park->stage);
+    if ((int)(threadIdx.x & (kWave - 1)) == owner) {
+        unsigned int n_dummy = 0;
+        bool und_dummy = false;
+        consider<true, false>(lead, x_all[i_c], x_all[i_c + d_c], i_c, widths_c[k_c].inv_d, (double)d_c, rule,
+                              widths_c[k_c].overshoot, widths_c[k_c].sum_q2, B, k_c, n_dummy, und_dummy, widths_c, x_all);
+    }
+}
+// park a cell (lane-divergent); a full list values it on the spot
+__device__ __forceinline__ void park_cell(Lead& lead, double lo, int k_c, int i_c, const DepthRule& rule, const_width_ptr widths_c,
+                                          const double* x_all, const ScreenEnv& env) {
+    const unsigned int at = atomicAdd(&env.park->n, 1u);
+    if (at < (unsigned int)kParkCap) {
+        env.cells[at].lo = lo; env.cells[at].k = k_c; env.cells[at].i = i_c;
+    } else {
+        screen_value_cell_lane(lead, k_c, i_c, rule, widths_c, x_all, env);
+    }
+    if (env.stat) atomicAdd(env.stat, 1ull);
+}
+
+// R cells of one row (the kR windows of a chunk, or one window) against the lane's slot: consider_cells for the screen.
+// Straight-line code decides which cells can still be the minimum (`qual`); those few are handled out of line.
+template <int R>
+__device__ __forceinline__ void screen_cells(Lead& lead, ScreenSlot& slot, const double* x, int i0, int step, int d, double inv_d,
+                                             double dd, const DepthRule& rule, double overshoot, double A, const float (&B32)[R],
+                                             int k, double errB2, bool& undecided, const_width_ptr widths_c, const double* x_all,
+                                             const ScreenEnv& env) {
+    const double hi_t = rule.dmin + rule.eps, lo_t = rule.dmin - rule.eps;
+    const double rel = rule.reach + 1e-13;
+    bool pend = false;
+    unsigned int qual = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double dX = x[i0 + r * step + d] - x[i0 + r * step];
+        const double m_fast = dX * inv_d;
+        const bool live = m_fast > hi_t;
+        pend |= !live && m_fast >= lo_t;
+        const double rs_f = 2.0 * (m_fast * overshoot);            // (the same expressions as consider)
+        const double est = rs_f * (rs_f * A - 2.0 * (double)B32[r]);
+        const double err = fabs(rs_f) * errB2 + fabs(est) * rel;
+        const double lo = est - err, hi = est + err;
+        // below the slot cell for certain: it takes the slot, the old cell (lower bound above this upper bound) is out;
+        // intervals that overlap: out of line (about one cell in a few hundred)
+        const bool clear = live && hi < slot.lo;
+        qual |= (live && !clear && lo <= slot.hi) ? (1u << r) : 0u;
+        slot.hi = clear ? hi : slot.hi;
+        slot.lo = clear ? lo : slot.lo;
+        slot.k = clear ? k : slot.k;
+        slot.i = clear ? i0 + r * step : slot.i;
+    }
+    if (pend) {   // a window inside the undecided band of the depth predicate (depth_pass)
+        if (!rule.exact_mode) undecided = true;
+        else {
+#pragma unroll 1
+            for (int r = 0; r < R; ++r) {
+                const double* xr = x + (i0 + r * step);
+                asm volatile("" : "+v"(xr));
+                const double dX = xr[d] - xr[0];
+                const double m_fast = dX * inv_d;
+                if (!(m_fast > hi_t) && m_fast >= lo_t && (1.0 - (dd - dX) / dd) > rule.dmin) qual |= 1u << r;   // (the slot test follows)
+            }
+        }
+    }
+#pragma unroll 1
+    while (qual) {
+        const int r = __ffs((int)qual) - 1;
+        qual &= qual - 1u;
+        float b32 = B32[0];
+#pragma unroll
+        for (int rr = 1; rr < R; ++rr) b32 = r == rr ? B32[rr] : b32;
+        const int i = i0 + r * step;
+        const double* xr = x + i;
+        asm volatile("" : "+v"(xr));   // a second read, not values kept from the first
+        const double dX = xr[d] - xr[0];
+        const double m_fast = dX * inv_d;
+        const double rs_f = 2.0 * (m_fast * overshoot);
+        const double est = rs_f * (rs_f * A - 2.0 * (double)b32);
+        const double err = fabs(rs_f) * errB2 + fabs(est) * rel;
+        const double lo = est - err, hi = est + err;
+        if (!(lo <= slot.hi)) continue;   // (the slot may have moved since the straight-line test)
+        if (hi < slot.hi) {   // the new smallest upper bound takes the slot; the old slot cell is parked if it still overlaps
+            const double lo_o = slot.lo;
+            const int k_o = slot.k, i_o = slot.i;
+            slot.hi = hi; slot.lo = lo; slot.k = k; slot.i = i;
+            if (lo_o <= hi) park_cell(lead, lo_o, k_o, i_o, rule, widths_c, x_all, env);
+        } else {
+            park_cell(lead, lo, k, i, rule, widths_c, x_all, env);
+        }
+    }
+}
+
 // append the live lanes' units to the row's list (order inside a list is irrelevant)
 __device__ __forceinline__ void push_live(bool live, unsigned int unit, unsigned int* live_count,
                                           unsigned int* list, int lane) {
@@ -2906,7 +3175,9 @@ typedef const __attribute__((address_space(4))) SearchArgs* args_ptr;
 // the same code, so the results are the same bits.
 enum { kRoleAll = 0, kRoleFold = 1, kRoleSearch = 2 };
 // One kernel, one workgroup per period from the fold to the argmin (LDS-resident series; survey batches on long series).
-template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false, bool COUNTING = true>
+// SCREEN: the fp32 screen of the dot products (screen_cells; LDS-resident series, uniform weights, plain variant; the
+// host admits it when every sample splits exactly into two fp32 halves).
+template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false, bool COUNTING = true, bool SCREEN = false>
 __global__ void __launch_bounds__(TLS_LAUNCH_THREADS, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs) {
     constexpr int ROLE = kRoleAll;
@@ -2925,14 +3196,14 @@ template <bool UNI_, bool STAGE_, bool PRUNE_ = false, bool COUNT_ = true>
 __global__ void __launch_bounds__(TLS_LAUNCH_THREADS, TLS_WAVES_PER_EU)
 tls_fold_search_kernel(const SearchArgs) {
     {
-        constexpr bool RESIDENT = false, UNIFORM_W = UNI_, STAGE_C = false, WITH_PRUNING = false, COUNTING = false;
+        constexpr bool RESIDENT = false, UNIFORM_W = UNI_, STAGE_C = false, WITH_PRUNING = false, COUNTING = false, SCREEN = false;
         typedef unsigned int IdxT;
         constexpr int ROLE = kRoleFold;
 #include "tls_search_body.inc.h"
     }
     __syncthreads();
     {
-        constexpr bool RESIDENT = false, UNIFORM_W = UNI_, STAGE_C = STAGE_, WITH_PRUNING = PRUNE_, COUNTING = COUNT_;
+        constexpr bool RESIDENT = false, UNIFORM_W = UNI_, STAGE_C = STAGE_, WITH_PRUNING = PRUNE_, COUNTING = COUNT_, SCREEN = false;
         typedef unsigned int IdxT;
         constexpr int ROLE = kRoleSearch;
 #include "tls_search_body.inc.h"

@@ -27,6 +27,8 @@
     // the pruning variant is a separate instantiation: its extra state costs the plain variant 3-8 %
     // when both live in one kernel, and the host knows from the noise level which one pays
     constexpr bool PRUNE = UNIFORM_W && WITH_PRUNING && (TLS_PRUNE != 0);
+    // the fp32 screen of the dot products (screen_cells): its own instantiation, chosen by the host
+    constexpr bool SCR = SCREEN && RESIDENT && UNIFORM_W && !WITH_PRUNING && !COUNTING && ROLE == kRoleAll;
     // coarse prefix sum of e^2 for the pruning bound; the cumsum scratch is dead by the time it is built
     double* P2 = reinterpret_cast<double*>(cumsum_scratch);
     static_assert(kCumsumScratchBytes >= 8 * (kP2MaxBlocks + 1), "coarse prefix sum does not fit the cumsum scratch");
@@ -393,8 +395,55 @@
         }
         __syncthreads();
         pc.mark(8);
+        // fp32 screen: the samples leave their fp64 form -- high halves twice in LDS (hi[k] and, one sample later, hi1[k] =
+        // hi[k + 1]: a lane reads PAIRS of samples with 8-byte-aligned ds_read_b64 whatever the parity of its first
+        // sample), low halves in the workgroup's global scratch (read only when a cell is valued in fp64)
+        [[maybe_unused]] unsigned eh_addr = 0, eh1_addr = 0;
+        [[maybe_unused]] glob_f32_ptr lo_g = nullptr;
+        if constexpr (SCR) {
+            // in place, in ascending chunks: the floats of a chunk land below every double that is still to be read
+            constexpr int kSplitPer = 6;
+            float* const hi0 = reinterpret_cast<float*>(regA);
+            float* const hi1 = hi0 + ((RS + 1) & ~1);   // 8-byte aligned like hi0; its RS - 1 entries end inside the region
+            float* const lo_w = ap->split_lo + (long long)blockIdx.x * RS;
+#pragma unroll 1
+            for (int c0 = 0; c0 < RS; c0 += kSplitPer * nt) {
+                double v[kSplitPer];
+#pragma unroll
+                for (int j = 0; j < kSplitPer; ++j) { const int k = c0 + tid + j * nt; v[j] = k < RS ? regA[k] : 0.0; }
+                lds_barrier();   // (LDS only: the low halves in global memory are published by the barrier behind phase 3a)
+#pragma unroll
+                for (int j = 0; j < kSplitPer; ++j) {
+                    const int k = c0 + tid + j * nt;
+                    if (k < RS) {
+                        const float h = (float)v[j];
+                        const float l = (float)(v[j] - (double)h);
+                        TLS_CHECK(*ap, (double)h + (double)l == v[j], kChkSplit);
+                        hi0[k] = h;
+                        lo_w[k] = l;
+                    }
+                }
+                // (the next chunk's doubles lie above this chunk's floats: no barrier between the stores and its loads)
+            }
+            lds_barrier();
+            for (int k = tid; k + 1 < RS; k += nt) hi1[k] = hi0[k + 1];
+            eh_addr = lds_address(hi0);
+            eh1_addr = lds_address(hi1);
+            lo_g = (glob_f32_ptr)lo_w;
+            if (tid == 0) reinterpret_cast<ParkList*>(cumsum_scratch)->n = 0u;   // (the prefix-sum scratch is idle in phase 3)
+            lds_barrier();
+            pc.mark(18);
+        }
+        [[maybe_unused]] ScreenEnv scr_env;
+        if constexpr (SCR) {
+            scr_env.eh_addr = eh_addr; scr_env.lo_g = lo_g; scr_env.q_g = (glob_f64_ptr)ap->q;
+            scr_env.park = reinterpret_cast<ParkList*>(cumsum_scratch);
+            scr_env.cells = reinterpret_cast<ParkedCell*>(ap->park_cells) + (long long)blockIdx.x * kParkCap;
+            scr_env.stat = ap->phase_cycles ? ap->phase_cycles + 38 : nullptr;
+        }
 
         Lead lead = no_lead();
+        [[maybe_unused]] ScreenSlot scr_slot = empty_slot();
         unsigned int n_eval = 0;          // cells this lane evaluated in this period (32 bits: one add per window)
         unsigned long long n_steps = 0;
         unsigned long long n_issued = 0;   // FMAs per lane of this wave's dot products (wave-uniform)
@@ -1094,7 +1143,35 @@
                     const int reach = (tiled && !relisted) ? (kR - 1) * xth : 0;
                     n_issued += (unsigned long long)((L + reach + kU - 1) / kU * kU) * (reach ? kR : 1) * (UNIFORM_W ? 1 : 2);
                 }
-                if (tiled && !relisted) {
+                [[maybe_unused]] const double errB2 = SCR ? widths_c[k].screen_c * ap->e_abs_max + 1e-30 : 0.0;
+                if (SCR && tiled && !relisted) {
+                    if constexpr (SCR) {
+                        // kR windows per lane in packed fp32, then the screen
+                        const int b = unit * kR * xth;
+                        TLS_CHECK(*ap, !have || (b >= p_lo && b + (L + (kR - 1) * xth + kU - 1) / kU * kU <= M + 1 + region_pad), kChkDotWindow);
+                        const unsigned pa = ((b & 1) ? eh1_addr - 4u : eh_addr) + 4u * (unsigned)b;
+                        const const_f32_ptr q32 = (const_f32_ptr)ap->q32 + q_offset;
+                        const const_f32_ptr q32s = (const_f32_ptr)ap->q32 + (ap->q32_shifted + q_offset);
+                        float B32[kR];
+                        switch (xth) {
+                            case 1: dot_windows32<1>(pa, q32, q32s, L, B32); break;
+                            case 2: dot_windows32<2>(pa, q32, q32s, L, B32); break;
+                            case 3: dot_windows32<3>(pa, q32, q32s, L, B32); break;
+                            case 4: dot_windows32<4>(pa, q32, q32s, L, B32); break;
+                            case 5: dot_windows32<5>(pa, q32, q32s, L, B32); break;
+                            default:
+#pragma unroll
+                                for (int r = 0; r < kR; ++r) {
+                                    const int br = b + r * xth;
+                                    B32[r] = dot_window32(((br & 1) ? eh1_addr - 4u : eh_addr) + 4u * (unsigned)br, q32, L);
+                                }
+                                break;
+                        }
+                        if (have)
+                            screen_cells<kR>(lead, scr_slot, c_base, b, xth, d, inv_d, dd, rule, overshoot, sum_q2, B32, k, errB2, undecided,
+                                             widths_c, regB, scr_env);
+                    }
+                } else if (tiled && !relisted) {
                     // kR windows per lane, xth samples apart
                     const int u0 = unit * kR;
                     const int b = u0 * xth;
@@ -1169,6 +1246,14 @@
                     }
                     const int i = unit * xth;
                     TLS_CHECK(*ap, !have || (i >= p_lo && i + (L + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + ap->tile_len + ap->tile_halo)), kChkDotWindow);
+                    if constexpr (SCR) {
+                        float B1w[1];
+                        B1w[0] = dot_window32(((i & 1) ? eh1_addr - 4u : eh_addr) + 4u * (unsigned)i, (const_f32_ptr)ap->q32 + q_offset, L);
+                        if (have)
+                            screen_cells<1>(lead, scr_slot, c_base, i, 1, d, inv_d, dd, rule, overshoot, sum_q2, B1w, k, errB2, undecided,
+                                            widths_c, regB, scr_env);
+                        continue;
+                    }
                     const double* e = e_base + i;
                     double B0 = 0, B1 = 0, A0 = 0, A1 = 0;
                     if constexpr (UNIFORM_W) {
@@ -1210,6 +1295,13 @@
         // (an LDS flag, not __syncthreads_or: the library routine brings static LDS of its own, and the slab variant's
         // launches already ask for all 160 KB)
         if (undecided) s_work[flag_slot] = 1;
+        if constexpr (SCR) {
+            // (fp32 screen: every wavefront's smallest upper bound travels with the same barrier; wsum is idle here)
+            double u_min = scr_slot.hi;
+#pragma unroll
+            for (int delta = kWave / 2; delta > 0; delta >>= 1) u_min = fmin(u_min, __shfl_down(u_min, delta, kWave));
+            if (lane == 0) reinterpret_cast<double*>(wsum)[wave] = u_min;
+        }
         __syncthreads();
         const int any_undecided = __builtin_amdgcn_readfirstlane(s_work[flag_slot]);
         if (tid == 0) s_work[3 - flag_slot] = 0;   // the next attempt's flag: nobody touches it before several barriers from now
@@ -1221,6 +1313,28 @@
             break;
         }
         pc.mark(21);
+
+        if constexpr (SCR) {
+            // the smallest upper bound of the workgroup: a slot cell whose lower bound reaches it may be the period's
+            // minimum and is valued now; every other cell of the period has been dropped above it or valued already
+            double U = reinterpret_cast<const double*>(wsum)[0];
+            for (int v = 1; v < nw; ++v) U = fmin(U, reinterpret_cast<const double*>(wsum)[v]);
+            // the slot cells that reach it join the parked ones; then every wavefront takes its share of the list
+            if (scr_slot.hi < INFINITY && scr_slot.lo <= U) park_cell(lead, scr_slot.lo, scr_slot.k, scr_slot.i, rule, widths_c, regB, scr_env);
+            __syncthreads();
+            const int n_parked = (int)(scr_env.park->n < (unsigned int)kParkCap ? scr_env.park->n : (unsigned int)kParkCap);
+            // (one wavefront values them, one after the other: a period has one or two; the others wait at phase 4's barrier)
+#pragma unroll 1
+            for (int e = 0; e < (wave == 0 ? n_parked : 0); ++e) {
+                const ParkedCell pcell = scr_env.cells[e];
+                if (__builtin_amdgcn_readfirstlane((int)(pcell.lo <= U)) != 0) {
+                    screen_value_cell(lead, 0, __builtin_amdgcn_readfirstlane(pcell.k), __builtin_amdgcn_readfirstlane(pcell.i), rule,
+                                      widths_c, regB, scr_env);
+                    if (ap->phase_cycles && lane == 0) atomicAdd(&ap->phase_cycles[39], 1ull);
+                }
+            }
+            pc.mark(19);
+        }
 
         // ---- phase 4: argmin over the workgroup --------------------------------------
         Best best = settle_best<UNIFORM_W, !RESIDENT>(lead, widths_c, regB);
