@@ -1323,14 +1323,22 @@
             if (scr_slot.hi < INFINITY && scr_slot.lo <= U) park_cell(lead, scr_slot.lo, scr_slot.k, scr_slot.i, rule, widths_c, regB, scr_env);
             __syncthreads();
             const int n_parked = (int)(scr_env.park->n < (unsigned int)kParkCap ? scr_env.park->n : (unsigned int)kParkCap);
-            // (one wavefront values them, one after the other: a period has one or two; the others wait at phase 4's barrier)
+            // (one wavefront values them, one after the other: a period has one or two that still reach U; the others wait
+            // at phase 4's barrier.  The list is read 64 cells at a time, one per lane.)
+            if (wave == 0) {
 #pragma unroll 1
-            for (int e = 0; e < (wave == 0 ? n_parked : 0); ++e) {
-                const ParkedCell pcell = scr_env.cells[e];
-                if (__builtin_amdgcn_readfirstlane((int)(pcell.lo <= U)) != 0) {
-                    screen_value_cell(lead, 0, __builtin_amdgcn_readfirstlane(pcell.k), __builtin_amdgcn_readfirstlane(pcell.i), rule,
-                                      widths_c, regB, scr_env);
-                    if (ap->phase_cycles && lane == 0) atomicAdd(&ap->phase_cycles[39], 1ull);
+                for (int e0 = 0; e0 < n_parked; e0 += kWave) {
+                    ParkedCell pcell;
+                    pcell.lo = INFINITY; pcell.k = 0; pcell.i = 0;
+                    if (e0 + lane < n_parked) pcell = scr_env.cells[e0 + lane];
+                    unsigned long long reach = ballot64(pcell.lo <= U);
+#pragma unroll 1
+                    while (reach) {
+                        const int src = __ffsll((long long)reach) - 1;
+                        reach &= reach - 1ull;
+                        screen_value_cell(lead, 0, lane_value(pcell.k, src), lane_value(pcell.i, src), rule, widths_c, regB, scr_env);
+                        if (ap->phase_cycles && lane == 0) atomicAdd(&ap->phase_cycles[39], 1ull);
+                    }
                 }
             }
             pc.mark(19);
