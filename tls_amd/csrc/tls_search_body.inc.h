@@ -410,7 +410,8 @@
             for (int c0 = 0; c0 < RS; c0 += kSplitPer * nt) {
                 double v[kSplitPer];
 #pragma unroll
-                for (int j = 0; j < kSplitPer; ++j) { const int k = c0 + tid + j * nt; v[j] = k < RS ? regA[k] : 0.0; }
+                // (the spare entries behind the samples hold the previous period's floats by now: zero again)
+                for (int j = 0; j < kSplitPer; ++j) { const int k = c0 + tid + j * nt; v[j] = k < M ? regA[k] : 0.0; }
                 lds_barrier();   // (LDS only: the low halves in global memory are published by the barrier behind phase 3a)
 #pragma unroll
                 for (int j = 0; j < kSplitPer; ++j) {
