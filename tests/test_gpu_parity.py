@@ -25,7 +25,8 @@ def assert_parity(got, want, n_points, tight=RTOL_TIGHT, allow_tie=False):
     numpy.testing.assert_allclose(chi2[finite], ochi2[finite], rtol=RTOL_CONTRACT, atol=0)
     numpy.testing.assert_allclose(chi2[finite], ochi2[finite], rtol=tight, atol=0)
     numpy.testing.assert_array_equal(row, orow)
-    numpy.testing.assert_allclose(depth, odepth, rtol=0, atol=1e-12)
+    # (fast prefix-sum mode moves a window's mean depth by up to 2^-53 (N + W) max|flux|: DESIGN.md section 3)
+    numpy.testing.assert_allclose(depth, odepth, rtol=0, atol=max(1e-12, 3e-16 * n_points))
     if finite.any():
         # the argmin period index is exact (north_star).  Only the randomised sweep (allow_tie) accepts
         # the one case its 160-seed run met: two near-identical trial periods at the end of a very

@@ -699,9 +699,12 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     {
         // the sequential cumsum C of the reference (helpers.py:72) rounds by at most half an ulp of its running value
         // per step, and C <= (n + W) * max|flux|: the two constants below follow from that (tls_kernels.hip.h,
-        // depth_pass and window_bound); both carry a factor 2 of margin
+        // depth_pass and window_bound)
         const double c_max = (double)ctx->M * ctx->y_abs_max;
-        a.eps_fast = 2.0 * (1.1102230246251565e-16 * c_max) + 1e-15;
+        // (band half-width: 1.25 x the bound 2^-53 c_max on |dX/d - mean_reference|, plus 1e-14 for what the bound leaves out --
+        // the plain scan's own rounding, <= ~20 * 2^-53 * max|X| / d, and the reference's division; rounds 3 and early 4
+        // shipped 2 x: twice the second attempts for no additional safety)
+        a.eps_fast = 1.25 * (1.1102230246251565e-16 * c_max) + 1e-14;
         a.slack_unit = 2.5e-16 * c_max;
         const char* env = std::getenv("TLS_EXACT_PREFIX");
         a.exact_prefix = (env && std::atoi(env) != 0) ? 1 : 0;
