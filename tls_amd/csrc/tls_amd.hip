@@ -170,6 +170,9 @@ struct tls_ctx {
     double e_abs_max = INFINITY;   // largest |1 - flux| of the same (inf: a sample outside [0.5, 2]): admits the fp32 screen
     DevBuf<float> d_split;    // fp32 screen: low halves of the folded samples, one region per workgroup
     DevBuf<double> d_park;    // fp32 screen: parked cells, kParkCap per workgroup
+    DevBuf<double> d_band;    // slab variant, fast mode: band_prefix of the next launch
+    double flux_sigma = 0.0;  // scatter of the flux of the next launch (mean over the curves of a batch)
+    double band_sigma = -1.0, band_eps = -1.0;   // what d_band was computed for
     long long q_count = 0;    // elements of the padded template rows (the fp32 screen's second copy starts there)
     tls_counters plan_counters = {0, 0, 0, 0, 0};
     bool counted = false;
@@ -714,8 +717,30 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         // (the folded flux is kept).  Round 4, same box: Kepler full grid 275.8 -> 254.8 ms, TESS 2.97 -> 2.90 ms.
         // The two-role kernel always runs exact mode (its fold role cannot know what its search role will find).
         a.fast_slab = 1;
+        // (a launch of up to four rounds of periods stays exact: a second attempt in its last round would end it a whole
+        // period late -- the 512- and 411-period blocks of an 8-GPU TESS job ran 0.61 / 0.73 instead of 0.57 ms)
+        if ((long long)ctx->n_periods <= 4LL * ctx->blocks) a.fast_slab = 0;
         if (const char* fs = std::getenv("TLS_FAST_SLAB")) a.fast_slab = std::atoi(fs) != 0 ? 1 : 0;
     }
+    a.band_prefix = nullptr; a.band_max = 0.1;   // (Kepler full grid, same box: 0.35 -> 244 ms, 0.1 -> 241, 0.01 -> 240, never -> 249)
+    if (const char* env = std::getenv("TLS_BAND_MAX")) a.band_max = std::atof(env);   // developer switch (PERF_LOG round 4)
+    if (!ctx->resident && a.fast_slab && ctx->flux_sigma > 0 &&
+        !(ctx->band_sigma == ctx->flux_sigma && ctx->band_eps == a.eps_fast && ctx->d_band.ptr)) {
+        // expected number of windows of row k inside the band: n_pos * 2 eps * density of the window mean at depth_min
+        // (a flat, white light curve: mean of 1 - flux ~ N(0, sigma^2 / d)); its prefix over the width table lets the kernel
+        // form a period's expectation from its duration window [k_lo, k_hi)
+        std::vector<double> pre(ctx->host_widths.size() + 1, 0.0);
+        for (size_t k = 0; k < ctx->host_widths.size(); ++k) {
+            const auto& we = ctx->host_widths[k];
+            const double sd = ctx->flux_sigma / std::sqrt((double)we.width), z = ctx->depth_min / sd;
+            pre[k + 1] = pre[k] + (double)we.n_pos * 2.0 * a.eps_fast * std::exp(-0.5 * z * z) / (sd * 2.5066282746310002);
+        }
+        TLS_HIP(ctx, ctx->d_band.reserve(pre.size()));
+        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_band.ptr, pre.data(), pre.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (pageable source; once per prepared flux)
+        ctx->band_sigma = ctx->flux_sigma; ctx->band_eps = a.eps_fast;
+    }
+    if (!ctx->resident && a.fast_slab && ctx->flux_sigma > 0) a.band_prefix = ctx->d_band.ptr;
     a.sort2 = ctx->sort2 ? 1 : 0;
     a.sort3 = ctx->sort3 ? 1 : 0; a.sort3_scratch = ctx->d_sort3.ptr;
     a.n_curves = ctx->batch_curves;
@@ -901,7 +926,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release();
     ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_pqueues.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
-    ctx->d_split.release(); ctx->d_park.release();
+    ctx->d_split.release(); ctx->d_park.release(); ctx->d_band.release();
     for (auto& sl : ctx->slot) {
         sl.d_y.release(); sl.d_w.release(); sl.d_S0.release(); sl.d_w0.release(); sl.d_chi2.release(); sl.d_depth.release(); sl.d_row.release();
         if (sl.h_in) (void)hipHostFree(sl.h_in);
@@ -1202,8 +1227,10 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->n_widths = (int)widths.size();
     ctx->uniform_w = uniform; ctx->w0 = w0; ctx->S0 = S0; ctx->depth_min = params->transit_depth_min;
     ctx->host_widths = widths;
+    ctx->band_sigma = -1.0;   // (d_band belongs to the previous width table)
     {
         const double sigma = flux_scatter(y, n);
+        ctx->flux_sigma = sigma;
         const bool scr_ok = screen_admissible(ctx->resident, uniform, ctx->e_abs_max);
         ctx->prune_kernel = uniform && pruning_pays(widths, sigma, params->transit_depth_min, ctx->resident, scr_ok);
         ctx->screen_kernel = screen_pays(widths, sigma, params->transit_depth_min, scr_ok);
@@ -1288,6 +1315,7 @@ int update_flux_impl(tls_ctx* ctx, const double* y, const double* dy) {
     ctx->w0 = w0; ctx->S0 = S0; ctx->y_abs_max = y_abs_max; ctx->e_abs_max = e_abs_max;
     {
         const double sigma = flux_scatter(y, ctx->n);
+        ctx->flux_sigma = sigma;
         const bool scr_ok = screen_admissible(ctx->resident, uniform, ctx->e_abs_max);
         ctx->prune_kernel = uniform && pruning_pays(ctx->host_widths, sigma, ctx->depth_min, ctx->resident, scr_ok);
         ctx->screen_kernel = screen_pays(ctx->host_widths, sigma, ctx->depth_min, scr_ok);
@@ -1710,6 +1738,7 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         TLS_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ev_in, 0));
         ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = group_y_max; ctx->e_abs_max = group_e_max;
         {
+            ctx->flux_sigma = sigma_sum / (double)gc;
             const bool scr_ok = screen_admissible(ctx->resident, uni, ctx->e_abs_max);
             ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
             ctx->screen_kernel = screen_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, scr_ok);
@@ -1860,6 +1889,7 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         TLS_HIP(ctx, hipMemcpyAsync(sl.d_w0.ptr, h_w0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->stream));
         ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = group_y_max; ctx->e_abs_max = group_e_max;
         {
+            ctx->flux_sigma = sigma_sum / (double)gc;
             const bool scr_ok = screen_admissible(ctx->resident, uni, ctx->e_abs_max);
             ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
             ctx->screen_kernel = screen_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, scr_ok);

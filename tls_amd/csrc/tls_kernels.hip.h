@@ -521,6 +521,8 @@ struct SearchArgs {
     int exact_prefix;           // != 0: every period in exact mode (developer switch TLS_EXACT_PREFIX=1, debug entries)
     int cumsum_round;           // slab variant: elements the prefix sum takes through LDS per round
     int fast_slab;              // != 0: fast mode also for a series in the HBM slab (the host's choice: few undecided windows)
+    const double* band_prefix;  // [n_widths + 1] expected number of windows inside the undecided band, rows < k (fast_slab)
+    double band_max;            // a period that expects more of them than this starts in exact mode
     const float* q32;           // fp32 screen: the template rows rounded to fp32, same layout as q (uniform weights)
     long long q32_shifted;      // ... and, this many floats further, the same rows stored one element later
     float* split_lo;            // fp32 screen: [blocks][region] low halves of the folded samples (e = hi + lo exactly)

@@ -99,8 +99,17 @@
         // (the mode of a period depends on the series and the period alone, never on its place in the launch: sending the
         // launch's last round straight to exact mode would spare TESS-size grids a late second attempt -- measured 2.90
         // -> 2.81 ms -- but a period's bits would then depend on which other periods the call holds)
-        const bool period_exact = (!RESIDENT && (ROLE != kRoleAll || ap->fast_slab == 0 || ap->sort3 != 0)) || retry_exact ||
-                                  ap->exact_prefix != 0 || ap->debug_prefix != nullptr;
+        bool period_exact = (!RESIDENT && (ROLE != kRoleAll || ap->fast_slab == 0 || ap->sort3 != 0)) || retry_exact ||
+                            ap->exact_prefix != 0 || ap->debug_prefix != nullptr;
+        if constexpr (!RESIDENT && ROLE == kRoleAll) {
+            // a period whose windows are EXPECTED to hit the undecided band (long periods of a long series: many wide
+            // windows, little noise on their means) starts in exact mode: the fast attempt would mostly be wasted.  The
+            // expectation depends on the period's duration window and the light curve alone (host: band_prefix).
+            if (!period_exact && ap->band_prefix != nullptr && work < ap->n_periods) {   // (the queue's end is tested below)
+                const int pp = ap->order[work];
+                period_exact = ap->band_prefix[rows_c[pp].k_hi] - ap->band_prefix[rows_c[pp].k_lo] > ap->band_max;
+            }
+        }
         // (slab variant, one light curve: the folded flux of the fast attempt is still in the slab -- only X was written
         // behind it --, so the second attempt keeps it and starts at the prefix sum)
         [[maybe_unused]] const bool refold = !(retry_exact && !RESIDENT && ROLE == kRoleAll && ap->n_curves == 1 && ap->debug_folded == nullptr);
