@@ -107,13 +107,18 @@ def test_sharded_search_equals_single_process(tmp_path, oracle_lib, world):
     assert sum(int(r["cells"]) for r in ranks) == int(numpy.sum(shard._lib.grid_cells(inp["t"], inp["periods"], inp["table"], inp["params"])))
 
 
-@pytest.mark.parametrize("fixture,limit", [("k2_90d", 1.05), ("tess_27d", 1.06), ("kepler_4yr_8", 1.06), ("k2_90d_500", 1.05)])
-def test_time_model_balances_measured_period_cycles(fixture, limit):
+@pytest.mark.parametrize("fixture,limit", [("k2_90d", 1.05), ("tess_27d", 1.06), ("kepler_4yr_8", 1.06), ("k2_90d_500", 1.05),
+                                           ("kepler_4yr_8_fast", 1.07)])
+def test_time_model_balances_measured_period_cycles(fixture, limit, monkeypatch):
     """The shard boundaries against MEASURED per-period shader cycles (tls_debug_period_cycles on an MI355X,
     tools/gpu_cost_model.py; committed as tests/golden/period_cycles_*.npz): blocks placed by the time model of
     tls_period_costs are balanced in measured time at 2, 4 and 8 ranks; blocks placed by trial cells alone (round 2)
-    are not."""
+    are not.  The round-3 fixtures of the long series were measured in exact prefix-sum mode (TLS_FAST_SLAB=0, which
+    the model honours like the search); `kepler_4yr_8_fast` is the same grid in round 4's default: fast mode, second
+    attempts of the periods that hit the undecided band included, the expected hitters in exact mode from the start."""
     from tls_amd import synthetic
+    if fixture in ("tess_27d", "kepler_4yr_8"):
+        monkeypatch.setenv("TLS_FAST_SLAB", "0")
     g = numpy.load(os.path.join(os.path.dirname(__file__), "golden", "period_cycles_%s.npz" % fixture))
     sigma = float(g["sigma_ppm"]) * 1e-6 or None
     t, f, kw = synthetic.config(str(g["config"]), sigma=sigma)
