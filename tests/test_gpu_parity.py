@@ -904,6 +904,24 @@ def test_fp32_screen_kernel_is_exact(gpu, name, sigma, stride, monkeypatch):
         numpy.testing.assert_array_equal(x, y)
 
 
+def test_host_picks_the_kernel_variant_by_noise_level(gpu, monkeypatch):
+    """Which of the three bit-identical variants of the LDS-resident kernel a launch takes is the host's choice from the
+    expected passing fraction of the depth predicate (screen_pays / pruning_pays in tls_amd.hip; round-4 measurements in
+    PERF_LOG.md): plain at 50 ppm, the fp32 screen at 100 ppm, pruning at 500 ppm.  The statistics slots of the phase-clock
+    buffer tell which one ran."""
+    monkeypatch.delenv("TLS_PRUNE", raising=False)
+    monkeypatch.delenv("TLS_SCREEN32", raising=False)
+    seen = {}
+    for ppm in (50, 100, 500):
+        inp = _inputs("k2_90d", sigma=ppm * 1e-6)
+        sel = inp["periods"][::9]
+        gpu.prepare(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+        gpu.execute(phase_clock=True)
+        stats = gpu.phase_cycles()
+        seen[ppm] = ("screen" if stats["stat_screen_valued"] > 0 else "pruning" if stats["stat_pruned_periods"] > 0 else "plain")
+    assert seen == {50: "plain", 100: "screen", 500: "pruning"}, seen
+
+
 def test_fp32_screen_on_ties_deep_transits_and_inadmissible_flux(gpu, monkeypatch):
     """Edge cases of the fp32 screen against the plain kernel, bit for bit: (i) a light curve built from a few repeated
     values -- thousands of trial cells with EQUAL statistics, so the workgroup's list of parked cells overflows and the
