@@ -1853,29 +1853,43 @@ __device__ __forceinline__ float dot_window32(unsigned addr, const_f32_ptr q, in
 
 // The dot product of ONE cell as the plain kernel forms it: one fp64 accumulator, taps in order (the zero taps of the
 // padded rows add nothing), samples rebuilt from their halves.  One wavefront works on the one cell (wave-uniform
-// arguments): lane j rebuilds sample j of a 64-sample stretch -- one memory round trip per stretch instead of one per
-// tap -- and puts it into the wavefront's staging buffer in LDS; the chain of additions then runs like the plain kernel's
-// one-window loop: taps from scalar loads, samples as broadcast LDS reads, eight at a time.  Every period needs this
-// once (its winner) and now and then for a near-tie.
-__device__ __forceinline__ double exact_window_dot(unsigned hi_addr, glob_f32_ptr lo, const_f64_ptr q_row, int L, int i, double* stage) {
+// arguments): lane j rebuilds sample j and fetches tap j of a 64-sample stretch -- one memory round trip per stretch instead
+// of one per tap -- into the wavefront's staging buffers in LDS; the chain of additions then runs like the plain kernel's
+// one-window loop on broadcast LDS reads, eight taps at a time.  Every period needs this once (its winner) and now and
+// then for a near-tie.
+__device__ __forceinline__ double exact_window_dot(unsigned hi_addr, glob_f32_ptr lo, glob_f64_ptr q_row, int L, int i, double* stage) {
+    // (stage: 2 * kWave doubles -- samples, then taps.  Both are read back as broadcast LDS loads, so the only wait inside
+    // the chain is for LDS data requested one step earlier: the next eight taps and samples travel while these eight are added)
     const lds_f32_ptr hi = (lds_f32_ptr)(uintptr_t)hi_addr;
     const int lane = (int)(threadIdx.x & (kWave - 1));
+    double* const st_e = stage;
+    double* const st_q = stage + kWave;
     double B = 0.0;
 #pragma unroll 1
     for (int base = 0; base < L; base += kWave) {
         const int idx = base + lane;
-        stage[lane] = idx < L ? (double)hi[i + idx] + (double)lo[i + idx] : 0.0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wavefront's own buffer: no barrier)
+        double ev = 0.0, qv = 0.0;
+        if (idx < L) {
+            ev = (double)hi[i + idx] + (double)lo[i + idx];
+            qv = q_row[idx];
+        }
+        st_e[lane] = ev;
+        st_q[lane] = qv;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wavefront's own buffers: no barrier)
         const int n = L - base < kWave ? L - base : kWave;
+        double x[kU], tq[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { x[u] = st_e[u]; tq[u] = st_q[u]; }
 #pragma unroll 1
         for (int t0 = 0; t0 < n; t0 += kU) {
-            const const_f64_ptr qs = q_row + (base + t0);   // (rows are zero padded to a multiple of kU and beyond)
-            double taps[kU], x[kU];
+            double xn[kU], tn[kU];
+            const int t1 = t0 + kU < kWave ? t0 + kU : 0;   // (the last step's prefetch is not used)
 #pragma unroll
-            for (int u = 0; u < kU; ++u) taps[u] = qs[u];
-            load_taps<true>(stage + t0, x);
+            for (int u = 0; u < kU; ++u) { xn[u] = st_e[t1 + u]; tn[u] = st_q[t1 + u]; }
 #pragma unroll
-            for (int u = 0; u < kU; ++u) B = fma(taps[u], x[u], B);
+            for (int u = 0; u < kU; ++u) B = fma(tq[u], x[u], B);   // (entries past L are zero taps on zero samples)
+#pragma unroll
+            for (int u = 0; u < kU; ++u) { x[u] = xn[u]; tq[u] = tn[u]; }
         }
     }
     return B;
@@ -1899,7 +1913,7 @@ struct ParkedCell { double lo; int k, i; };
 constexpr int kParkCap = 1024;    // cells per workgroup and period; beyond that a lane values its cell on the spot
 struct ParkList {                 // lives in the idle prefix-sum scratch (LDS)
     unsigned int n; unsigned int pad_[3];
-    double stage[kWave];          // staging buffer of the wavefront that values the parked cells (exact_window_dot)
+    double stage[2 * kWave];      // staging buffers of the wavefront that values the parked cells (exact_window_dot)
 };
 static_assert(sizeof(ParkList) <= kCumsumScratchBytes, "the list head of the parked cells does not fit the prefix-sum scratch");
 struct ScreenEnv {          // what the screen needs besides the cells
@@ -1925,8 +1939,8 @@ __device__ __forceinline__ void screen_value_cell_lane(Lead& lead, int k_c, int 
 __device__ __forceinline__ void screen_value_cell(Lead& lead, int owner, int k_c, int i_c, const DepthRule& rule,
                                                   const_width_ptr widths_c, const double* x_all, const ScreenEnv& env) {
     const int d_c = widths_c[k_c].width;
-    const double B = exact_window_dot(env.eh_addr, env.lo_g, (const_f64_ptr)(const double*)env.q_g + widths_c[k_c].q_offset,
-                                      widths_c[k_c].q_len, i_c, env.park->stage);
+    const double B = exact_window_dot(env.eh_addr, env.lo_g, env.q_g + widths_c[k_c].q_offset, widths_c[k_c].q_len, i_c,
+                                      env.park->stage);
     if ((int)(threadIdx.x & (kWave - 1)) == owner) {
         unsigned int n_dummy = 0;
         bool und_dummy = false;
