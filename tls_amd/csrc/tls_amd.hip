@@ -722,6 +722,13 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         if ((long long)ctx->n_periods <= 4LL * ctx->blocks) a.fast_slab = 0;
         if (const char* fs = std::getenv("TLS_FAST_SLAB")) a.fast_slab = std::atoi(fs) != 0 ? 1 : 0;
     }
+    a.x_at_staging = 0;
+    if (!ctx->resident && a.fast_slab && !ctx->stage_c) {
+        bool any_oversize = false;   // (rows evaluated straight from the slab list their cells with the first tile: they need all of X)
+        for (const auto& we : ctx->host_widths) any_oversize = any_oversize || we.oversize != 0;
+        a.x_at_staging = any_oversize ? 0 : 1;
+        if (const char* env = std::getenv("TLS_X_STAGED")) a.x_at_staging = a.x_at_staging && std::atoi(env) != 0;
+    }
     a.band_prefix = nullptr; a.band_max = 0.1;   // (Kepler full grid, same box: 0.35 -> 244 ms, 0.1 -> 241, 0.01 -> 240, never -> 249)
     if (const char* env = std::getenv("TLS_BAND_MAX")) a.band_max = std::atof(env);   // developer switch (PERF_LOG round 4)
     if (!ctx->resident && a.fast_slab && ctx->flux_sigma > 0 &&

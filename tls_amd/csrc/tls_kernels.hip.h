@@ -521,6 +521,7 @@ struct SearchArgs {
     int exact_prefix;           // != 0: every period in exact mode (developer switch TLS_EXACT_PREFIX=1, debug entries)
     int cumsum_round;           // slab variant: elements the prefix sum takes through LDS per round
     int fast_slab;              // != 0: fast mode also for a series in the HBM slab (the host's choice: few undecided windows)
+    int x_at_staging;           // != 0 (fast_slab): no prefix-sum pass -- X of a tile is formed when the tile is staged (scan_tile_x)
     const double* band_prefix;  // [n_widths + 1] expected number of windows inside the undecided band, rows < k (fast_slab)
     double band_max;            // a period that expects more of them than this starts in exact mode
     const float* q32;           // fp32 screen: the template rows rounded to fp32, same layout as q (uniform weights)
@@ -1456,6 +1457,33 @@ __device__ __forceinline__ double exact_cumsum(const double* f, double* C, int c
         if (k0 < count) lds_barrier();               // the scratch is rewritten by the next block
     }
     return s0;
+}
+
+// Fast mode, series in the HBM slab: X of one tile formed in place from the tile's staged flux.  buf[k] holds the folded flux
+// of position p_lo + k for k < have; afterwards buf[k] = X[p_lo + k] = carry + sum_{j<k} (1 - f_j) for k <= min(have, cap - 1)
+// (a plain parallel scan, any association: depth_pass).  Two LDS-only barriers; wtot: kMaxWaves doubles of scratch.
+__device__ __forceinline__ void scan_tile_x(double* buf, int have, int cap, double carry, double* wtot, int tid) {
+    const int nt = blockDim.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    int per = (have + nt - 1) / nt;
+    if ((per & 1) == 0) per += 1;    // odd stride: the 8-byte LDS accesses of a wave hit 32 bank pairs
+    const int lo = tid * per < have ? tid * per : have;
+    const int hi = lo + per < have ? lo + per : have;
+    double local = 0.0;
+    for (int k = lo; k < hi; ++k) local += 1.0 - buf[k];
+    const double incl = wave_inclusive_sum(local);
+    if (lane == kWave - 1) wtot[wave] = incl;
+    lds_barrier();
+    double run = carry;
+    for (int v = 0; v < wave; ++v) run += wtot[v];   // the same additions in every thread of the wave
+    run += incl - local;
+    for (int k = lo; k < hi; ++k) { const double e1 = 1.0 - buf[k]; buf[k] = run; run += e1; }
+    if (have < cap) {   // X behind the last staged sample
+        if (have == 0) { if (tid == 0) buf[0] = carry; }
+        else if (hi == have && lo < hi) buf[have] = run;
+    }
+    lds_barrier();
 }
 
 // Fast mode of the LDS-resident kernel: fe[k] = e_k = 1 - f[k] in place and X[0] = 0, X[k+1] = X[k] + e_k as a plain

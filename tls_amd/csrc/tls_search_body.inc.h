@@ -232,6 +232,11 @@
         // story for a transit_depth_min near zero -- then every cell takes the exact comparison)
         rule.reach = (rule.dmin - rule.eps > 4e-15) ? fmin(fmax(1e-9, 4e-15 / (rule.dmin - rule.eps)), 1.0) : 1.0;
         bool undecided = false;
+        // series in the HBM slab, fast mode: X of a tile is formed from the tile's staged flux (scan_tile_x) instead of by a
+        // prefix-sum pass over the whole series -- one pass of slab reads and the pass's barriers less per period
+        [[maybe_unused]] const bool x_staging = !RESIDENT && !STAGE_C && ROLE == kRoleAll && TLS_SLAB_DMA && !exact_mode &&
+                                                ap->x_at_staging != 0 && (n & 1) == 0;
+        [[maybe_unused]] double x_carry = 0.0;   // X at the first position of the next tile
         const double* y_c = ap->y + (long long)curve * n;
         if constexpr (ROLE != kRoleSearch) {
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  kG
@@ -297,6 +302,8 @@
             exact_sequential_cumsum(regA, regB, M, cumsum_scratch, ap->phase_cycles);
 #endif
             }
+        } else if (!fused && x_staging) {
+            // (fast mode with X formed at tile-staging time: no prefix-sum pass, the slab's X region is written tile by tile)
         } else if (!fused) {
             // the series is in the HBM slab: the scan runs through LDS, 16 K elements a round, in place
             // (C[k+1] over f[k]); the patch (core.py:126: the first W samples again) is an index mapping
@@ -503,7 +510,18 @@
                 // no room for C beside the samples: the predicate pass gets C in the samples' place
                 // (sequential HBM reads instead of the predicate's scattered ones), the samples follow
                 // once the live units are listed
-                {
+                if (x_staging) {
+                    // the flux of positions p_lo .. (patch: an index mapping), X in place, X of the tile and its halo to the slab
+                    const int have = M - p_lo < staged ? (M - p_lo > 0 ? M - p_lo : 0) : staged;
+                    slab_to_lds_async(tile_e, regA, p_lo, have, n, tid);
+                    vmem_wait_all();
+                    lds_barrier();
+                    scan_tile_x(tile_e, have, staged, x_carry, reinterpret_cast<double*>(cumsum_scratch), tid);
+                    const int got = have < staged ? have + 1 : staged;          // X entries formed
+                    if (tile_len < got) x_carry = tile_e[tile_len];
+                    copy_out_stream(regB + p_lo, tile_e, got, tid);
+                    for (int k = got + tid; k < staged; k += nt) tile_e[k] = -(double)(p_lo + k - M) * 1.0e300;
+                } else {
                     const int avail = M + 1 + region_pad - p_lo;            // entries the slab still holds
                     const int valid = avail < staged ? (avail > 0 ? avail : 0) : staged;
                     if (TLS_SLAB_DMA) {
