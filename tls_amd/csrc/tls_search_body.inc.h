@@ -237,6 +237,7 @@
         [[maybe_unused]] const bool x_staging = !RESIDENT && !STAGE_C && ROLE == kRoleAll && TLS_SLAB_DMA && !exact_mode &&
                                                 ap->x_at_staging != 0 && (n & 1) == 0;
         [[maybe_unused]] double x_carry = 0.0;   // X at the first position of the next tile
+        [[maybe_unused]] int x_got = 0;          // X entries of the tile in flight (scan_tile_x)
         const double* y_c = ap->y + (long long)curve * n;
         if constexpr (ROLE != kRoleSearch) {
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  kG
@@ -519,7 +520,7 @@
                     scan_tile_x(tile_e, have, staged, x_carry, reinterpret_cast<double*>(cumsum_scratch), tid);
                     const int got = have < staged ? have + 1 : staged;          // X entries formed
                     if (tile_len < got) x_carry = tile_e[tile_len];
-                    copy_out_stream(regB + p_lo, tile_e, got, tid);
+                    x_got = got;   // (X goes to the slab only if the tile turns out to have live cells: below)
                     for (int k = got + tid; k < staged; k += nt) tile_e[k] = -(double)(p_lo + k - M) * 1.0e300;
                 } else {
                     const int avail = M + 1 + region_pad - p_lo;            // entries the slab still holds
@@ -736,6 +737,10 @@
             double* tile_e = reinterpret_cast<double*>(smem + ap->hdr_bytes);
             const int staged = ap->tile_len + ap->tile_halo;
             double* tile_w = tile_e + staged;
+            if (x_staging) {   // ... to which a tile with live cells now sends its X (tile + halo); the LDS copy is then free
+                copy_out_stream(regB + p_lo, tile_e, x_got, tid);
+                lds_barrier();
+            }
             {
                 if (TLS_SLAB_DMA && (n & 1) == 0) {
                     stage_samples_async<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M, tid);
