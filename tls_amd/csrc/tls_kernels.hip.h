@@ -2462,7 +2462,10 @@ constexpr int kSort2BinCap = 384;     // points one wavefront can sort in its LD
 #define TLS_SORT2_FINE 384
 #endif
 constexpr int kSort2Fine = TLS_SORT2_FINE;   // fine buckets of a bin (<= kSort2BinCap: the counters share its window slot)
-constexpr int kSort2BinMean = 160;    // target points per coarse bin
+#ifndef TLS_SORT2_BIN_MEAN
+#define TLS_SORT2_BIN_MEAN 280   // (round 4, Kepler full grid: 128 233.8 ms, 160 226.4, 200 227.4, 240 221.6, 280 219.3, 320 218.5; the cap is 384)
+#endif
+constexpr int kSort2BinMean = TLS_SORT2_BIN_MEAN;    // target points per coarse bin
 constexpr int kSort2MaxBins = 1024;
 __host__ __device__ constexpr int sort2_bins(int n) {
     return (n + kSort2BinMean - 1) / kSort2BinMean < kSort2MaxBins ? (n + kSort2BinMean - 1) / kSort2BinMean : kSort2MaxBins;
