@@ -2462,13 +2462,17 @@ constexpr int kSort2BinCap = 384;     // points one wavefront can sort in its LD
 #define TLS_SORT2_FINE 384
 #endif
 constexpr int kSort2Fine = TLS_SORT2_FINE;   // fine buckets of a bin (<= kSort2BinCap: the counters share its window slot)
+// target points per coarse bin: 280 for long series (round 4, Kepler full grid: 128 233.8 ms, 160 226.4, 200 227.4, 240 221.6,
+// 280 219.3, 320 218.5; the cap is 384), 160 below 50 000 points (TESS size: 70 bins for 16 wavefronts fill the last round of
+// pass 2 badly -- 2.83 against 2.81 ms, a 307-period block 5 % slower)
 #ifndef TLS_SORT2_BIN_MEAN
-#define TLS_SORT2_BIN_MEAN 280   // (round 4, Kepler full grid: 128 233.8 ms, 160 226.4, 200 227.4, 240 221.6, 280 219.3, 320 218.5; the cap is 384)
+#define TLS_SORT2_BIN_MEAN 280
 #endif
-constexpr int kSort2BinMean = TLS_SORT2_BIN_MEAN;    // target points per coarse bin
+constexpr int kSort2BinMeanLong = TLS_SORT2_BIN_MEAN, kSort2BinMeanShort = 160, kSort2LongFrom = 50000;
 constexpr int kSort2MaxBins = 1024;
 __host__ __device__ constexpr int sort2_bins(int n) {
-    return (n + kSort2BinMean - 1) / kSort2BinMean < kSort2MaxBins ? (n + kSort2BinMean - 1) / kSort2BinMean : kSort2MaxBins;
+    const int mean = n >= kSort2LongFrom ? kSort2BinMeanLong : kSort2BinMeanShort;
+    return (n + mean - 1) / mean < kSort2MaxBins ? (n + mean - 1) / mean : kSort2MaxBins;
 }
 __host__ __device__ constexpr long long sort2_lds_bytes(int n, int threads = 1024) {
     // counters (4 arrays of bins+1 words) + the larger of the pass-1 staging and the pass-2 windows
