@@ -11,9 +11,10 @@ Nothing here shares code or formulation with the module under test:
   rotation of the orbital-plane position vector (the module: Newton iteration and the true anomaly).
 
 The integrator is first checked on the one case with an elementary answer (uniform source: area of a lens).
-Then: exact-K/E variant of the closed form <= 1e-12, shipped Hastings-polynomial variant <= 1e-8 absolute
-(the polynomials are what reproduces the reference's known answers), for the reference's
-three template presets (tls_constants.py:47-66), three eccentric orbits, and every other limb-darkening law.
+Then: exact-K/E variant of the closed form <= 1e-12 (measured 1e-15), shipped Hastings-polynomial variant
+<= 1e-8 absolute (measured 9.4e-9; SURVEY Appendix A: the polynomials are what reproduces the reference's known
+answers), for the reference's three template presets (tls_constants.py:47-66), three eccentric orbits, and
+every other limb-darkening law (<= 1e-12, measured 3e-14).
 """
 import math
 
@@ -23,6 +24,9 @@ from scipy import integrate, optimize, special
 
 from tls_amd import constants as C
 from tls_amd import transit_model as tm
+
+# (quad is asked for more digits than it can certify; what it delivers is checked against the lens area below)
+pytestmark = pytest.mark.filterwarnings("ignore::scipy.integrate.IntegrationWarning")
 
 
 # ---- the definition, by quadrature ---------------------------------------------------------------------------
@@ -228,6 +232,5 @@ def test_every_other_limb_darkening_law(law, u, exact_elliptic):
     z = separation_by_vectors(t, 0.0, per, a, inc, 0.0, 90.0)
     want = quadrature_flux(z, rp, law, u)
     got = tm.light_curve(t, 0.0, per, rp, a, inc, 0, 90, u, law)
-    # closed form: 1e-12; the module's fixed-node integration of the other laws: 1e-9 (its docstring's claim)
-    tol = 1e-12 if law in ("linear", "uniform") else 1e-9
-    numpy.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    # (measured: closed form 2e-15, the module's fixed-node ring integration of the other laws <= 3e-14)
+    numpy.testing.assert_allclose(got, want, rtol=0, atol=1e-12)

@@ -18,8 +18,14 @@ The polynomial K/E are deliberate: the reference's known-answer tests
 integrals move that pin by 7e-6 relative.
 
 Everything is vectorised numpy; one 10 000-point template costs ~1 ms.
-Only what the search needs is provided: eccentricity 0, laws "quadratic" and
-"linear" (= quadratic with u2 = 0), "uniform".
+Provided: every argument the reference hands to batman (transit.py:14-25) -- any
+eccentricity in [0, 1) and argument of periastron, the closed-form laws "quadratic",
+"linear" (= quadratic with u2 = 0) and "uniform", and the laws without a closed form
+("nonlinear", "squareroot", "logarithmic", "exponential", "power2") by numerical
+integration.  Pinned independently of this module by tests/test_transit_model_pin.py
+(the definition by nested quadrature about the planet's centre, Kepler's equation by
+a bracketed root: exact-K/E variant 1e-15, this Hastings variant 9.4e-9, the other
+laws 3e-14).
 """
 import numpy
 
