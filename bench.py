@@ -543,24 +543,17 @@ def main():
                      "evaluated_fraction": c5["evaluated_cells"] / c5["grid_cells"],
                      "inner_steps": c5["inner_steps"]}
             # ... and at 100 ppm, where the host takes the fp32-screen variant of the kernel (tls_amd.hip, screen_pays):
-            # the three variants side by side (TLS_PRUNE / TLS_SCREEN32 are read when the flux is prepared)
+            # the three variants side by side (the context's switches, tls_options: prune / screen32)
             t1_, f1_, kw1_ = synthetic.config(args.config, seed=0, sigma=100e-6)
             i1_ = synthetic.search_inputs(t1_, f1_, **kw1_)
             variants = {}
-            saved = {k: os.environ.get(k) for k in ("TLS_PRUNE", "TLS_SCREEN32")}
-            for label, env in (("chosen_by_host", {}), ("plain", {"TLS_PRUNE": "0", "TLS_SCREEN32": "0"}),
-                               ("fp32_screen", {"TLS_PRUNE": "0", "TLS_SCREEN32": "1"}),
-                               ("pruning", {"TLS_PRUNE": "1", "TLS_SCREEN32": "0"})):
-                for k in saved:
-                    os.environ.pop(k, None)
-                os.environ.update(env)
+            for label, sw in (("chosen_by_host", {"prune": None, "screen32": None}), ("plain", {"prune": 0, "screen32": 0}),
+                              ("fp32_screen", {"prune": 0, "screen32": 1}), ("pruning", {"prune": 1, "screen32": 0})):
+                ctx.set_options(**sw)
                 ctx.prepare(i1_["t"], i1_["y"], i1_["dy"], i1_["periods"], i1_["table"], i1_["params"])
                 ctx.execute(); ctx.synchronize()
                 variants[label] = ctx.execute_timed(10)
-            for k, v in saved.items():
-                os.environ.pop(k, None)
-                if v is not None:
-                    os.environ[k] = v
+            ctx.set_options(prune=None, screen32=None)
             noisy["at_100_ppm_kernel_ms"] = variants
 
         # wall clock of the whole drop-in call for one light curve (host buffers in, results object

@@ -56,6 +56,7 @@ def gpu():
     """A GPU context; fails (does not skip) when the HIP library or the GPU is missing."""
     from tls_amd import _lib
     ctx = _lib.Context(0)
+    ctx.initial_options = ctx.get_options()   # (the process's TLS_* environment, read once: an A/B run of the suite keeps it)
     yield ctx
     # a checked build (make -C tls_amd/csrc debug, TLS_AMD_DEBUG=1 TLS_AMD_LIB=.../libtls_amd_debug.so) counts every violated
     # device-side bound: after the whole session none may have fired
@@ -64,6 +65,15 @@ def gpu():
     if checked:
         print("\ndevice-side bound checks of the debug build:", counts)
         assert not any(counts.values()), counts
+
+
+@pytest.fixture(autouse=True)
+def _gpu_switches_back(request):
+    """A test that changes the context's switches (gpu.set_options) leaves them as the session started with them."""
+    yield
+    if "gpu" in request.fixturenames:
+        ctx = request.getfixturevalue("gpu")
+        ctx.set_options(**ctx.initial_options)
 
 
 def oracle_search(oracle_lib, inp, periods=None, n_threads=0):

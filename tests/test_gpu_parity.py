@@ -386,7 +386,7 @@ def test_sort_order_is_the_stable_argsort_bit_for_bit(gpu, path, monkeypatch):
     t[n // 3] = t[42]
     dy = rng.uniform(1e-4, 3e-4, n) if path == "slab_weighted" else None
     if path == "slab_fused":
-        monkeypatch.setenv("TLS_SORT3", "1")
+        gpu.set_options(sort3="1")
     inp = synthetic.search_inputs(t, y, dy=dy, period_max=9.0)
     periods = numpy.sort(numpy.concatenate([inp["periods"][::300], [0.025, 0.05, 0.75, 1.0, 2.5, 3.7, 8.0]]))
     gpu.prepare(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
@@ -626,7 +626,7 @@ def test_search_batch_groups_weights_and_tiled_layout(gpu, name, n_curves, strid
     search per light curve returns, bit for bit.  (Same kernel shape on both sides: a batch runs the
     one-workgroup-per-period kernel, so the single searches are kept from the two-role kernel, which a few dozen
     periods of a long series would otherwise take and which runs exact prefix-sum mode only -- 1e-10 apart.)"""
-    monkeypatch.setenv("TLS_SPLIT", "0")
+    gpu.set_options(split="0")
     t, f0, kw = synthetic.config(name, seed=0)
     rng = numpy.random.RandomState(5)
     inputs = []
@@ -717,7 +717,7 @@ def test_both_slab_sort_paths_vs_oracle(gpu, oracle_lib, monkeypatch, name, stri
     """The HBM-slab variant has two sort paths (two-level per-wave bins; partition + per-bin workgroup
     sort fused with the prefix sum); the size picks the default, TLS_SORT3 forces either: both against
     the oracle on both sizes, evaluated-cell counts included."""
-    monkeypatch.setenv("TLS_SORT3", sort3)
+    gpu.set_options(sort3=sort3)
     inp = _inputs(name)
     sel = inp["periods"][::stride]
     got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
@@ -739,7 +739,7 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
     TLS_SPLIT forces either.)  The two-role kernel runs exact mode only, so the bit-for-bit comparison pins the one-kernel
     path to exact mode (TLS_FAST_SLAB=0); its default -- fast mode -- must give the same rows and counts and the same
     chi^2 to 1e-10."""
-    monkeypatch.setenv("TLS_FAST_SLAB", "0")
+    gpu.set_options(fast_slab="0")
     t, f, kw = synthetic.config(name)
     dy = None
     if per_point:
@@ -747,10 +747,10 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
     inp = synthetic.search_inputs(t, f, dy, **kw)
     sel = inp["periods"][::stride]
     if batch:
-        monkeypatch.setenv("TLS_SPLIT_BATCH", batch)
+        gpu.set_options(split_batch=batch)
     results = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("TLS_SPLIT", mode)
+        gpu.set_options(split=mode)
         counted = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
         assert not gpu.plan_info()["resident"]
         plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
@@ -768,8 +768,8 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
     assert_parity(results["1"], want, len(inp["t"]))
     assert results["1"][3]["evaluated_cells"] == int(want[3][1])
     # the one-kernel path as it runs by default (fast prefix-sum mode)
-    monkeypatch.delenv("TLS_FAST_SLAB")
-    monkeypatch.setenv("TLS_SPLIT", "0")
+    gpu.set_options(fast_slab=None)
+    gpu.set_options(split="0")
     fast = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
     numpy.testing.assert_array_equal(fast[1], results["1"][1])
     numpy.testing.assert_allclose(fast[0], results["1"][0], rtol=1e-10, atol=0)
@@ -792,11 +792,11 @@ def test_fast_prefix_mode_in_the_slab_decides_the_reference_cells(gpu, oracle_li
         dy = numpy.random.RandomState(7).uniform(0.7, 1.5, len(f)) * synthetic.CONFIGS[name][2]
     inp = synthetic.search_inputs(t, f, dy, **kw)
     sel = inp["periods"][::stride]
-    monkeypatch.setenv("TLS_PRUNE", "0")
-    monkeypatch.setenv("TLS_SPLIT", "0")
-    monkeypatch.setenv("TLS_FAST_SLAB", "0")
+    gpu.set_options(prune="0")
+    gpu.set_options(split="0")
+    gpu.set_options(fast_slab="0")
     exact = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
-    monkeypatch.delenv("TLS_FAST_SLAB")
+    gpu.set_options(fast_slab=None)
     fast = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
     assert not gpu.plan_info()["resident"]
     plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
@@ -868,11 +868,11 @@ def test_pruning_kernel_is_exact(gpu, name, sigma, stride, monkeypatch):
     however aggressively it is switched on (TLS_PRUNE / TLS_PRUNE_MIN_LIVE are read at prepare time)."""
     inp = _inputs(name, sigma=sigma)
     sel = inp["periods"][::stride]
-    monkeypatch.setenv("TLS_PRUNE", "0")
+    gpu.set_options(prune="0")
     plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
-    monkeypatch.setenv("TLS_PRUNE", "1")
+    gpu.set_options(prune="1")
     for min_live in ("0", "4000"):
-        monkeypatch.setenv("TLS_PRUNE_MIN_LIVE", min_live)
+        gpu.set_options(prune_min_live=min_live)
         pruned = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
         for x, y in zip(plain[:3], pruned[:3]):
             numpy.testing.assert_array_equal(x, y)
@@ -888,10 +888,10 @@ def test_fp32_screen_kernel_is_exact(gpu, name, sigma, stride, monkeypatch):
     buffer say that the variant ran: every period values at least its winner."""
     inp = _inputs(name, sigma=sigma)
     sel = inp["periods"][::stride]
-    monkeypatch.setenv("TLS_PRUNE", "0")
-    monkeypatch.setenv("TLS_SCREEN32", "0")
+    gpu.set_options(prune="0")
+    gpu.set_options(screen32="0")
     plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
-    monkeypatch.setenv("TLS_SCREEN32", "1")
+    gpu.set_options(screen32="1")
     screened = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
     assert gpu.plan_info()["resident"]
     for x, y in zip(plain[:3], screened[:3]):
@@ -909,8 +909,8 @@ def test_host_picks_the_kernel_variant_by_noise_level(gpu, monkeypatch):
     expected passing fraction of the depth predicate (screen_pays / pruning_pays in tls_amd.hip; round-4 measurements in
     PERF_LOG.md): plain at 50 ppm, the fp32 screen at 100 ppm, pruning at 500 ppm.  The statistics slots of the phase-clock
     buffer tell which one ran."""
-    monkeypatch.delenv("TLS_PRUNE", raising=False)
-    monkeypatch.delenv("TLS_SCREEN32", raising=False)
+    gpu.set_options(prune=None)
+    gpu.set_options(screen32=None)
     seen = {}
     for ppm in (50, 100, 500):
         inp = _inputs("k2_90d", sigma=ppm * 1e-6)
@@ -942,12 +942,12 @@ def test_fp32_screen_on_ties_deep_transits_and_inadmissible_flux(gpu, monkeypatc
         cases.append((label, y))
     y = 1.0 + rng.normal(0, 1e-4, n); y[100] = 2.5
     cases.append(("outlier", y))
-    monkeypatch.setenv("TLS_PRUNE", "0")
+    gpu.set_options(prune="0")
     for label, y in cases:
         inp = synthetic.search_inputs(t, y, **kw)
-        monkeypatch.setenv("TLS_SCREEN32", "0")
+        gpu.set_options(screen32="0")
         plain = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
-        monkeypatch.setenv("TLS_SCREEN32", "1")
+        gpu.set_options(screen32="1")
         screened = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
         for x, z in zip(plain[:3], screened[:3]):
             numpy.testing.assert_array_equal(x, z, err_msg=label)
@@ -961,9 +961,9 @@ def test_fp32_screen_on_ties_deep_transits_and_inadmissible_flux(gpu, monkeypatc
     inp = synthetic.search_inputs(t, ys[0], **kw)
     assert len(inp["t"]) == n
     dy = numpy.stack([numpy.full(n, numpy.std(v)) for v in ys])
-    monkeypatch.setenv("TLS_SCREEN32", "0")
+    gpu.set_options(screen32="0")
     plain = gpu.search_batch(inp["t"], ys, dy, inp["periods"], inp["table"], inp["params"])
-    monkeypatch.setenv("TLS_SCREEN32", "1")
+    gpu.set_options(screen32="1")
     screened = gpu.search_batch(inp["t"], ys, dy, inp["periods"], inp["table"], inp["params"])
     for x, z in zip(plain, screened):
         numpy.testing.assert_array_equal(x, z)
@@ -983,10 +983,10 @@ def test_fast_prefix_mode_decides_the_reference_cells(gpu, oracle_lib, monkeypat
         dy = numpy.random.RandomState(5).uniform(0.7, 1.5, len(f)) * synthetic.CONFIGS[name][2]
     inp = synthetic.search_inputs(t, f, dy, **kw)
     sel = inp["periods"] if not weights else inp["periods"][::3]
-    monkeypatch.setenv("TLS_PRUNE", "0")
-    monkeypatch.setenv("TLS_EXACT_PREFIX", "1")
+    gpu.set_options(prune="0")
+    gpu.set_options(exact_prefix="1")
     exact = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
-    monkeypatch.setenv("TLS_EXACT_PREFIX", "0")
+    gpu.set_options(exact_prefix="0")
     fast = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
     assert gpu.plan_info()["resident"]
     assert fast[3]["evaluated_cells"] == exact[3]["evaluated_cells"]

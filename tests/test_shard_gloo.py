@@ -114,11 +114,10 @@ def test_time_model_balances_measured_period_cycles(fixture, limit, monkeypatch)
     tools/gpu_cost_model.py; committed as tests/golden/period_cycles_*.npz): blocks placed by the time model of
     tls_period_costs are balanced in measured time at 2, 4 and 8 ranks; blocks placed by trial cells alone (round 2)
     are not.  The round-3 fixtures of the long series were measured in exact prefix-sum mode (TLS_FAST_SLAB=0, which
-    the model honours like the search); `kepler_4yr_8_fast` is the same grid in round 4's default: fast mode, second
+    the model honours like the search: `options`); `kepler_4yr_8_fast` is the same grid in round 4's default: fast mode, second
     attempts of the periods that hit the undecided band included, the expected hitters in exact mode from the start."""
     from tls_amd import synthetic
-    if fixture in ("tess_27d", "kepler_4yr_8"):
-        monkeypatch.setenv("TLS_FAST_SLAB", "0")
+    options = {"fast_slab": 0} if fixture in ("tess_27d", "kepler_4yr_8") else None
     g = numpy.load(os.path.join(os.path.dirname(__file__), "golden", "period_cycles_%s.npz" % fixture))
     sigma = float(g["sigma_ppm"]) * 1e-6 or None
     t, f, kw = synthetic.config(str(g["config"]), sigma=sigma)
@@ -127,7 +126,7 @@ def test_time_model_balances_measured_period_cycles(fixture, limit, monkeypatch)
     cycles = g["cycles"].astype(float)
     assert len(cycles) == len(periods)
     job = shard.ShardedSearch(0, 1)
-    job.plan(inp["t"], periods, inp["table"], inp["params"], y=inp["y"])
+    job.plan(inp["t"], periods, inp["table"], inp["params"], y=inp["y"], options=options)
     assert job.slots in (256, 512)
     worst_model = worst_cells = 0.0
     for ranks in (2, 4, 8):
@@ -175,7 +174,29 @@ def test_block_makespan_never_shrinks_with_one_more_period_and_every_partition_c
     from tls_amd import shard
     assert shard.block_makespan([10, 1, 1, 1], 4) == 10.0
     assert shard.block_makespan([10, 1, 1, 1, 0.1], 4) >= 10.0
+    # round 4's counter-example: five periods of 10 and any number of free ones on four slots take 20 (the fifth runs behind
+    # one of the first four), at EVERY block length -- the value is the largest over all round boundaries, not the last one's
+    for zeros in range(0, 12):
+        assert shard.block_makespan([10] * 5 + [0] * zeros, 4) == 20.0, zeros
+    # ... and the value stays within a factor two of the longest-first schedule it models (simulated here: the model lets a
+    # round's longest period start at the AVERAGE end of the rounds before it), exact for equal times
+    import heapq
+    def simulate(times, slots):
+        free = [0.0] * slots
+        heapq.heapify(free)
+        end = 0.0
+        for c in sorted(times, reverse=True):
+            s0 = heapq.heappop(free)
+            heapq.heappush(free, s0 + c)
+            end = max(end, s0 + c)
+        return end
     rng = numpy.random.RandomState(5)
+    for trial in range(30):
+        slots = int(rng.choice([2, 4, 16]))
+        times = rng.uniform(0.5, 1.5, int(rng.randint(1, 6 * slots)))
+        times[rng.randint(0, len(times), 2)] *= rng.uniform(5, 60)
+        assert simulate(times, slots) / 2.0 <= shard.block_makespan(times, slots) <= simulate(times, slots) * 2.0
+    assert shard.block_makespan(numpy.full(40, 1.5), 8) == simulate(numpy.full(40, 1.5), 8)
     for trial in range(40):
         slots = int(rng.choice([2, 4, 16, 256]))
         n = int(rng.randint(1, 6 * slots))

@@ -85,8 +85,39 @@ struct PlanKey {
     std::vector<double> t, periods, values, overshoot;
     std::vector<int64_t> offset, length, width;
     tls_params params = {0, 0, 0, 0, 0, 0};
-    std::string env;
+    tls_options opt;
 };
+
+// every switch "the library decides"
+tls_options default_options() {
+    tls_options o;
+    std::memset(&o, 0, sizeof o);
+    o.exact_prefix = o.prune = o.screen32 = o.no_screen = o.fast_slab = o.x_staged = o.split = o.split_batch = -1;
+    o.sort2 = o.sort3 = o.stage_c = o.slab_wgs = o.threads = o.blocks = o.plan_threads = -1;
+    o.reserved_ = 0;
+    o.prune_min_live = -1;
+    o.band_max = -1.0;
+    return o;
+}
+
+// The TLS_* environment variables (include/tls_amd.h, tls_options), read ONCE per process: what a new context starts
+// with and what the context-free planning calls (tls_period_costs) use.  Nothing reads the environment after this.
+const tls_options& process_options() {
+    static const tls_options cached = [] {
+        tls_options o = default_options();
+        auto geti = [](const char* name, int32_t& field) { if (const char* v = std::getenv(name)) field = (int32_t)std::atoi(v); };
+        geti("TLS_EXACT_PREFIX", o.exact_prefix); geti("TLS_PRUNE", o.prune); geti("TLS_SCREEN32", o.screen32);
+        if (std::getenv("TLS_NO_SCREEN")) o.no_screen = 1;
+        geti("TLS_FAST_SLAB", o.fast_slab); geti("TLS_X_STAGED", o.x_staged); geti("TLS_SPLIT", o.split);
+        geti("TLS_SPLIT_BATCH", o.split_batch); geti("TLS_SORT2", o.sort2); geti("TLS_SORT3", o.sort3);
+        geti("TLS_STAGE_C", o.stage_c); geti("TLS_SLAB_WGS", o.slab_wgs); geti("TLS_THREADS", o.threads);
+        geti("TLS_BLOCKS", o.blocks); geti("TLS_PLAN_THREADS", o.plan_threads);
+        if (const char* v = std::getenv("TLS_PRUNE_MIN_LIVE")) o.prune_min_live = std::atoll(v);
+        if (const char* v = std::getenv("TLS_BAND_MAX")) o.band_max = std::atof(v);
+        return o;
+    }();
+    return cached;
+}
 
 }  // namespace
 
@@ -154,7 +185,8 @@ struct tls_ctx {
     int hdr_bytes = 0, tile_len = 0, tile_halo = 0, region_pad = 0, p2_shift = 4;
     bool prune_kernel = false;        // launch the pruning variant (pruning_pays)
     std::vector<tlsdev::WidthEntry> host_widths;  // kept for tls_update_flux's pruning decision
-    long long prune_min_live = 256;   // live units per period (tile) from which pruning pays; TLS_PRUNE_MIN_LIVE overrides
+    long long prune_min_live = 256;   // live units per period (tile) from which pruning pays; tls_options::prune_min_live overrides
+    tls_options opt;                  // the context's switches (tls_set_options; initially the process's TLS_* environment)
     bool stage_c = false;
 
     // host-side plan
@@ -170,7 +202,10 @@ struct tls_ctx {
     double e_abs_max = INFINITY;   // largest |1 - flux| of the same (inf: a sample outside [0.5, 2]): admits the fp32 screen
     DevBuf<float> d_split;    // fp32 screen: low halves of the folded samples, one region per workgroup
     DevBuf<double> d_park;    // fp32 screen: parked cells, kParkCap per workgroup
-    DevBuf<double> d_band;    // slab variant, fast mode: band_prefix of the next launch
+    DevBuf<double> d_band;    // slab variant, fast mode: band_prefix of the launches (two slots, like h_band)
+    double* d_band_now = nullptr;   // the slot the next launch reads
+    double* h_band = nullptr; size_t h_band_cap = 0;   // pinned: two slots of (n_widths + 1) doubles
+    hipEvent_t ev_band[2] = {nullptr, nullptr}; bool band_used[2] = {false, false}; int band_slot = 0;
     double flux_sigma = 0.0;  // scatter of the flux of the next launch (mean over the curves of a batch)
     double band_sigma = -1.0, band_eps = -1.0;   // what d_band was computed for
     long long q_count = 0;    // elements of the padded template rows (the fp32 screen's second copy starts there)
@@ -225,23 +260,13 @@ int stage_reserve(tls_ctx* ctx, size_t bytes) {
     return TLS_OK;
 }
 
-std::string plan_env() {   // developer switches that change the plan
-    std::string e;
-    for (const char* name : {"TLS_PRUNE", "TLS_PRUNE_MIN_LIVE", "TLS_SORT2", "TLS_SORT3", "TLS_THREADS", "TLS_BLOCKS", "TLS_STAGE_C", "TLS_SLAB_WGS", "TLS_SPLIT", "TLS_SPLIT_BATCH", "TLS_NO_SCREEN"}) {
-        const char* v = std::getenv(name);
-        e += v ? v : "-";
-        e += '|';
-    }
-    return e;
-}
-
 size_t template_values(const tls_template* tmpl) {
     int64_t total = 0;
     for (int64_t r = 0; r < tmpl->n_rows; ++r) total = std::max(total, tmpl->offset[r] + std::max<int64_t>(tmpl->length[r], 0));
     return (size_t)std::max<int64_t>(total, 0);
 }
 
-bool key_matches(const PlanKey& k, const double* t, int64_t n, const double* periods, int64_t n_periods,
+bool key_matches(const PlanKey& k, const tls_options& opt, const double* t, int64_t n, const double* periods, int64_t n_periods,
                  const tls_template* tmpl, const tls_params* params) {
     if (!k.valid || k.n != n || k.n_periods != n_periods || k.n_rows != tmpl->n_rows) return false;
     if (std::memcmp(&k.params, params, sizeof(tls_params)) != 0) return false;
@@ -251,10 +276,10 @@ bool key_matches(const PlanKey& k, const double* t, int64_t n, const double* per
         return false;
     if (k.values.size() != template_values(tmpl) || std::memcmp(k.values.data(), tmpl->values, k.values.size() * 8)) return false;
     if (std::memcmp(k.t.data(), t, (size_t)n * 8) || std::memcmp(k.periods.data(), periods, (size_t)n_periods * 8)) return false;
-    return k.env == plan_env();
+    return std::memcmp(&k.opt, &opt, sizeof(tls_options)) == 0;
 }
 
-void key_store(PlanKey& k, const double* t, int64_t n, const double* periods, int64_t n_periods,
+void key_store(PlanKey& k, const tls_options& opt, const double* t, int64_t n, const double* periods, int64_t n_periods,
                const tls_template* tmpl, const tls_params* params) {
     k.n = n; k.n_periods = n_periods; k.n_rows = tmpl->n_rows; k.params = *params;
     k.t.assign(t, t + n); k.periods.assign(periods, periods + n_periods);
@@ -262,7 +287,7 @@ void key_store(PlanKey& k, const double* t, int64_t n, const double* periods, in
     k.offset.assign(tmpl->offset, tmpl->offset + rows); k.length.assign(tmpl->length, tmpl->length + rows);
     k.width.assign(tmpl->width, tmpl->width + rows); k.overshoot.assign(tmpl->overshoot, tmpl->overshoot + rows);
     k.values.assign(tmpl->values, tmpl->values + template_values(tmpl));
-    k.env = plan_env();
+    k.opt = opt;
     k.valid = true;
 }
 
@@ -384,7 +409,7 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
 // differences and the squared remainder are then exact sums over each row's own taps (long double, remainder
 // rounded up): the bound is rigorous for ANY boundaries, good ones only make it tight.
 void build_screens(const std::vector<tlsdev::WidthEntry>& widths, const std::vector<double>& q,
-                   std::vector<tlsdev::RowScreen>& screens) {
+                   std::vector<tlsdev::RowScreen>& screens, bool one_segment_only) {
     constexpr int K = tlsdev::kSeg;
     screens.assign(widths.size(), tlsdev::RowScreen());
     for (auto& sc : screens) { std::memset(&sc, 0, sizeof sc); }
@@ -460,7 +485,7 @@ void build_screens(const std::vector<tlsdev::WidthEntry>& widths, const std::vec
         // q~' within 1 ulp of levd -- absorbed by inflating the remainder; |dsum| * mean enters the same way)
         sc.sq = (double)sq;
         sc.r2 = (double)(r2 * (1.0L + 1e-9L)) + 1e-24 + 1e-12 * (double)fabsl(dsum);
-        sc.valid = std::getenv("TLS_NO_SCREEN") ? 0 : 1;   // developer switch: the one-segment bound (cell_bound) for every row
+        sc.valid = one_segment_only ? 0 : 1;   // developer switch (tls_options::no_screen): the one-segment bound (cell_bound) for every row
     }
 }
 
@@ -484,19 +509,19 @@ bool screen_admissible(bool resident, bool uniform, double e_abs_max) {
 // (0.32) 2.94 / 2.54 / 2.47; 300 ppm (0.38) 3.22 / 2.76 / 2.58; 500 ppm (0.42) 3.61 / 2.93 / 2.75.  The
 // screen halves the FMA instructions of the dot products but adds a split pass and a valuation pass per period (DESIGN
 // section 4): it pays where the dot products dominate and the pruning passes do not pay yet.
-// TLS_PRUNE=0/1 and TLS_SCREEN32=0/1 force either choice (tests run all three variants).
+// tls_options::prune = 0/1 and ::screen32 = 0/1 force either choice (tests run all three variants).
 constexpr double kScreenFromFraction = 0.13, kPruneFromFraction = 0.24, kPruneFromFractionBesideScreen = 0.30;
-bool pruning_pays(const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool resident,
+bool pruning_pays(const tls_options& opt, const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool resident,
                   bool screen_ok = false) {
-    if (const char* env = std::getenv("TLS_PRUNE")) return std::atoi(env) != 0;
+    if (opt.prune >= 0) return opt.prune != 0;
     if (!resident || !(sigma > 0) || widths.empty()) return false;
     for (const auto& we : widths) if (!we.prunable) return false;
-    if (const char* env = std::getenv("TLS_SCREEN32")) screen_ok = screen_ok && std::atoi(env) != 0;
+    if (opt.screen32 >= 0) screen_ok = screen_ok && opt.screen32 != 0;
     return passing_fraction(widths, sigma, depth_min) >= (screen_ok ? kPruneFromFractionBesideScreen : kPruneFromFraction);
 }
-bool screen_pays(const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool admissible) {
+bool screen_pays(const tls_options& opt, const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool admissible) {
     if (!admissible) return false;
-    if (const char* env = std::getenv("TLS_SCREEN32")) return std::atoi(env) != 0;
+    if (opt.screen32 >= 0) return opt.screen32 != 0;
     return passing_fraction(widths, sigma, depth_min) >= kScreenFromFraction;
 }
 
@@ -510,6 +535,29 @@ double flux_scatter(const double* y, int64_t n) {
     return (double)std::sqrt((double)(v / (long double)n));
 }
 
+// Fast prefix-sum mode: half-width of the band around transit_depth_min inside which the plain scan
+// cannot decide a window -- 1.25 x the bound 2^-53 c_max on |dX/d - mean_reference| (c_max = (n + W) max|flux| bounds the
+// reference's running sum), plus 1e-14 for what the bound leaves out (the plain scan's own rounding, <= ~20 * 2^-53 *
+// max|X| / d, and the reference's division; rounds 3 and early 4 shipped 2 x: twice the second attempts for no safety).
+constexpr double kBandMax = 0.1;   // (Kepler full grid, same box: 0.35 -> 244 ms, 0.1 -> 241, 0.01 -> 240, never -> 249)
+double fast_mode_eps(int64_t M, double y_abs_max) {
+    return 1.25 * (1.1102230246251565e-16 * ((double)M * y_abs_max)) + 1e-14;
+}
+// Expected number of windows of width row k inside that band, as a prefix over the width table: n_pos * 2 eps * density of
+// the window mean at depth_min (a flat, white light curve: mean of 1 - flux ~ N(0, sigma^2 / d)).  A period's expectation
+// is pre[k_hi] - pre[k_lo]; above band_max the period starts in exact mode (kernel), and it weighs on the queue order (host).
+// n_pos of a row is (M - width) / xth + 1, the same for every period of the plan.
+void band_prefix_for(const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, double eps,
+                     std::vector<double>& pre, int64_t M = -1) {
+    pre.assign(widths.size() + 1, 0.0);
+    for (size_t k = 0; k < widths.size(); ++k) {
+        const auto& we = widths[k];
+        const double n_pos = M >= 0 ? (double)((M - we.width) / we.xth + 1) : (double)we.n_pos;
+        const double sd = sigma / std::sqrt((double)we.width), z = depth_min / sd;
+        pre[k + 1] = pre[k] + n_pos * 2.0 * eps * std::exp(-0.5 * z * z) / (sd * 2.5066282746310002);
+    }
+}
+
 // In-range width window of every period (core.py:143-156) and its trial-cell count.
 // The same for every period of a grid (what tls_prepare and tls_grid_cells need): the in-range rows [k_lo, k_hi)
 // of the ascending width table by binary search, the dense rows [k_lo, k_x), and the trial-cell count from a
@@ -521,7 +569,7 @@ struct GridPlan {
 };
 bool plan_periods(const std::vector<tlsdev::WidthEntry>& widths, const tls_params* params, const double* periods,
                   int64_t n_periods, double length, int64_t n, int64_t M, tlsdev::PeriodRows* prow, int64_t* cost,
-                  GridPlan* total) {
+                  GridPlan* total, int plan_threads = -1) {
     const int nw = (int)widths.size();
     std::vector<int> wd((size_t)nw);
     std::vector<int64_t> prefix((size_t)nw + 1, 0);
@@ -564,7 +612,7 @@ bool plan_periods(const std::vector<tlsdev::WidthEntry>& widths, const tls_param
     if (n_periods >= 4096) {
         n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
         n_threads = (unsigned)std::min<int64_t>(n_threads, n_periods / 2048);
-        if (const char* env = std::getenv("TLS_PLAN_THREADS")) n_threads = (unsigned)std::max(1, std::min(64, std::atoi(env)));
+        if (plan_threads > 0) n_threads = (unsigned)std::max(1, std::min(64, plan_threads));
     }
     std::vector<GridPlan> part(n_threads);
     std::vector<char> ok(n_threads, 1);
@@ -707,47 +755,57 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         // (band half-width: 1.25 x the bound 2^-53 c_max on |dX/d - mean_reference|, plus 1e-14 for what the bound leaves out --
         // the plain scan's own rounding, <= ~20 * 2^-53 * max|X| / d, and the reference's division; rounds 3 and early 4
         // shipped 2 x: twice the second attempts for no additional safety)
-        a.eps_fast = 1.25 * (1.1102230246251565e-16 * c_max) + 1e-14;
+        a.eps_fast = fast_mode_eps(ctx->M, ctx->y_abs_max);
         a.slack_unit = 2.5e-16 * c_max;
-        const char* env = std::getenv("TLS_EXACT_PREFIX");
-        a.exact_prefix = (env && std::atoi(env) != 0) ? 1 : 0;
-        // Series in the HBM slab, one-workgroup-per-period kernel: fast mode too (TLS_FAST_SLAB=0: exact mode).  The band
-        // grows with the series (eps ~ 2^-52 (n + W) max|flux|) while the noise of a window mean shrinks: 2.6 % of the
-        // TESS-size and 10 % of the Kepler-size periods hit it and go through the prefix sum and phase 3 a second time
+        a.exact_prefix = ctx->opt.exact_prefix == 1 ? 1 : 0;
+        // Series in the HBM slab, one-workgroup-per-period kernel: fast mode too (tls_options::fast_slab = 0: exact mode).
+        // The band grows with the series (eps ~ 2^-52 (n + W) max|flux|) while the noise of a window mean shrinks: 2.6 % of
+        // the TESS-size and 10 % of the Kepler-size periods hit it and go through the prefix sum and phase 3 a second time
         // (the folded flux is kept).  Round 4, same box: Kepler full grid 275.8 -> 254.8 ms, TESS 2.97 -> 2.90 ms.
-        // The two-role kernel always runs exact mode (its fold role cannot know what its search role will find).
-        a.fast_slab = 1;
-        // (a launch of up to four rounds of periods stays exact: a second attempt in its last round would end it a whole
-        // period late -- the 512- and 411-period blocks of an 8-GPU TESS job ran 0.61 / 0.73 instead of 0.57 ms)
-        if ((long long)ctx->n_periods <= 4LL * ctx->blocks) a.fast_slab = 0;
-        if (const char* fs = std::getenv("TLS_FAST_SLAB")) a.fast_slab = std::atoi(fs) != 0 ? 1 : 0;
+        // WHICH mode a period takes depends on the light curve and the period alone (the expectation below) -- never on how
+        // many other periods the launch holds or on the device: a shard of a multi-GPU search returns the bits of the
+        // full-grid search.  (Round 4 kept launches of <= 4 rounds exact to spare them a late second attempt; a period's
+        // bits then depended on the launch.  The queue order now sends the periods most likely to need one first.)
+        a.fast_slab = ctx->opt.fast_slab == 0 ? 0 : 1;
     }
     a.x_at_staging = 0;
     if (!ctx->resident && a.fast_slab && !ctx->stage_c) {
         bool any_oversize = false;   // (rows evaluated straight from the slab list their cells with the first tile: they need all of X)
         for (const auto& we : ctx->host_widths) any_oversize = any_oversize || we.oversize != 0;
         a.x_at_staging = any_oversize ? 0 : 1;
-        if (const char* env = std::getenv("TLS_X_STAGED")) a.x_at_staging = a.x_at_staging && std::atoi(env) != 0;
+        if (ctx->opt.x_staged == 0) a.x_at_staging = 0;
     }
-    a.band_prefix = nullptr; a.band_max = 0.1;   // (Kepler full grid, same box: 0.35 -> 244 ms, 0.1 -> 241, 0.01 -> 240, never -> 249)
-    if (const char* env = std::getenv("TLS_BAND_MAX")) a.band_max = std::atof(env);   // developer switch (PERF_LOG round 4)
+    a.band_prefix = nullptr;
+    a.band_max = ctx->opt.band_max >= 0 ? ctx->opt.band_max : kBandMax;
     if (!ctx->resident && a.fast_slab && ctx->flux_sigma > 0 &&
-        !(ctx->band_sigma == ctx->flux_sigma && ctx->band_eps == a.eps_fast && ctx->d_band.ptr)) {
-        // expected number of windows of row k inside the band: n_pos * 2 eps * density of the window mean at depth_min
-        // (a flat, white light curve: mean of 1 - flux ~ N(0, sigma^2 / d)); its prefix over the width table lets the kernel
-        // form a period's expectation from its duration window [k_lo, k_hi)
-        std::vector<double> pre(ctx->host_widths.size() + 1, 0.0);
-        for (size_t k = 0; k < ctx->host_widths.size(); ++k) {
-            const auto& we = ctx->host_widths[k];
-            const double sd = ctx->flux_sigma / std::sqrt((double)we.width), z = ctx->depth_min / sd;
-            pre[k + 1] = pre[k] + (double)we.n_pos * 2.0 * a.eps_fast * std::exp(-0.5 * z * z) / (sd * 2.5066282746310002);
+        !(ctx->band_sigma == ctx->flux_sigma && ctx->band_eps == a.eps_fast && ctx->d_band_now)) {
+        // the band expectation of every width row (band_prefix_for), as a prefix over the width table: the kernel forms a
+        // period's expectation from its duration window [k_lo, k_hi).  Uploaded from one of two pinned slots, nothing is
+        // waited for (a survey changes sigma with every group of light curves: the launch in flight keeps reading its own slot).
+        const size_t cnt = ctx->host_widths.size() + 1;
+        if (ctx->h_band_cap < 2 * cnt) {
+            TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->h_band) TLS_HIP(ctx, hipHostFree(ctx->h_band));
+            ctx->h_band = nullptr; ctx->h_band_cap = 0;
+            TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_band), 2 * cnt * sizeof(double), hipHostMallocDefault));
+            ctx->h_band_cap = 2 * cnt;
+            TLS_HIP(ctx, ctx->d_band.reserve(2 * cnt));
+            for (auto& ev : ctx->ev_band) if (!ev) TLS_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->band_used[0] = ctx->band_used[1] = false;
         }
-        TLS_HIP(ctx, ctx->d_band.reserve(pre.size()));
-        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_band.ptr, pre.data(), pre.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (pageable source; once per prepared flux)
+        const int slot = ctx->band_slot ^= 1;
+        if (ctx->band_used[slot]) TLS_HIP(ctx, hipEventSynchronize(ctx->ev_band[slot]));   // (two uploads ago: long done)
+        double* h = ctx->h_band + (size_t)slot * cnt;
+        std::vector<double> pre;
+        band_prefix_for(ctx->host_widths, ctx->flux_sigma, ctx->depth_min, a.eps_fast, pre);
+        std::memcpy(h, pre.data(), cnt * sizeof(double));
+        ctx->d_band_now = ctx->d_band.ptr + (size_t)slot * cnt;
+        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_band_now, h, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TLS_HIP(ctx, hipEventRecord(ctx->ev_band[slot], ctx->stream));
+        ctx->band_used[slot] = true;
         ctx->band_sigma = ctx->flux_sigma; ctx->band_eps = a.eps_fast;
     }
-    if (!ctx->resident && a.fast_slab && ctx->flux_sigma > 0) a.band_prefix = ctx->d_band.ptr;
+    if (!ctx->resident && a.fast_slab && ctx->flux_sigma > 0) a.band_prefix = ctx->d_band_now;
     a.sort2 = ctx->sort2 ? 1 : 0;
     a.sort3 = ctx->sort3 ? 1 : 0; a.sort3_scratch = ctx->d_sort3.ptr;
     a.n_curves = ctx->batch_curves;
@@ -761,8 +819,11 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.fold_ready = ctx->d_tiles_done.ptr ? ctx->d_tiles_done.ptr + ctx->split_batch : nullptr;   // (only the two-role plan has them)
     hipError_t e;
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
-    if ((e = timing_pair(ctx, &evp)) != hipSuccess || (e = hipEventRecord(evp->first, ctx->stream)) != hipSuccess)
+    if ((e = timing_pair(ctx, &evp)) != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("timing events: ") + hipGetErrorString(e));
+    if ((e = hipEventRecord(evp->first, ctx->stream)) != hipSuccess) {
+        --ctx->ev_used;
         return fail(ctx, TLS_E_HIP, std::string("timing events: ") + hipGetErrorString(e));
+    }
     // pruning variant: uniform weights, noisy enough that most trial cells pass the depth predicate,
     // and not while the evaluated cells are being counted (counting means evaluating all of them)
     const bool prune = ctx->uniform_w && ctx->prune_kernel && !count_work;
@@ -787,10 +848,10 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     if (screen) {
         const size_t region = (size_t)ctx->M + 1 + (size_t)ctx->region_pad;
         hipError_t er = ctx->d_split.reserve((size_t)ctx->blocks * region);
-        if (er != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er));
+        if (er != hipSuccess) { --ctx->ev_used; return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er)); }
         a.split_lo = ctx->d_split.ptr;
         er = ctx->d_park.reserve((size_t)ctx->blocks * tlsdev::kParkCap * 2);   // (a ParkedCell is two doubles wide)
-        if (er != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er));
+        if (er != hipSuccess) { --ctx->ev_used; return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er)); }
         a.park_cells = ctx->d_park.ptr;
         e = launch_variant<true, true, false, unsigned short, false, false, true>(ctx, a, ctx->blocks);
     } else if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short, ctx->blocks);
@@ -812,9 +873,13 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     }
 #undef TLS_LAUNCH_SPLIT
 #undef TLS_LAUNCH
-    if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    if ((e = hipEventRecord(evp->second, ctx->stream)) != hipSuccess)
+    // (a failure from here on gives the event pair back: tls_kernel_timing must not meet a pair whose second event was
+    // never recorded)
+    if (e != hipSuccess) { --ctx->ev_used; return fail(ctx, TLS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    if ((e = hipEventRecord(evp->second, ctx->stream)) != hipSuccess) {
+        --ctx->ev_used;
         return fail(ctx, TLS_E_HIP, std::string("timing events: ") + hipGetErrorString(e));
+    }
     ctx->executed = true;
     ctx->counted = count_work;
     return TLS_OK;
@@ -874,7 +939,7 @@ int visible_compute_units() {
 
 extern "C" {
 
-const char* tls_version(void) { return "tls_amd 0.3 (gfx950)"; }
+const char* tls_version(void) { return "tls_amd 0.4 (gfx950)"; }
 
 int tls_abi_version(void) { return TLS_AMD_ABI_VERSION; }
 
@@ -904,6 +969,7 @@ tls_ctx* tls_ctx_create(int device_id) {
     tls_ctx* ctx = new (std::nothrow) tls_ctx();
     if (!ctx) { g_create_error = "out of host memory"; return nullptr; }
     ctx->device = device_id;
+    ctx->opt = process_options();
     hipDeviceProp_t prop;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -920,6 +986,24 @@ tls_ctx* tls_ctx_create(int device_id) {
     return ctx;
 }
 
+int tls_get_options(const tls_ctx* ctx, tls_options* out) {
+    if (!ctx || !out) return TLS_E_ARG;
+    *out = ctx->opt;
+    return TLS_OK;
+}
+
+int tls_set_options(tls_ctx* ctx, const tls_options* opt) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!opt) return fail(ctx, TLS_E_ARG, "null options");
+    tls_options o = *opt;
+    o.reserved_ = 0;
+    if (std::memcmp(&o, &ctx->opt, sizeof o) == 0) return TLS_OK;
+    ctx->opt = o;
+    // a prepared plan was built for the old switches: the next tls_prepare plans again (the key holds them too)
+    ctx->prepared = false; ctx->executed = false;
+    return TLS_OK;
+}
+
 void tls_ctx_destroy(tls_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -934,6 +1018,8 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_pqueues.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     ctx->d_split.release(); ctx->d_park.release(); ctx->d_band.release();
+    if (ctx->h_band) (void)hipHostFree(ctx->h_band);
+    for (auto& ev : ctx->ev_band) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : ctx->slot) {
         sl.d_y.release(); sl.d_w.release(); sl.d_S0.release(); sl.d_w0.release(); sl.d_chi2.release(); sl.d_depth.release(); sl.d_row.release();
         if (sl.h_in) (void)hipHostFree(sl.h_in);
@@ -963,7 +1049,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
 
     // The same time stamps, periods, template and parameters as the plan this context already holds (a survey, or
     // repeated power() calls): only the flux is new.  tls_prepare then costs two passes over y and one upload.
-    if (ctx->key.valid && key_matches(ctx->key, t, n, periods, n_periods, tmpl, params)) {
+    if (ctx->key.valid && key_matches(ctx->key, ctx->opt, t, n, periods, n_periods, tmpl, params)) {
         const int rcu = update_flux_impl(ctx, y, dy);
         if (rcu == TLS_OK) { ctx->prepared = true; ++ctx->plan_reuses; return TLS_OK; }
         if (rcu != kWeightsDiffer) return rcu;
@@ -989,10 +1075,18 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     tls_counters pc = {0, 0, 0, 0, 0};
     {
         GridPlan gp;
-        if (!plan_periods(widths, params, periods, n_periods, t_max - t_min, n, M, prow.data(), cost.data(), &gp))
+        if (!plan_periods(widths, params, periods, n_periods, t_max - t_min, n, M, prow.data(), cost.data(), &gp, ctx->opt.plan_threads))
             return fail(ctx, TLS_E_ARG, "periods must be positive and finite");
         pc.grid_cells = gp.cells; pc.pd_pairs = gp.pairs;
     }
+    // weights
+    std::vector<double> w;
+    bool uniform; double w0, S0;
+    double y_abs_max = 0.0, e_abs_max = 0.0;
+    weights_from(y, dy, n, uniform, w0, w, S0, &y_abs_max, &e_abs_max);
+    ctx->y_abs_max = y_abs_max; ctx->e_abs_max = e_abs_max;
+    const double flux_sigma = flux_scatter(y, n);
+
     // Work order: most expensive first.  A period commensurate with the cadence of a regularly sampled series piles
     // the phases onto a few values and its sort costs several ordinary periods: such a period
     // goes to the head of the queue, where its long run overlaps everything else instead of ending the launch.
@@ -1016,15 +1110,23 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
                 }
             }
         }
+        // Fast prefix-sum mode: a period whose windows are likely to meet the undecided band pays a second attempt
+        // (0.65 of itself); among periods of similar cost the likelier ones start first, so that the second attempts
+        // fall into the body of the launch and not into its last round.  (Only the order: which mode a period takes
+        // never depends on it.)  The expectation is band_prefix_for's, as in enqueue; the LDS-resident kernel has no
+        // per-period expectation (every period starts in fast mode): the same weight orders its queue.
+        if (flux_sigma > 0 && ctx->opt.exact_prefix != 1) {
+            std::vector<double> pre;
+            band_prefix_for(widths, flux_sigma, params->transit_depth_min, fast_mode_eps(M, y_abs_max), pre, M);
+            const double band_max = ctx->opt.band_max >= 0 ? ctx->opt.band_max : kBandMax;
+            for (int64_t p = 0; p < n_periods; ++p) {
+                const double lambda = pre[(size_t)prow[(size_t)p].k_hi] - pre[(size_t)prow[(size_t)p].k_lo];
+                if (lambda > band_max) continue;                                   // (starts in exact mode: no second attempt)
+                queue_cost[(size_t)p] += (int64_t)(0.3 * std::min(1.0, lambda / std::max(band_max, 1e-300)) * (double)cost[(size_t)p]);
+            }
+        }
         order_by_cost(queue_cost, order);
     }
-
-    // weights
-    std::vector<double> w;
-    bool uniform; double w0, S0;
-    double y_abs_max = 0.0, e_abs_max = 0.0;
-    weights_from(y, dy, n, uniform, w0, w, S0, &y_abs_max, &e_abs_max);
-    ctx->y_abs_max = y_abs_max; ctx->e_abs_max = e_abs_max;
 
     // launch geometry
     const size_t regions = uniform ? 2 : 3;
@@ -1043,9 +1145,10 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         ctx->lds_bytes = resident_bytes;
         const size_t per_cu = kLdsPerCU / resident_bytes;
         ctx->threads = per_cu >= 2 ? 512 : 1024;
-        if (const char* env = std::getenv("TLS_THREADS")) ctx->threads = std::max(64, std::min(1024, std::atoi(env) / 64 * 64));   // developer switch
+        if (ctx->opt.threads > 0) ctx->threads = std::max(64, std::min(1024, ctx->opt.threads / 64 * 64));   // developer switch
         const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)ctx->threads);
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)wg_per_cu * ctx->n_cu);
+        if (ctx->opt.blocks > 0) ctx->blocks = std::max(1, std::min(ctx->blocks, ctx->opt.blocks));   // developer switch
     } else {
         // the folded series lives in a per-workgroup HBM slab; phase 3 stages it through LDS in
         // tiles of `tile_len` window-start positions plus a halo of the widest window
@@ -1057,7 +1160,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // Workgroups per CU of the slab variant: one 1024-thread workgroup with all of the LDS, or (TLS_SLAB_WGS=2, measured
         // below) two 512-thread ones with half each, so that one period's latency-bound phases overlap another's arithmetic.
         int slab_wgs = 1;
-        if (const char* env = std::getenv("TLS_SLAB_WGS")) slab_wgs = std::atoi(env) == 2 ? 2 : 1;
+        if (ctx->opt.slab_wgs == 2) slab_wgs = 2;
         const size_t lds_budget = kLdsPerCU / (size_t)slab_wgs;
         ctx->nb = (int)std::min<int64_t>(n, (int64_t)((lds_budget - hdr) / 4));
         size_t halo = (size_t)W + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
@@ -1097,7 +1200,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         const size_t tiles_c = tiles_for(buffers_c), tiles_noc = tiles_for(buffers_noc);
         if (tiles_noc == 0) return fail(ctx, TLS_E_ARG, "widest transit window does not fit the LDS tile");
         ctx->stage_c = tiles_c != 0 && tiles_c <= tiles_noc;
-        if (const char* env = std::getenv("TLS_STAGE_C")) ctx->stage_c = tiles_c != 0 && std::atoi(env) != 0;   // A/B switch
+        if (ctx->opt.stage_c >= 0) ctx->stage_c = tiles_c != 0 && ctx->opt.stage_c != 0;   // A/B switch
         const size_t buffers = ctx->stage_c ? buffers_c : buffers_noc;
         const size_t cap_doubles = (lds_budget - hdr) / 8 / buffers;
         const size_t cap_tile = (cap_doubles - halo) / unit * unit;
@@ -1143,24 +1246,22 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         ctx->lds_bytes = hdr + std::max<size_t>(std::max<size_t>(4 * (size_t)ctx->nb, cumsum_bytes),
                                                 buffers * 8 * (tile + halo));
         ctx->threads = slab_wgs == 2 ? 512 : 1024;
-        if (const char* env = std::getenv("TLS_THREADS")) ctx->threads = std::max(64, std::min(1024, std::atoi(env) / 64 * 64));   // developer switch
+        if (ctx->opt.threads > 0) ctx->threads = std::max(64, std::min(1024, ctx->opt.threads / 64 * 64));   // developer switch
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)ctx->n_cu * slab_wgs);
-        if (const char* env = std::getenv("TLS_BLOCKS"))   // developer switch: workgroups in flight (memory-system experiments)
-            ctx->blocks = std::max(1, std::min(ctx->blocks, std::atoi(env)));
+        if (ctx->opt.blocks > 0)   // developer switch: workgroups in flight (memory-system experiments)
+            ctx->blocks = std::max(1, std::min(ctx->blocks, ctx->opt.blocks));
         // two-level sort with sequential HBM accesses (fold_and_sort_tiled) when its LDS windows fit
         const size_t sort2_bytes = hdr + (size_t)tlsdev::sort2_lds_bytes((int)n, ctx->threads);
-        const char* env_sort2 = std::getenv("TLS_SORT2");
-        ctx->sort2 = sort2_bytes <= lds_budget && !(env_sort2 && std::atoi(env_sort2) == 0);
+        ctx->sort2 = sort2_bytes <= lds_budget && ctx->opt.sort2 != 0;
         if (ctx->sort2) ctx->lds_bytes = std::max(ctx->lds_bytes, sort2_bytes);
         // one light curve per launch: partition into large phase bins, per-bin LDS sort fused with the prefix sum
         const size_t sort3_bytes = hdr + (size_t)tlsdev::sort3_lds_bytes();
-        const char* env_sort3 = std::getenv("TLS_SORT3");
         // (measured on the Kepler-size series: 8 % fewer HBM bytes than the two-level sort -- 5.2 vs 5.7 MB per
         // period -- but 32 % more kernel time, its 23 bin rounds of eleven barriers each cost more than the
         // gather they avoid; on the TESS-size series 15 % slower.  The two-level sort stays the default,
         // TLS_SORT3=1 selects this path; both are tested.)
         ctx->sort3 = sort3_bytes <= lds_budget && tlsdev::sort3_bins((int)n) <= tlsdev::kSort3MaxBins && (int64_t)W <= n &&
-                     (env_sort3 ? std::atoi(env_sort3) != 0 : false);
+                     ctx->opt.sort3 == 1;
         // Two-role slab kernel: every workgroup folds periods into per-period slabs, then searches
         // (period, tile) items; the periods go through it in batches that hold one slab per period in HBM (as many periods as
         // fit `kSplitSlabBytes`, at least four rounds of workgroups; all of them when the grid is small).
@@ -1171,17 +1272,21 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // N = 70 128, 2.8 rounds: 1.37 vs 1.63 ms; 308 periods of the TESS-size series: 0.53 ms both ways).  Hence: up to one
         // and a half rounds of periods -> two-role kernel.  TLS_SPLIT=0/1 forces the choice (A/B, tests).
         ctx->split_blocks = ctx->n_cu * slab_wgs;
-        if (const char* env = std::getenv("TLS_BLOCKS")) ctx->split_blocks = std::max(1, std::min(ctx->split_blocks, std::atoi(env)));
+        if (ctx->opt.blocks > 0) ctx->split_blocks = std::max(1, std::min(ctx->split_blocks, ctx->opt.blocks));
         {
-            const char* env_split = std::getenv("TLS_SPLIT");
-            ctx->split = n_periods > 0 && (env_split ? std::atoi(env_split) != 0 : 2 * n_periods <= 3 * (int64_t)ctx->split_blocks);
+            // The two-role kernel has no fast prefix-sum mode (its fold role cannot know what its search role will find), and
+            // the mode of a period must not depend on the launch shape (enqueue): the plan takes it by itself only where every
+            // period runs exact mode anyway; tls_options::split = 0 / 1 forces the choice (A/B, tests).
+            const bool all_exact = ctx->opt.exact_prefix == 1 || ctx->opt.fast_slab == 0 || ctx->opt.sort3 == 1;
+            ctx->split = n_periods > 0 && (ctx->opt.split >= 0 ? ctx->opt.split != 0
+                                                               : all_exact && 2 * n_periods <= 3 * (int64_t)ctx->split_blocks);
             // (Cutting the positions finer than the LDS requires -- more items per workgroup when the periods are few -- was
             // measured and is not done: every tile stages its halo, waits for its slab and walks every row; 307 periods of the
             // TESS-size series 0.53 ms with two tiles per period, 0.62 / 0.75 / 1.00 ms with 4 / 8 / 16 items per workgroup.)
             const size_t slab_bytes = regions * ((region_doubles + 1) & ~(size_t)1) * 8;
             constexpr size_t kSplitSlabBytes = (size_t)12 << 30;
             int64_t batch = std::max<int64_t>((int64_t)(kSplitSlabBytes / slab_bytes), (int64_t)4 * ctx->split_blocks);
-            if (const char* env = std::getenv("TLS_SPLIT_BATCH")) batch = std::max<int64_t>(1, std::atoll(env));
+            if (ctx->opt.split_batch > 0) batch = ctx->opt.split_batch;
             ctx->split_batch = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), batch);
             ctx->host_tile_prefix.assign((size_t)n_periods + 1, 0u);
             ctx->split_max_items = 0;
@@ -1226,7 +1331,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->list_stride = (list_cap + 63) / 64 * 64;
     // three arrays per workgroup: the live units, (pruning) the bound of each, and the units the bound keeps
     TLS_HIP(ctx, ctx->d_lists.reserve((size_t)std::max(ctx->blocks, (!ctx->resident && ctx->split) ? ctx->split_blocks : 0) * 3 * ctx->list_stride));
-    if (const char* env = std::getenv("TLS_PRUNE_MIN_LIVE")) ctx->prune_min_live = std::atoll(env);
+    ctx->prune_min_live = ctx->opt.prune_min_live >= 0 ? (long long)ctx->opt.prune_min_live : 256;
     ctx->p2_shift = 4;  // block length of the coarse prefix sum of e^2: at most kP2MaxBlocks blocks
     while ((((size_t)M + ((size_t)1 << ctx->p2_shift) - 1) >> ctx->p2_shift) > (size_t)tlsdev::kP2MaxBlocks) ++ctx->p2_shift;
 
@@ -1234,20 +1339,20 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->n_widths = (int)widths.size();
     ctx->uniform_w = uniform; ctx->w0 = w0; ctx->S0 = S0; ctx->depth_min = params->transit_depth_min;
     ctx->host_widths = widths;
-    ctx->band_sigma = -1.0;   // (d_band belongs to the previous width table)
+    ctx->band_sigma = -1.0; ctx->d_band_now = nullptr;   // (d_band belongs to the previous width table)
     {
-        const double sigma = flux_scatter(y, n);
+        const double sigma = flux_sigma;
         ctx->flux_sigma = sigma;
         const bool scr_ok = screen_admissible(ctx->resident, uniform, ctx->e_abs_max);
-        ctx->prune_kernel = uniform && pruning_pays(widths, sigma, params->transit_depth_min, ctx->resident, scr_ok);
-        ctx->screen_kernel = screen_pays(widths, sigma, params->transit_depth_min, scr_ok);
+        ctx->prune_kernel = uniform && pruning_pays(ctx->opt, widths, sigma, params->transit_depth_min, ctx->resident, scr_ok);
+        ctx->screen_kernel = screen_pays(ctx->opt, widths, sigma, params->transit_depth_min, scr_ok);
     }
     ctx->plan_counters = pc;
 
     // ONE pinned staging buffer, ONE device allocation, ONE asynchronous copy; nothing is waited for here (the
     // staging buffer is reused only after its event)
     std::vector<tlsdev::RowScreen> screens;
-    build_screens(widths, q, screens);
+    build_screens(widths, q, screens, ctx->opt.no_screen == 1);
     {
         PlanLayout& L = ctx->layout;
         size_t off = 0;
@@ -1306,7 +1411,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         TLS_HIP(ctx, ctx->d_squeue.reserve(4));   // [0..1] the search (or fold) kernel's queue, [2..3] the split path's search kernel
         TLS_HIP(ctx, hipMemsetAsync(ctx->d_squeue.ptr, 0, 4 * sizeof(unsigned int), ctx->stream));
     }
-    key_store(ctx->key, t, n, periods, n_periods, tmpl, params);
+    key_store(ctx->key, ctx->opt, t, n, periods, n_periods, tmpl, params);
     ctx->prepared = true;
     return TLS_OK;
 }
@@ -1324,8 +1429,8 @@ int update_flux_impl(tls_ctx* ctx, const double* y, const double* dy) {
         const double sigma = flux_scatter(y, ctx->n);
         ctx->flux_sigma = sigma;
         const bool scr_ok = screen_admissible(ctx->resident, uniform, ctx->e_abs_max);
-        ctx->prune_kernel = uniform && pruning_pays(ctx->host_widths, sigma, ctx->depth_min, ctx->resident, scr_ok);
-        ctx->screen_kernel = screen_pays(ctx->host_widths, sigma, ctx->depth_min, scr_ok);
+        ctx->prune_kernel = uniform && pruning_pays(ctx->opt, ctx->host_widths, sigma, ctx->depth_min, ctx->resident, scr_ok);
+        ctx->screen_kernel = screen_pays(ctx->opt, ctx->host_widths, sigma, ctx->depth_min, scr_ok);
     }
     const PlanLayout& L = ctx->layout;
     const size_t nn = (size_t)ctx->n;
@@ -1503,24 +1608,13 @@ int tls_debug_cumsum(tls_ctx* ctx, const double* f, int64_t count, double* out, 
     TLS_HIP(ctx, d_f.reserve((size_t)count));
     TLS_HIP(ctx, d_out.reserve((size_t)count + 1));
     if (count) TLS_HIP(ctx, hipMemcpyAsync(d_f.ptr, f, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
-    const int variant = getenv("TLS_DEBUG_CUMSUM_OLD") ? 1 : 0;
+    const int variant = 0;   // (1: the first version of the routine, kept in the kernel for A/B builds)
     // block / fallback counts of this call land in the phase-clock buffer (tls_debug_phase_cycles slots 10, 11)
     TLS_HIP(ctx, ctx->d_phase.reserve(tlsdev::kPhases));
     TLS_HIP(ctx, hipMemsetAsync(ctx->d_phase.ptr, 0, tlsdev::kPhases * sizeof(unsigned long long), ctx->stream));
     { const unsigned long long big = ~0ull; TLS_HIP(ctx, hipMemcpyAsync(ctx->d_phase.ptr + 22, &big, 8, hipMemcpyHostToDevice, ctx->stream)); TLS_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
     hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3((unsigned)threads), 0, ctx->stream, d_f.ptr, d_out.ptr, (int)count, variant, ctx->d_phase.ptr);
     TLS_HIP(ctx, hipGetLastError());
-    if (const char* reps_env = getenv("TLS_DEBUG_CUMSUM_REPS")) {  // developer timing of one workgroup
-        const int reps = atoi(reps_env);
-        TLS_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        for (int r = 0; r < reps; ++r)
-            hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3((unsigned)threads), 0, ctx->stream, d_f.ptr, d_out.ptr, (int)count, variant, (unsigned long long*)nullptr);
-        TLS_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        TLS_HIP(ctx, hipEventSynchronize(ctx->ev1));
-        float ms = 0;
-        TLS_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        std::fprintf(stderr, "tls_debug_cumsum: %lld elements, %d threads: %.2f us per launch\n", (long long)count, threads, 1e3 * ms / reps);
-    }
     TLS_HIP(ctx, hipMemcpyAsync(out, d_out.ptr, ((size_t)count + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     d_f.release(); d_out.release();
@@ -1747,8 +1841,8 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         {
             ctx->flux_sigma = sigma_sum / (double)gc;
             const bool scr_ok = screen_admissible(ctx->resident, uni, ctx->e_abs_max);
-            ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
-            ctx->screen_kernel = screen_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, scr_ok);
+            ctx->prune_kernel = uni && pruning_pays(ctx->opt, ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
+            ctx->screen_kernel = screen_pays(ctx->opt, ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, scr_ok);
         }
         ctx->batch_curves = (int)gc;
         ctx->over_y = sl.d_y.ptr; ctx->over_w = uni ? nullptr : sl.d_w.ptr; ctx->over_S0 = sl.d_S0.ptr; ctx->over_w0 = sl.d_w0.ptr;
@@ -1898,8 +1992,8 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         {
             ctx->flux_sigma = sigma_sum / (double)gc;
             const bool scr_ok = screen_admissible(ctx->resident, uni, ctx->e_abs_max);
-            ctx->prune_kernel = uni && pruning_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
-            ctx->screen_kernel = screen_pays(ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, scr_ok);
+            ctx->prune_kernel = uni && pruning_pays(ctx->opt, ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
+            ctx->screen_kernel = screen_pays(ctx->opt, ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, scr_ok);
         }
         ctx->batch_curves = (int)gc;
         ctx->over_y = sl.d_y.ptr; ctx->over_w = uni ? nullptr : sl.d_w.ptr; ctx->over_S0 = sl.d_S0.ptr; ctx->over_w0 = sl.d_w0.ptr;
@@ -2045,7 +2139,8 @@ int tls_grid_cells(const double* t, int64_t n, const double* periods, int64_t n_
 
 int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t n_periods, const tls_template* tmpl,
                      const tls_params* params, double sigma, int64_t* cells_per_period, double* taps_per_period,
-                     double* time_per_period, int64_t* workgroups_in_flight) {
+                     double* time_per_period, int64_t* workgroups_in_flight, const tls_options* options) {
+    const tls_options po = options ? *options : process_options();
     if (!t || !periods || !cells_per_period || !taps_per_period || n < 3 || n_periods < 0) {
         g_create_error = "tls_period_costs: invalid argument";
         return TLS_E_ARG;
@@ -2088,7 +2183,7 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         const size_t resident_bytes = hdr + 2 * 8 * region_doubles;
         const bool resident = resident_bytes <= kLdsPerCU && n <= 65535;
         const bool two_per_cu = resident && kLdsPerCU / resident_bytes >= 2;
-        const bool prune = pruning_pays(widths, sigma, params->transit_depth_min, resident);
+        const bool prune = pruning_pays(po, widths, sigma, params->transit_depth_min, resident);
         double a0, aN, b, c;
         if (!resident) { a0 = 458384.0; aN = 4.5716; b = 0.4604; c = 0.03275; }        // HBM slab variant (TESS 27 d + Kepler 4 yr)
         else if (prune) { a0 = 116100.0; aN = 0.0; b = 1.906; c = 0.0125; }             // LDS-resident, pruning kernel (90 d at 500 ppm)
@@ -2096,25 +2191,19 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         else { a0 = 56564.0; aN = 0.0; b = 0.3189; c = 0.1267; }                        // LDS-resident, one 1024-thread workgroup per CU (100 d)
         for (int64_t p = 0; p < n_periods; ++p)
             time_per_period[p] = a0 + aN * (double)n + b * (double)cells_per_period[p] + c * taps_per_period[p];
-        // Series in the HBM slab: the coefficients are exact-mode measurements.  A grid long enough for every rank of a
-        // node to hold more than four rounds of periods runs fast mode (enqueue): the plain prefix sum saves ~3.5 cycles per
-        // point, a period pays a second attempt (0.65 of itself) with the probability that one of its windows hits the
-        // undecided band, and a period that expects to hit it starts in exact mode (the same expectation as in enqueue, for a
-        // normalised flux).  Without this the block of the longest periods came out a fifth late (PERF_LOG round 4).
-        bool fast_slab_on = true;
-        if (const char* fs = std::getenv("TLS_FAST_SLAB")) fast_slab_on = std::atoi(fs) != 0;   // (as in enqueue)
-        if (!resident && fast_slab_on && sigma > 0 && n_periods > 8 * 4 * (int64_t)visible_compute_units()) {
-            const double eps = 1.25 * (1.1102230246251565e-16 * (double)M * (1.0 + 5.0 * sigma)) + 1e-14;
-            std::vector<double> band(widths.size() + 1, 0.0);
-            for (size_t k = 0; k < widths.size(); ++k) {
-                const auto& we = widths[k];
-                const double n_pos = (double)((M - we.width) / we.xth + 1);
-                const double sd = sigma / std::sqrt((double)we.width), z = params->transit_depth_min / sd;
-                band[k + 1] = band[k] + n_pos * 2.0 * eps * std::exp(-0.5 * z * z) / (sd * 2.5066282746310002);
-            }
+        // Series in the HBM slab: the coefficients are exact-mode measurements.  The search runs fast mode (enqueue; whatever
+        // the number of periods or ranks: a period's mode depends on the light curve and the period alone): the plain prefix
+        // sum saves ~3.5 cycles per point, a period pays a second attempt (0.65 of itself) with the probability that one of its
+        // windows hits the undecided band, and a period that expects to hit it starts in exact mode (the same expectation as in
+        // enqueue, for a normalised flux).  Without this the block of the longest periods came out a fifth late (PERF_LOG round 4).
+        if (!resident && po.fast_slab != 0 && po.exact_prefix != 1 && sigma > 0) {
+            const double eps = fast_mode_eps(M, 1.0 + 5.0 * sigma);
+            const double band_max = po.band_max >= 0 ? po.band_max : kBandMax;
+            std::vector<double> band;
+            band_prefix_for(widths, sigma, params->transit_depth_min, eps, band, M);
             for (int64_t p = 0; p < n_periods; ++p) {
                 const double lambda = band[(size_t)prow[(size_t)p].k_hi] - band[(size_t)prow[(size_t)p].k_lo];
-                if (lambda > 0.1) continue;                                       // starts in exact mode
+                if (lambda > band_max) continue;                                  // starts in exact mode
                 time_per_period[p] = (time_per_period[p] - 3.5 * (double)n) * (1.0 + 0.65 * std::min(1.0, lambda));
             }
         }

@@ -44,16 +44,14 @@ def block_makespan(times, slots):
     if n == 0:
         return 0.0
     c = numpy.sort(numpy.asarray(times, dtype=numpy.float64))[::-1]
-    rounds = -(-n // slots)
-    full = (rounds - 1) * slots
-    value = float(numpy.sum(c[:full]) / slots + c[full])
-    # No schedule beats its longest period, and one more (cheap) period never shortens a block: without these two the
-    # model is not monotone in the block length where a round boundary is crossed ([10, 1, 1, 1] on four slots takes
-    # 10, and [10, 1, 1, 1, 0.1] does not take 3.35) -- and the bisection of partition_by_makespan relies on monotony.
-    value = max(value, float(c[0]))
-    if full >= slots and n > full:      # the block as it was when its last round was still empty
-        value = max(value, float(numpy.sum(c[:full - slots]) / slots + c[full - slots]))
-    return value
+    # The block as it stood at EVERY round boundary r: the r full rounds before it share their work evenly, the round's
+    # most expensive period runs on top -- and the block takes the largest of these.  The top-k sum and the k-th largest
+    # of a multiset never shrink when an element is added, so the value is monotone in the block (the bisection of
+    # partition_by_makespan relies on that; a formula for the last boundary alone is not: five periods of 10 and eight
+    # of 0 on four slots take 20, not the 12.5 of "three full rounds + 0").  r = 0 says no schedule beats its longest period.
+    starts = numpy.arange(0, n, slots)
+    before = numpy.concatenate([[0.0], numpy.cumsum(c)])[starts]
+    return float(numpy.max(before / slots + c[starts]))
 
 
 def partition_by_makespan(times, n_ranks, slots):
@@ -143,17 +141,29 @@ class ShardedSearch(object):
         self.taps = None     # expected template taps per period
         self.times = None    # modelled search time per period: what the boundaries balance
 
-    def plan(self, t, periods, table, params, y=None):
+    def plan(self, t, periods, table, params, y=None, options=None, allgather_digests=None):
         """Block boundaries by cumulative MODELLED TIME (tls_period_costs): per period a fixed part (fold, sort,
         prefix sum), a part per trial cell and a part per expected template tap.  Balancing trial cells alone
         leaves the blocks of short periods -- many cheap periods, each with the full fixed cost -- 1.2x (90 d),
         2.1x (TESS) and 4x (Kepler 4 yr) slower than the mean at 8 ranks (profiles/r03_cost_model_fit.json).
-        y (the flux) only sets the noise level the tap estimate assumes; every rank must pass the same."""
+        y (the flux) only sets the noise level the tap estimate assumes; every rank must pass the same.
+        options: the switches of the searching context (Context.get_options()): the model prices the kernel variant
+        and prefix-sum mode the search will run.  allgather_digests: a callable (32-byte digest) -> list of every
+        rank's digest; when given, the ranks compare the boundaries they derived before anything is searched (every
+        rank derives them itself from floating-point model times: ranks that disagreed -- different devices visible,
+        different switches -- would assemble mismatched blocks without any error)."""
         sigma = 0.0 if y is None else float(numpy.std(numpy.asarray(y, dtype=numpy.float64)))
-        self.costs, self.taps, self.times, self.slots = _lib.period_costs(t, periods, table, params, sigma, with_slots=True)
+        self.costs, self.taps, self.times, self.slots = _lib.period_costs(t, periods, table, params, sigma, with_slots=True,
+                                                                          options=options)
         # (a rank's GPU searches `slots` periods side by side: what is balanced is the time of its LAST round's end)
         self.bounds = partition_by_makespan(self.times, self.n_ranks, self.slots)
         self.count_per_rank = max(1, int(numpy.max(numpy.diff(self.bounds))))
+        if allgather_digests is not None:
+            mine = bounds_digest(self.bounds)
+            theirs = [bytes(d) for d in allgather_digests(mine)]
+            if len(theirs) != self.n_ranks or any(d != mine for d in theirs):
+                raise RuntimeError("tls_amd: the ranks derived different period blocks (rank %d of %d): same inputs, "
+                                   "switches and device type on every rank?" % (self.rank, self.n_ranks))
         lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         return int(lo), int(hi)
 

@@ -16,8 +16,7 @@ for case in range(10):
     sel = inp["periods"][::max(1, len(inp["periods"]) // 2600)]
     out = {}
     for flag in ("0", "1"):
-        os.environ["TLS_X_STAGED"] = flag
-        os.environ["TLS_SPLIT"] = "0"
+        ctx.set_options(x_staged=flag, split=0)
         out[flag] = ctx.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
     info = ctx.plan_info()
     same_rows = numpy.array_equal(out["0"][1], out["1"][1])
