@@ -212,3 +212,45 @@ def test_power_at_tess_size_gpu_equals_power_with_oracle_search(oracle_lib, monk
                                       rtol=1e-9, atol=atol, err_msg=key)
     assert int(numpy.argmin(got.chi2)) == int(numpy.argmin(want.chi2))
     assert abs(got.period - 10.123) < 0.05
+
+
+@pytest.mark.parametrize("name,devices", [("k2_90d", [0, 0]), ("tess_27d", [0, 0]), ("tess_27d", [0, 0, 0])])
+def test_devices_list_shards_the_period_grid_bit_for_bit(name, devices):
+    """power(devices=[...]) / DeviceGroup (reference: the use_threads pool over periods, main.py:140-163): one context and
+    one host thread per listed device, period blocks by modelled time, the blocks' results brought together -- here two and
+    three contexts on the one GPU of the box (the host-copy collective; the RCCL branch of distinct devices is exercised
+    with stand-in contexts in test_device_group.py).  A period's result does not depend on the partition: chi2, row and
+    depth of the sharded search are the BITS of the one-context search, on the LDS-resident and on the HBM-slab path
+    (whose prefix-sum mode is decided per period from the light curve and the period alone)."""
+    from tls_amd import _lib, search as tsearch
+    t, f, kw = synthetic.config(name)
+    inp = synthetic.search_inputs(t, f, **kw)
+    one = _lib.Context(0)
+    want = one.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+    one.close()
+    group = tsearch.DeviceGroup(devices)
+    try:
+        got = group.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+        assert group.last_collective == "host_concatenate"
+        blocks = numpy.diff(group.last_blocks)
+        assert len(blocks) == len(devices) and blocks.sum() == len(inp["periods"]) and blocks.min() > 0
+        for a, b in zip(got, want[:3]):
+            numpy.testing.assert_array_equal(a, b)
+        assert int(numpy.argmin(got[0])) == int(numpy.argmin(want[0]))
+    finally:
+        group.close()
+
+
+def test_power_with_a_devices_list_returns_the_one_device_results():
+    """The drop-in call itself: every field of the results object of power(devices=[0, 0]) equals power()'s."""
+    t, f = synthetic.light_curve(30.0, 48, 2e-4, per=4.321, rp=0.05, a=12)
+    kw = dict(period_min=1.0, period_max=9.0, oversampling_factor=2, show_progress_bar=False, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = tls_amd.transitleastsquares(t, f, verbose=False).power(**kw)
+        sharded = tls_amd.transitleastsquares(t, f, verbose=False).power(devices=[0, 0], **kw)
+        single = tls_amd.transitleastsquares(t, f, verbose=False).power(devices=[0], **kw)
+    for other in (sharded, single):
+        assert list(other.keys()) == list(plain.keys())
+        for k in plain.keys():
+            numpy.testing.assert_array_equal(numpy.asarray(other[k], dtype=float), numpy.asarray(plain[k], dtype=float), err_msg=k)

@@ -94,14 +94,24 @@ class transitleastsquares(object):
         # back ordered like the ascending period grid (main.py:190-196)
         test_statistic_periods = numpy.sort(numpy.asarray(periods, dtype=numpy.float64))
         table = TemplateTable(lc_cache_overview, lc_arr)
+        # devices=[...]: the period grid sharded over several GPUs of this process (tls_amd.search.DeviceGroup: one context
+        # and one host thread per device, blocks by modelled time, one RCCL all-gather) -- the counterpart of the
+        # reference's use_threads pool over periods (main.py:140-163, validate.py:81)
+        group = None
+        if kwargs.get("devices") is not None and len(kwargs["devices"]) > 1:
+            group = _search.device_group(kwargs["devices"])
+        elif kwargs.get("devices") is not None and kwargs.get("device") is None and kwargs.get("context") is None:
+            kwargs = dict(kwargs, device=int(list(kwargs["devices"])[0]))
         chi2, test_statistic_rows, test_statistic_depths = _search.search_periods(
             self.t, self.y, self.dy, test_statistic_periods, table,
             transit_depth_min=self.transit_depth_min,
             R_star_min=self.R_star_min, R_star_max=self.R_star_max,
             M_star_min=self.M_star_min, M_star_max=self.M_star_max,
             T0_fit_margin=self.T0_fit_margin,
-            context=kwargs.get("context"), device=kwargs.get("device"),
+            context=kwargs.get("context"), device=kwargs.get("device"), devices=group,
             verbose=self.verbose)
+        if group is not None:   # (what follows -- spectra, final T0 fit -- runs on the group's first device)
+            kwargs = dict(kwargs, context=group.contexts[0])
 
         idx_best = numpy.argmin(chi2)
         best_row = test_statistic_rows[idx_best]

@@ -68,4 +68,4 @@ VALID_PARAMETERS = (
     "transit_template", "verbose",
 )
 # extensions of this build; never collide with the reference's names
-EXTRA_PARAMETERS = ("device", "context")
+EXTRA_PARAMETERS = ("device", "context", "devices")
