@@ -1026,9 +1026,11 @@ def test_commensurate_periods_cost_no_more_than_their_neighbours(gpu, oracle_lib
     median = numpy.median(cycles[~special])
     worst = cycles[special].max()
     if n > 10000:
-        # series in HBM: such a period leaves the two-level sort for the general bucket sort through global memory
-        # (~6x an ordinary period whatever the pile-up); the pile-up itself must not add to that
-        assert worst < 5e-3 * 2.4e9            # shader cycles at <= 2.4 GHz: below 5 ms (it was 29 ms)
+        # series in HBM: the piled-up bins of the two-level sort go to the workgroup's bitonic network in the staging area of
+        # its first pass (round 5; before, such a period left for the general bucket sort through global memory: 2.4 ms,
+        # 12x the median of fast-mode periods).  Measured now: 2.2-4.5 M cycles for a series that is ALL piles (48-133 phase
+        # values: every point goes through the network, which is bound by the LDS pipe), 4-8x an ordinary period.
+        assert worst < 4e-3 * 2.4e9            # shader cycles at <= 2.4 GHz: below 4 ms (round 1: 29 ms)
         assert worst <= 10.0 * median, (worst, median, periods[special][numpy.argmax(cycles[special])])
     else:
         assert worst <= 3.0 * median, (worst, median, periods[special][numpy.argmax(cycles[special])])

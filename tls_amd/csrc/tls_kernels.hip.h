@@ -2504,6 +2504,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int B = sort2_bins(n);
     const double B_d = (double)B;
+    constexpr int kPerStage = kSort2Chunk / 1024;   // points per thread and pass-1 round (as kPer below)
     unsigned int* g_start = reinterpret_cast<unsigned int*>(lds);   // [B+1] first output slot of every bin
     unsigned int* g_cur = g_start + (B + 1);                        // [B+1] pass 1: next free slot of the bin
     unsigned int* l_cnt = g_cur + (B + 1);                          // [B+1] pass 1: points of the bin in this chunk
@@ -2545,7 +2546,14 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
         if (lane == 0) g_cur[B] = biggest;   // parked here for everybody to read
     }
     __syncthreads();
-    if (g_cur[B] > (unsigned int)kSort2BinCap) { __syncthreads(); return false; }
+    // A bin beyond a wavefront's window (phases piled up: a period commensurate with the cadence folds a regularly sampled
+    // series onto P / cadence phase values) is skipped by pass 2 and sorted by the WORKGROUP afterwards, in the staging
+    // area of pass 1: exact phase and index of every point side by side, a bitonic network on (phase, index) -- the order
+    // of the stable sort --, several bins per run of the network.  Only a bin beyond the staging area itself (a period of
+    // fewer than ~9 cadences on a Kepler-size series) still sends the period to the general sort.
+    const unsigned int biggest_bin = g_cur[B];
+    const int stage_pts = (int)((kPerStage * nt < kSort2Chunk ? kPerStage * nt : kSort2Chunk) * 10LL / 12);   // 12 B a point
+    if (biggest_bin > (unsigned int)stage_pts) { __syncthreads(); return false; }
     pc.mark(0);
 
     // ---- pass 1: partition, one chunk of points per round ---------------------------------------
@@ -2639,7 +2647,8 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
         for (int b0 = 0; b0 < B; b0 += nw) {
             const int b = b0 + wave;
             const unsigned int first = (unsigned int)__builtin_amdgcn_readfirstlane((int)(b < B ? g_start[b] : 0u));
-            const int m = __builtin_amdgcn_readfirstlane(b < B ? (int)(g_start[b + 1] - first) : 0);
+            const int m_all = __builtin_amdgcn_readfirstlane(b < B ? (int)(g_start[b + 1] - first) : 0);
+            const int m = m_all > kSort2BinCap ? 0 : m_all;   // (a piled-up bin is left to the workgroup: below)
             const int e_used = (m + kWave - 1) / kWave;   // slots per lane that hold a point in some lane
             const int bn = b + nw;
             const unsigned int first_n = (unsigned int)__builtin_amdgcn_readfirstlane((int)(bn < B ? g_start[bn] : 0u));
@@ -2779,6 +2788,112 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
         }
     }
     __syncthreads();
+    if (biggest_bin > (unsigned int)kSort2BinCap) {
+        // ---- the piled-up bins, by the whole workgroup ------------------------------------------------
+        unsigned int* big_list = l_cnt;   // [0] count, then the bins (pass 1's chunk counters are idle; l_start follows them: 2 (B + 1) words)
+        if (tid == 0) big_list[0] = 0u;
+        __syncthreads();
+        for (int b = tid; b < B; b += nt)
+            if (g_start[b + 1] - g_start[b] > (unsigned int)kSort2BinCap) big_list[1 + atomicAdd(&big_list[0], 1u)] = (unsigned int)b;
+        __syncthreads();
+        const int n_big = (int)big_list[0];
+        double* stage_key = reinterpret_cast<double*>(area);
+        unsigned int* stage_idx = reinterpret_cast<unsigned int*>(stage_key + stage_pts);
+        // A run of the network takes bins of (nearly) one size: every bin gets a slot of 2^lg entries, the entries behind
+        // its last point are +infinity -- so an exchange needs no table and no bounds test, the slot of entry x is x >> lg.
+        // (The first version kept offsets and lengths of up to 16 bins in per-thread arrays: indexed at run time they
+        // live in scratch memory, two HBM round trips per exchange -- 2.2 ms for a period of 66.5 cadences.)
+        int q0 = 0;
+        while (q0 < n_big) {
+            int lg = 0;
+            {
+                const int b = (int)big_list[1 + q0];
+                const int m = (int)(g_start[b + 1] - g_start[b]);
+                while ((1 << lg) < m) ++lg;
+            }
+            // as many of the following bins as fit a slot of this size and the staging area
+            int count = 0;
+            while (q0 + count < n_big && ((count + 1) << lg) <= stage_pts) {
+                const int b = (int)big_list[1 + q0 + count];
+                if ((int)(g_start[b + 1] - g_start[b]) > (1 << lg)) break;
+                ++count;
+            }
+            if (count == 0) count = 1;   // (a bin whose slot exceeds the area but whose points fit: biggest_bin <= stage_pts; it runs alone, unpadded tail tested below)
+            const int slot_len = 1 << lg, total = count << lg;
+            const bool padded = total <= stage_pts;
+            for (int x = tid; x < (padded ? total : stage_pts); x += nt) {
+                const int g = x >> lg, j = x & (slot_len - 1);
+                const int b = (int)big_list[1 + q0 + g];
+                const unsigned int first = g_start[b], m = g_start[b + 1] - first;
+                unsigned int i = 0xffffffffu;
+                double key = INFINITY;
+                if ((unsigned int)j < m) { i = (unsigned int)g_rec[first + j]; key = fold_phase(t[i], period, epoch); }
+                stage_idx[x] = i; stage_key[x] = key;
+            }
+            __syncthreads();   // (also: every record of the run has been read -- f_out may be g_rec)
+            const int limit = padded ? total : stage_pts;   // entries that exist
+            auto exchange4 = [&](int x0, int x1, int x2, int x3, int d0, int d1, int d2, int d3, int valid) {
+                // four independent compare-exchanges (x, x + d): all reads first, then the stores
+                const int xs[4] = {x0, x1, x2, x3}, ds[4] = {d0, d1, d2, d3};
+                double kx[4], ky[4]; unsigned int ix[4], iy[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool on = e < valid && xs[e] + ds[e] < limit;
+                    kx[e] = on ? stage_key[xs[e]] : 0.0; ky[e] = on ? stage_key[xs[e] + ds[e]] : 1.0;
+                    ix[e] = on ? stage_idx[xs[e]] : 0u; iy[e] = on ? stage_idx[xs[e] + ds[e]] : 1u;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (kx[e] > ky[e] || (kx[e] == ky[e] && ix[e] > iy[e])) {
+                        stage_key[xs[e]] = ky[e]; stage_key[xs[e] + ds[e]] = kx[e];
+                        stage_idx[xs[e]] = iy[e]; stage_idx[xs[e] + ds[e]] = ix[e];
+                    }
+                }
+            };
+            const int pairs = total >> 1;
+            for (int lk = 1; lk <= lg; ++lk) {
+                const int lh = lk - 1;
+                for (int i0 = tid; i0 < pairs; i0 += 4 * nt) {
+                    int xs[4], ds[4], valid = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = i0 + e * nt;
+                        const int blk = i >> lh, pos = i & ((1 << lh) - 1);
+                        xs[e] = (blk << lk) + pos; ds[e] = (1 << lk) - 1 - 2 * pos;
+                        if (i < pairs) valid = e + 1;
+                    }
+                    exchange4(xs[0], xs[1], xs[2], xs[3], ds[0], ds[1], ds[2], ds[3], valid);
+                }
+                lds_barrier();
+                for (int lj = lk - 2; lj >= 0; --lj) {
+                    for (int i0 = tid; i0 < pairs; i0 += 4 * nt) {
+                        int xs[4], valid = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = i0 + e * nt;
+                            xs[e] = ((i >> lj) << (lj + 1)) + (i & ((1 << lj) - 1));
+                            if (i < pairs) valid = e + 1;
+                        }
+                        exchange4(xs[0], xs[1], xs[2], xs[3], 1 << lj, 1 << lj, 1 << lj, 1 << lj, valid);
+                    }
+                    lds_barrier();
+                }
+            }
+            for (int x = tid; x < limit; x += nt) {
+                const int g = x >> lg, j = x & (slot_len - 1);
+                const int b = (int)big_list[1 + q0 + g];
+                const unsigned int first = g_start[b], m = g_start[b + 1] - first;
+                if ((unsigned int)j < m) {
+                    const unsigned int i = stage_idx[x];
+                    if (perm) perm[first + j] = i;
+                    if (y_gather) f_out[first + j] = y_gather[i];
+                    if constexpr (HAS_W) { if (y_gather) w_out_g[first + j] = w_gather[i]; }
+                }
+            }
+            __syncthreads();
+            q0 += count;
+        }
+    }
     pc.mark(3);
     return true;
 }
