@@ -82,11 +82,20 @@
     const double dmin = ap->depth_min;
 
     bool retry_exact = false;   // the period just searched in fast mode left a window undecided: again, in exact mode
+    // Series in the HBM slab, one light curve, plain variant: windows inside the undecided band are noted (band_window) and
+    // decided after the attempt on the period's exact prefix sum -- the period loop is entered a second time for the prefix
+    // pass only (`resolve_band`), the lanes' leads and counts of the attempt are kept
+    constexpr bool BAND = !RESIDENT && ROLE == kRoleAll && !WITH_PRUNING;
+    [[maybe_unused]] bool resolve_band = false;
+    [[maybe_unused]] Lead kept_lead = no_lead();
+    [[maybe_unused]] unsigned int kept_eval = 0;
+    [[maybe_unused]] unsigned long long kept_steps = 0, kept_issued = 0;
+    [[maybe_unused]] BandEntry* const band_list = reinterpret_cast<BandEntry*>(chunk_list + ap->list_cap);   // (the pruning variant's second list: idle here)
     int work = 0;
     for (;;) {
         // ---- fetch the next period from the queue ----------------------------------
         if (!retry_exact) {
-            if (tid == 0) { s_work[0] = (int)atomicAdd(ap->queue + (ROLE == kRoleSearch ? 2 : 0), 1u); s_work[1] = 0; s_work[2] = 0; }
+            if (tid == 0) { s_work[0] = (int)atomicAdd(ap->queue + (ROLE == kRoleSearch ? 2 : 0), 1u); s_work[1] = 0; s_work[2] = 0; s_work[4] = 0; }
             __syncthreads();
             work = __builtin_amdgcn_readfirstlane(s_work[0]);
             __syncthreads();
@@ -228,6 +237,13 @@
         curve_exact = false;
         DepthRule rule;
         rule.dmin = ap->depth_min; rule.eps = exact_mode ? 1e-15 : ap->eps_fast; rule.exact_mode = exact_mode;
+        rule.band_count = nullptr; rule.band_list = nullptr;
+        if constexpr (BAND) {
+            // (16 bytes an entry in the idle list region: list_cap words hold list_cap / 4 of them)
+            if (!exact_mode && ap->list_cap >= 4 * kBandCap) {
+                rule.band_count = reinterpret_cast<unsigned int*>(&s_work[4]); rule.band_list = band_list;
+            }
+        }
         // (the estimate's mean depth is off by ~1e-16 absolute: negligible against transit_depth_min = 1e-5, the whole
         // story for a transit_depth_min near zero -- then every cell takes the exact comparison)
         rule.reach = (rule.dmin - rule.eps > 4e-15) ? fmin(fmax(1e-9, 4e-15 / (rule.dmin - rule.eps)), 1.0) : 1.0;
@@ -290,6 +306,7 @@
         TLS_CHECK(*ap, 0 <= k_lo && k_lo <= k_x && k_x <= k_hi && k_hi <= ap->n_widths, kChkWorkItem);
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
         if (tid == 0) s_work[3] = 0;   // ticket counter of the strided rows (phase 3a), published the same way
+        if constexpr (BAND) { if (tid == 0 && !resolve_band) s_work[4] = 0; }   // the noted band windows of this light curve's attempt
         if constexpr (ROLE != kRoleSearch) {
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup -- or, in fast mode,
         // e = 1 - f and its plain prefix sum X in one pass (depth_pass explains why that decides the same cells)
@@ -475,7 +492,15 @@
         const int tile_len = RESIDENT ? (1 << 30) : (tile_len_p > 0 ? tile_len_p : ap->tile_len);
         // (search role: the one tile of this work item)
         const int p_first = ROLE == kRoleSearch ? item_tile * tile_len : 0;
-        const int p_end = ROLE == kRoleSearch ? p_first + 1 : M;
+        // (second pass over a period whose noted band windows wait for the exact prefix sum: no tile is searched again)
+        [[maybe_unused]] bool resolving = false;
+        if constexpr (BAND) {
+            if (resolve_band) {
+                resolving = true; resolve_band = false;
+                lead = kept_lead; n_eval = kept_eval; n_steps = kept_steps; n_issued = kept_issued;
+            }
+        }
+        const int p_end = ROLE == kRoleSearch ? p_first + 1 : (resolving ? 0 : M);
         for (int p_lo = p_first; p_lo < p_end; p_lo += tile_len) {
         const int p_hi = p_lo + tile_len;
         const double* e_base = regA;   // e_base[b] = sample b of e (or e*w)
@@ -605,7 +630,22 @@
                             } else {         // fast mode: no branch per row; a chunk inside the band is noted for the tile
                                 const double m_fast = dC[j] * inv[j];
                                 mask = ballot64(m_fast > thr_hi);
-                                band_mask |= ballot64(m_fast >= thr_lo) & ~mask;   // (two compares, the rest on the scalar unit)
+                                const unsigned long long band_j = ballot64(m_fast >= thr_lo) & ~mask & valid_mask;   // (two compares, the rest on the scalar unit)
+                                if (band_j != 0ull) {   // (a scalar branch, rarely taken)
+                                    if (rule.band_count != nullptr) {
+                                        // the chunk's deepest window is inside the band: its windows there are noted one by one
+                                        // (the others lie below it: decided)
+                                        if ((band_j >> lane) & 1ull) {
+#pragma unroll
+                                            for (int r = 0; r < kR; ++r) {
+                                                const double dXr = c_hi[j][r] - c_lo[r];
+                                                if (dXr * inv[j] >= thr_lo) band_window(rule, k + j, u0 + r, dXr, undecided);
+                                            }
+                                        }
+                                    } else {
+                                        band_mask |= band_j;
+                                    }
+                                }
                             }
                             mask &= valid_mask;
                             if (n_dense <= kWave) {   // lane (row) of row_mask := mask
@@ -691,7 +731,13 @@
                     } else {
                         const double m_fast = dC * inv_d;
                         live = m_fast > thr_hi;
-                        undecided |= !live && m_fast >= thr_lo && unit < unit_hi;
+                        if (!live && m_fast >= thr_lo && unit < unit_hi) {
+#pragma unroll
+                            for (int r = 0; r < kR; ++r) {
+                                const double dXr = c_hi[r] - c_lo[r];
+                                if (dXr * inv_d >= thr_lo) band_window(rule, k, (uc * kR + r) * xth, dXr, undecided);
+                            }
+                        }
                     }
                     live = live && unit < unit_hi;
                     const unsigned long long mask = ballot64(live);
@@ -709,7 +755,9 @@
                         double dC;
                         if (oversize) dC = regB[i + d] - regB[i];
                         else dC = c_base[i + d] - c_base[i];
-                        live = depth_pass(dC, inv_d, (double)d, dmin, rule.eps, exact_mode, undecided);
+                        bool und_w = false;
+                        live = depth_pass(dC, inv_d, (double)d, dmin, rule.eps, exact_mode, und_w);
+                        if (und_w) band_window(rule, k, i, dC, undecided);
                     }
                     const unsigned long long mask = ballot64(live);
                     if (live) list[n_listed + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
@@ -1082,7 +1130,9 @@
                     if (idx < n_tail * kR) {
                         const int i = u * xth;
                         const double dX = c_base[i + d] - c_base[i];   // past the grid: sentinel
-                        pass = depth_pass(dX, inv_d, dd, dmin, rule.eps, exact_mode, undecided);
+                        bool und_w = false;
+                        pass = depth_pass(dX, inv_d, dd, dmin, rule.eps, exact_mode, und_w);
+                        if (und_w) band_window(rule, k, i, dX, undecided);
                         if (bound_row && pass) {
                             if ((RESIDENT || STAGE_C) && screened_row)
                                 pass = (double)window_bound(c_base, i, d, dd, inv_d, ov, widths_c[k].sum_q2, screens_c + k, P2,
@@ -1323,6 +1373,46 @@
         }
         pc.mark(7);
         }  // position tiles
+        if constexpr (BAND) {
+            if (resolving) {
+                // The noted windows, one wavefront each: decided by the reference's expression on X = k - numpy.cumsum (the
+                // slab's X region, just written by the exact prefix pass); a window that passes is evaluated -- lanes over the
+                // template taps, samples from the slab with the patch as an index mapping -- and meets lane 0's lead with
+                // the window sum of the plain scan it was noted with (every cell of the period is valued on the same X).
+                const int n_band = __builtin_amdgcn_readfirstlane(s_work[4]);
+                for (int e0 = wave; e0 < n_band; e0 += nw) {
+                    const int k = __builtin_amdgcn_readfirstlane(band_list[e0].k);
+                    const int i = __builtin_amdgcn_readfirstlane(band_list[e0].i);
+                    const double dX_noted = band_list[e0].dX;
+                    const int d = widths_c[k].width, L = widths_c[k].q_len, q_offset = widths_c[k].q_offset;
+                    const double overshoot = widths_c[k].overshoot, sum_q2 = widths_c[k].sum_q2, inv_d = widths_c[k].inv_d;
+                    const double dd = (double)d;
+                    const double dX_exact = regB[i + d] - regB[i];
+                    if (!((1.0 - (dd - dX_exact) / dd) > dmin)) continue;   // core.py:58 on the reference's bits (uniform branch)
+                    const double* qg = ap->q + q_offset;
+                    [[maybe_unused]] const double* q2g = UNIFORM_W ? nullptr : ap->q2 + q_offset;
+                    double Bs = 0.0, As = 0.0;
+                    for (int tt = lane; tt < L; tt += kWave) {
+                        const int pp = i + tt, src = pp < n ? pp : pp - n;
+                        double ev = 1.0 - regA[src];
+                        if constexpr (!UNIFORM_W) { const double ww = regW[src]; As = fma(q2g[tt], ww, As); ev *= ww; }
+                        Bs = fma(qg[tt], ev, Bs);
+                    }
+#pragma unroll
+                    for (int delta = kWave / 2; delta > 0; delta >>= 1) {
+                        Bs += __shfl_down(Bs, delta, kWave);
+                        if constexpr (!UNIFORM_W) As += __shfl_down(As, delta, kWave);
+                    }
+                    if (lane == 0) {
+                        bool und_none = false;
+                        consider<UNIFORM_W, true, true>(lead, 0.0, dX_noted, i, inv_d, dd, rule, overshoot, UNIFORM_W ? sum_q2 : As, Bs, k, n_eval,
+                                                        und_none, widths_c, regB);
+                        if constexpr (COUNTING) n_steps += (unsigned long long)L;
+                    }
+                }
+                if (ap->phase_cycles && tid == 0) atomicAdd(&ap->phase_cycles[38], (unsigned long long)n_band);
+            }
+        }
         // fast mode: a window too close to transit_depth_min for the plain prefix sum to decide (depth_pass) sends the
         // whole period through exact mode; nothing of this attempt is written or counted
         // (an LDS flag, not __syncthreads_or: the library routine brings static LDS of its own, and the slab variant's
@@ -1339,6 +1429,23 @@
         const int any_undecided = __builtin_amdgcn_readfirstlane(s_work[flag_slot]);
         if (tid == 0) s_work[3 - flag_slot] = 0;   // the next attempt's flag: nobody touches it before several barriers from now
         flag_slot = 3 - flag_slot;
+        if constexpr (BAND) {
+            // noted band windows (and nothing that voids the attempt): the period goes through the exact prefix pass and the
+            // resolution above; more of them than the list holds: a second search in exact mode, as without the list
+            if (rule.band_count != nullptr && any_undecided == 0) {
+                const int n_band = __builtin_amdgcn_readfirstlane(s_work[4]);
+                if (n_band > 0) {
+                    if (n_band <= kBandCap) {
+                        resolve_band = true;
+                        kept_lead = lead; kept_eval = n_eval; kept_steps = n_steps; kept_issued = n_issued;
+                    }
+                    if (ap->phase_cycles && tid == 0) atomicAdd(&ap->phase_cycles[37], 1ull);
+                    if (ap->n_curves > 1) { curve_exact = true; --curve; continue; }   // this curve's prefix pass; the others are not touched
+                    retry_exact = true;
+                    break;
+                }
+            }
+        }
         if (any_undecided != 0 && !exact_mode) {
             if (ap->phase_cycles && tid == 0) atomicAdd(&ap->phase_cycles[37], 1ull);
             if (ap->n_curves > 1) { curve_exact = true; --curve; continue; }   // this curve again; the others are not touched
