@@ -539,7 +539,11 @@ double flux_scatter(const double* y, int64_t n) {
 // cannot decide a window -- 1.25 x the bound 2^-53 c_max on |dX/d - mean_reference| (c_max = (n + W) max|flux| bounds the
 // reference's running sum), plus 1e-14 for what the bound leaves out (the plain scan's own rounding, <= ~20 * 2^-53 *
 // max|X| / d, and the reference's division; rounds 3 and early 4 shipped 2 x: twice the second attempts for no safety).
-constexpr double kBandMax = 0.1;   // (Kepler full grid, same box: 0.35 -> 244 ms, 0.1 -> 241, 0.01 -> 240, never -> 249)
+// (round 4, when a band hit cost a second search of the period -- Kepler full grid, same box: 0.35 -> 244 ms, 0.1 -> 241,
+// 0.01 -> 240, never -> 249.  Round 5: a hit costs one exact prefix pass (band_window in tls_kernels.hip.h) -- every 16th
+// Kepler period: 0 (all exact) 16.97 ms, 0.1 14.22, 1 14.02, 10 14.04, never 14.02; TESS 3.01 / 2.72 / 2.72 / 2.72 / 2.73.)
+constexpr double kBandMax = 1.0;
+constexpr double kBandHitCost = 0.15;   // of a period: the exact prefix pass and the few windows it decides
 double fast_mode_eps(int64_t M, double y_abs_max) {
     return 1.25 * (1.1102230246251565e-16 * ((double)M * y_abs_max)) + 1e-14;
 }
@@ -1111,8 +1115,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             }
         }
         // Fast prefix-sum mode: a period whose windows are likely to meet the undecided band pays a second attempt
-        // (0.65 of itself); among periods of similar cost the likelier ones start first, so that the second attempts
-        // fall into the body of the launch and not into its last round.  (Only the order: which mode a period takes
+        // pass (kBandHitCost of itself); among periods of similar cost the likelier ones start first, so that the extra
+        // passes fall into the body of the launch and not into its last round.  (Only the order: which mode a period takes
         // never depends on it.)  The expectation is band_prefix_for's, as in enqueue; the LDS-resident kernel has no
         // per-period expectation (every period starts in fast mode): the same weight orders its queue.
         if (flux_sigma > 0 && ctx->opt.exact_prefix != 1) {
@@ -1122,7 +1126,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             for (int64_t p = 0; p < n_periods; ++p) {
                 const double lambda = pre[(size_t)prow[(size_t)p].k_hi] - pre[(size_t)prow[(size_t)p].k_lo];
                 if (lambda > band_max) continue;                                   // (starts in exact mode: no second attempt)
-                queue_cost[(size_t)p] += (int64_t)(0.3 * std::min(1.0, lambda / std::max(band_max, 1e-300)) * (double)cost[(size_t)p]);
+                queue_cost[(size_t)p] += (int64_t)(kBandHitCost * std::min(1.0, lambda) * (double)cost[(size_t)p]);
             }
         }
         order_by_cost(queue_cost, order);
@@ -2193,7 +2197,7 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
             time_per_period[p] = a0 + aN * (double)n + b * (double)cells_per_period[p] + c * taps_per_period[p];
         // Series in the HBM slab: the coefficients are exact-mode measurements.  The search runs fast mode (enqueue; whatever
         // the number of periods or ranks: a period's mode depends on the light curve and the period alone): the plain prefix
-        // sum saves ~3.5 cycles per point, a period pays a second attempt (0.65 of itself) with the probability that one of its
+        // sum saves ~3.5 cycles per point, a period pays an exact prefix pass (kBandHitCost of itself) with the probability that one of its
         // windows hits the undecided band, and a period that expects to hit it starts in exact mode (the same expectation as in
         // enqueue, for a normalised flux).  Without this the block of the longest periods came out a fifth late (PERF_LOG round 4).
         if (!resident && po.fast_slab != 0 && po.exact_prefix != 1 && sigma > 0) {
@@ -2204,7 +2208,7 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
             for (int64_t p = 0; p < n_periods; ++p) {
                 const double lambda = band[(size_t)prow[(size_t)p].k_hi] - band[(size_t)prow[(size_t)p].k_lo];
                 if (lambda > band_max) continue;                                  // starts in exact mode
-                time_per_period[p] = (time_per_period[p] - 3.5 * (double)n) * (1.0 + 0.65 * std::min(1.0, lambda));
+                time_per_period[p] = (time_per_period[p] - 3.5 * (double)n) * (1.0 + kBandHitCost * std::min(1.0, lambda));
             }
         }
         // periods searched side by side on one GPU (one workgroup each): its CUs (256 on an MI355X; the first visible
