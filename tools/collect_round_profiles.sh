@@ -33,7 +33,9 @@ t = json.load(open("gpurun_out/prof_tess_27d_%s.json" % tag)); t["commit"] = com
 json.dump(t, open("profiles/%s_tess_hbm_traffic.json" % tag, "w"))
 doc = json.load(open("profiles/hbm_traffic.json"))
 recs = [r for r in doc["records"] if r.get("config") != "tess_27d"]
-recs.append({"config": "tess_27d", "n_periods": 2459, "commit": commit,
+import sys; sys.path.insert(0, ".")
+import bench as _bench
+recs.append({"config": "tess_27d", "n_periods": 2459, "commit": commit, "kernel_sources": _bench.kernel_sources_digest(),
              "source": "FETCH_SIZE x2 + WRITE_SIZE, profiles/%s_tess_hbm_traffic.json" % tag,
              "fetch_size_kib_raw": t["fetch_kib"], "write_size_kib_raw": t["write_kib"],
              "bytes_per_launch": t["bytes_per_launch"], "kernel_avg_ms": t["kernel_ms"]})

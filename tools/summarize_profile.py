@@ -55,9 +55,12 @@ def update_traffic_record(rec):
 
 
 commit = os.environ.get("TLS_COMMIT", "unknown")
+sys.path.insert(0, root)
+import bench as _bench   # kernel_sources_digest: which sources the counters were taken on (bench.py compares)
+sources = _bench.kernel_sources_digest()
 if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
     fetch_kib, write_kib = means["FETCH_SIZE"]["mean"], means["WRITE_SIZE"]["mean"]
-    rec = {"config": "k2_90d", "n_periods": 9679, "commit": commit,
+    rec = {"config": "k2_90d", "n_periods": 9679, "commit": commit, "kernel_sources": sources,
            "source": "FETCH_SIZE x2 + WRITE_SIZE, profiles/%s_k2_90d_pmc_summary.csv" % tag,
            "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
            "bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0}
@@ -68,7 +71,7 @@ if os.path.exists(kep):
     k = json.load(open(kep))
     for variant in k:
         rec = {"config": "kepler_4yr" if variant["name"] == "default" else "kepler_4yr/" + variant["name"], "n_periods": variant["n_periods"],
-               "commit": commit, "source": "FETCH_SIZE x2 + WRITE_SIZE, profiles/%s_kepler_hbm_traffic.json (every 64th period)" % tag,
+               "commit": commit, "kernel_sources": sources, "source": "FETCH_SIZE x2 + WRITE_SIZE, profiles/%s_kepler_hbm_traffic.json (every 64th period)" % tag,
                "fetch_size_kib_raw": variant["fetch_kib"], "write_size_kib_raw": variant["write_kib"],
                "bytes_per_launch": (2.0 * variant["fetch_kib"] + variant["write_kib"]) * 1024.0, "kernel_avg_ms": variant["kernel_ms"]}
         update_traffic_record(rec)
