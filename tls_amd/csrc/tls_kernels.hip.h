@@ -3441,23 +3441,56 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a) {
     IdxT* idx_tmp = RESIDENT ? reinterpret_cast<IdxT*>(cnt + a.nb) : reinterpret_cast<IdxT*>(regB);
     IdxT* perm = idx_tmp + n;
     PhaseClock pc; pc.start(nullptr);
+    // The epochs of one fit share period and time stamps: fold(t, P, T0) = frac((t - T0) / P) for another T0 shifts every
+    // phase by the same amount, so the stable order of one epoch is -- rounding aside -- a ROTATION of the order of any
+    // other.  A workgroup therefore sorts once, for the first epoch it takes (LDS-resident series), and keeps that order
+    // (`perm`) and the flux in that order (`regA`); for every further epoch it folds each point and its successor in the
+    // kept order and counts the places where (phase, index) DEcreases around the cycle: exactly one such place means the
+    // kept order, started behind it, IS numpy's stable order of this epoch (the keys are distinct, so the sorted order is
+    // unique) -- bit for bit what a sort of its own would give; anything else (two phases that round the other way
+    // round under this epoch, ties that reorder) sends the epoch through the sort, whose order is kept from then on.
+    // stats.py:178-201 sorts N points for each of up to N epochs; here an epoch costs two folds per point.
+    bool have_base = false;
     for (;;) {
-        if (tid == 0) s_work[0] = (int)atomicAdd(a.queue, 1u);
+        if (tid == 0) { s_work[0] = (int)atomicAdd(a.queue, 1u); s_work[1] = 0; s_work[2] = 0; }
         __syncthreads();
         const int work = s_work[0];
         __syncthreads();
         if (work >= a.n_epochs) break;
-        // (a trial epoch does not change how the phases pile up: the period does -- same remedy as in the search)
-        fold_and_sort<IdxT>(a.t, n, a.period, a.epochs[work], regA, cnt, a.nb, idx_tmp, perm, wsum, pc,
-                            reinterpret_cast<unsigned int*>(wred), 2 * kMaxWaves);
-        for (int k = tid; k < n; k += nt) regA[k] = a.y[(int)perm[k]];   // phases are dead
-        __syncthreads();
+        const double epoch = a.epochs[work];
+        int start = 0;          // sorted position k holds the kept order's entry (k + start) mod n
+        bool rotated = false;
+        if constexpr (RESIDENT) {
+            if (have_base) {
+                int descents = 0, where = 0;
+                for (int k = tid; k < n; k += nt) {
+                    const int kn = k + 1 < n ? k + 1 : 0;
+                    const int i0 = (int)perm[k], i1 = (int)perm[kn];
+                    const double p0 = fold_phase(a.t[i0], a.period, epoch), p1 = fold_phase(a.t[i1], a.period, epoch);
+                    if (p1 < p0 || (p1 == p0 && i1 < i0)) { ++descents; where = kn; }
+                }
+                if (descents) { atomicAdd(&s_work[1], descents); s_work[2] = where; }
+                __syncthreads();
+                rotated = s_work[1] == 1 || n < 2;
+                start = n < 2 ? 0 : s_work[2];
+                __syncthreads();
+            }
+        }
+        if (!rotated) {
+            // (a trial epoch does not change how the phases pile up: the period does -- same remedy as in the search)
+            fold_and_sort<IdxT>(a.t, n, a.period, epoch, regA, cnt, a.nb, idx_tmp, perm, wsum, pc,
+                                reinterpret_cast<unsigned int*>(wred), 2 * kMaxWaves);
+            for (int k = tid; k < n; k += nt) regA[k] = a.y[(int)perm[k]];   // phases are dead
+            __syncthreads();
+            have_base = RESIDENT;   // (series in HBM: the sort's scratch is shared with the order; every epoch sorts)
+            start = 0;
+        }
         // flux rolled once: F1[k] = F[(k - roll) mod n]; weights: F2[k] = F[(k - 2 roll) mod n]
         const int r1 = a.roll % n, r2 = (2 * a.roll) % n;
         double acc = 0.0;
         for (int k = tid; k < n; k += nt) {
-            int k1 = k - r1; if (k1 < 0) k1 += n;
-            int k2 = k - r2; if (k2 < 0) k2 += n;
+            int k1 = k - r1 + start; if (k1 < 0) k1 += n; if (k1 >= n) k1 -= n;
+            int k2 = k - r2 + start; if (k2 < 0) k2 += n; if (k2 >= n) k2 -= n;
             const double f1 = regA[k1], f2 = regA[k2];
             const double model = k < a.dur ? a.signal[k] : 1.0;
             const double dlt = f1 - model;
