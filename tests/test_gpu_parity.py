@@ -874,8 +874,16 @@ def test_pruning_kernel_is_exact(gpu, name, sigma, stride, monkeypatch):
     for min_live in ("0", "4000"):
         gpu.set_options(prune_min_live=min_live)
         pruned = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
-        for x, y in zip(plain[:3], pruned[:3]):
-            numpy.testing.assert_array_equal(x, y)
+        if gpu.plan_info()["resident"]:
+            for x, y in zip(plain[:3], pruned[:3]):
+                numpy.testing.assert_array_equal(x, y)
+        else:
+            # series in the HBM slab (the pruning variant only runs there when forced): the plain variant's fast mode forms
+            # its dot products on X with the difference taps (x_dot), the pruning variant on the samples -- the same cells,
+            # rows and winners, values that differ by the rounding of one against the other
+            numpy.testing.assert_array_equal(plain[1], pruned[1])
+            numpy.testing.assert_allclose(plain[0], pruned[0], rtol=1e-12, atol=0)
+            numpy.testing.assert_allclose(plain[2], pruned[2], rtol=0, atol=1e-14)
 
 
 @pytest.mark.parametrize("name,sigma,stride", [("k2_90d", None, 2), ("k2_90d", 100e-6, 3), ("k2_90d", 500e-6, 5),

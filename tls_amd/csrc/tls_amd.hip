@@ -76,7 +76,7 @@ struct View {
 // parameters and developer switches only replaces the flux (the search call of a survey, or of repeated power()
 // calls).  Compared byte for byte (memcmp runs at ~10 GB/s; a cfg2 key is 120 KB).
 struct PlanLayout {   // byte offsets of the plan arrays inside d_plan / h_stage (256-byte aligned)
-    size_t t = 0, y = 0, w = 0, periods = 0, order = 0, rows = 0, widths = 0, screens = 0, q = 0, q2 = 0, tile_prefix = 0, total = 0;
+    size_t t = 0, y = 0, w = 0, periods = 0, order = 0, rows = 0, widths = 0, screens = 0, q = 0, q2 = 0, g = 0, tile_prefix = 0, total = 0;
 };
 
 struct PlanKey {
@@ -133,7 +133,7 @@ struct tls_ctx {
     // ONE allocation holds every plan array (views below); it is filled from ONE pinned staging buffer by ONE
     // asynchronous copy, and tls_prepare does not wait for it
     DevBuf<unsigned char> d_plan;
-    View<double> d_t, d_y, d_w, d_periods, d_q, d_q2;
+    View<double> d_t, d_y, d_w, d_periods, d_q, d_q2, d_g;
     View<int> d_order;
     View<tlsdev::PeriodRows> d_rows;
     View<tlsdev::WidthEntry> d_widths;
@@ -392,7 +392,7 @@ int build_widths(tls_ctx* ctx, const tls_template* tmpl, const tls_params* param
             const int S = we.tiled ? (tlsdev::kR - 1) * we.xth : 0;
             we.screen_c = 2.0 * (1 + 1e-6) * ((double)(len + S) / 2 + 8) * 5.9604644775390625e-08 * 1.001 * s_abs;
         }
-        size_t row_total = front + (size_t)len + back;
+        size_t row_total = front + (size_t)len + 1 + back;   // (+1: the row of difference taps, one tap longer, shares the layout)
         row_total = (row_total + 7) / 8 * 8;
         if (q) q->resize(q_count + row_total, 0.0);
         q_count += row_total;
@@ -722,6 +722,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.rows = ctx->d_rows.ptr;
     a.widths = ctx->d_widths.ptr; a.q = ctx->d_q.ptr; a.q2 = ctx->uniform_w ? nullptr : ctx->d_q2.ptr;
     a.q32 = ctx->uniform_w ? reinterpret_cast<const float*>(ctx->d_q2.ptr) : nullptr;
+    a.g = (ctx->resident || ctx->opt.x_staged == 2) ? nullptr : ctx->d_g.ptr;   // (x_staged = 2: A/B switch, X at staging time but the dot products on the re-staged samples)
     a.split_lo = nullptr; a.park_cells = nullptr; a.e_abs_max = ctx->e_abs_max; a.q32_shifted = ctx->q_count;
     a.screens = ctx->d_screens.ptr;
     a.out_chi2 = ctx->over_chi2 ? ctx->over_chi2 : ctx->d_chi2.ptr;
@@ -1366,6 +1367,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         L.periods = place(np * 8); L.order = place(np * sizeof(int)); L.rows = place(np * sizeof(tlsdev::PeriodRows));
         L.widths = place(nw * sizeof(tlsdev::WidthEntry)); L.screens = place(nw * sizeof(tlsdev::RowScreen));
         L.q = place(nq * 8); L.q2 = place(nq * 8);   // (uniform weights: the fp32 rows of the screen instead of q^2)
+        L.g = place(ctx->resident ? 0 : nq * 8);       // (series in the HBM slab: the difference taps, dot products on X)
         const bool with_tiles = !ctx->resident && ctx->split;
         L.tile_prefix = place(with_tiles ? (np + 1) * sizeof(unsigned int) : 0);
         L.total = off;
@@ -1392,6 +1394,21 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             float* q32 = reinterpret_cast<float*>(h + L.q2);   // [nq] the rows | [nq] the rows one element later
             for (size_t j = 0; j < nq; ++j) { q32[j] = (float)q[j]; q32[nq + j] = j ? (float)q[j - 1] : 0.0f; }
         }
+        if (!ctx->resident) {
+            // Difference taps of every row, same offsets: g_0 = -q_0, g_j = q_{j-1} - q_j, g_L = q_{L-1}.  With e_k =
+            // X_{k+1} - X_k (X the running sum of e) a window's dot product is  sum_j q_j e_{i+j} = sum_{j<=L} g_j X_{i+j}
+            // (summation by parts): the slab variant's fast mode evaluates it on the X a tile already holds in LDS for
+            // the depth predicate, instead of staging the tile's samples a second time (tls_search_body.inc.h, x_dot).
+            double* gt = reinterpret_cast<double*>(h + L.g);
+            std::memset(gt, 0, nq * 8);
+            for (const auto& we : widths) {
+                const double* qr = q.data() + we.q_offset;
+                double* gr = gt + we.q_offset;
+                gr[0] = -qr[0];
+                for (int j = 1; j < we.q_len; ++j) gr[j] = qr[j - 1] - qr[j];
+                gr[we.q_len] = qr[we.q_len - 1];
+            }
+        }
         if (with_tiles) std::memcpy(h + L.tile_prefix, ctx->host_tile_prefix.data(), (np + 1) * sizeof(unsigned int));
         unsigned char* d = ctx->d_plan.ptr;
         ctx->d_tile_prefix.ptr = reinterpret_cast<unsigned int*>(d + L.tile_prefix);
@@ -1401,6 +1418,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         ctx->d_widths.ptr = reinterpret_cast<tlsdev::WidthEntry*>(d + L.widths);
         ctx->d_screens.ptr = reinterpret_cast<tlsdev::RowScreen*>(d + L.screens);
         ctx->d_q.ptr = reinterpret_cast<double*>(d + L.q); ctx->d_q2.ptr = reinterpret_cast<double*>(d + L.q2);
+        ctx->d_g.ptr = reinterpret_cast<double*>(d + L.g);
         TLS_HIP(ctx, hipMemcpyAsync(d, h, L.total, hipMemcpyHostToDevice, ctx->stream));
         TLS_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
         ctx->stage_pending = true;

@@ -488,6 +488,7 @@ struct SearchArgs {
     const WidthEntry* widths;
     const double* q;        // template rows q_j = 1 - signal_j, zero padded front and back
     const double* q2;       // q_j^2, same layout (general weights only)
+    const double* g;        // difference taps g_j = q_{j-1} - q_j (q_len + 1 per row), same layout (series in the HBM slab)
     const RowScreen* screens;   // [n_widths] piecewise-constant rows of the pruning bound (pruning variant)
     double* out_chi2;       // [n_periods]
     long long* out_row;     // [n_periods]
@@ -1744,7 +1745,15 @@ __device__ __forceinline__ void consider(Lead& best, double x_lo, double x_hi, i
 // by the reference's values whenever the estimates are close), and a cell that meets itself there ties and stays.
 // (X is read here, x[i0 + r*step] and x[i0 + r*step + d], and read AGAIN by a pending lane: nothing but the dot products
 // stays in registers for the rare case)
-template <bool UNIFORM_W, bool KEEP_DX, int R, bool COUNTING>
+// X_LDS: x points into LDS (possibly biased below the tile: only its low 32 bits are used); read through the LDS address
+// space -- a pointer that may be an LDS or a global one at run time would be dereferenced as a FLAT address, and a biased
+// LDS pointer is not a valid one.
+template <bool X_LDS>
+__device__ __forceinline__ double x_load(const double* x, int idx) {
+    if constexpr (X_LDS) return *((lds_f64_ptr)x + idx);
+    else return x[idx];
+}
+template <bool UNIFORM_W, bool KEEP_DX, int R, bool COUNTING, bool X_LDS = false>
 __device__ __forceinline__ void consider_cells(Lead& best, const double* x, int i0, int step, int d,
                                                double inv_d, double dd, const DepthRule& rule, double overshoot,
                                                const double (&A)[R], const double (&B)[R], int k, unsigned int& n_eval,
@@ -1754,7 +1763,7 @@ __device__ __forceinline__ void consider_cells(Lead& best, const double* x, int 
     unsigned int n_fast = 0;
     double x_lo[R], x_hi[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { x_lo[r] = x[i0 + r * step]; x_hi[r] = x[i0 + r * step + d]; }
+    for (int r = 0; r < R; ++r) { x_lo[r] = x_load<X_LDS>(x, i0 + r * step); x_hi[r] = x_load<X_LDS>(x, i0 + r * step + d); }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const double dX = x_hi[r] - x_lo[r];
@@ -1778,9 +1787,9 @@ __device__ __forceinline__ void consider_cells(Lead& best, const double* x, int 
         unsigned int n_slow = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const double* xr = x + (i0 + r * step);
-            asm volatile("" : "+v"(xr));   // a second read, not a value kept from the first
-            consider<UNIFORM_W, KEEP_DX>(best, xr[0], xr[d], i0 + r * step, inv_d, dd, rule, overshoot, A[r], B[r], k, n_slow,
+            int at = i0 + r * step;
+            asm volatile("" : "+v"(at));   // a second read, not a value kept from the first
+            consider<UNIFORM_W, KEEP_DX>(best, x_load<X_LDS>(x, at), x_load<X_LDS>(x, at + d), i0 + r * step, inv_d, dd, rule, overshoot, A[r], B[r], k, n_slow,
                                          undecided, widths_c, x_all);
         }
         n_fast = n_slow;

@@ -780,7 +780,20 @@
             for (int row = 0; row < n_rows; ++row) tile_live += rt.live[row];
             if (__builtin_amdgcn_readfirstlane((int)tile_live) == 0) { __syncthreads(); continue; }
         }
+        // Uniform weights, fast mode with X formed at staging time: the dot products are evaluated ON X -- summation by
+        // parts, sum_j q_j e_{i+j} = sum_{j<=L} g_j X_{i+j} with the difference taps g (host: L.g) --, so the tile keeps its X
+        // for phase 3b: no second staging of the samples, no X written to the slab and read back (Kepler size: 4.0 -> 2.8 MB
+        // of slab traffic per period).  X is exact here (a sum of multiples of 2^-53 below 1), the taps carry one rounding.
+        [[maybe_unused]] const bool x_dot = !RESIDENT && !STAGE_C && UNIFORM_W && !PRUNE && x_staging && ap->g != nullptr;
+        [[maybe_unused]] const double* x_tile = nullptr;
         if constexpr (!RESIDENT && !STAGE_C) {
+          if (x_dot) {
+            // (the tile's X, biased by -p_lo like every tile pointer.  x_tile is read through the LDS address space only --
+            // x_load<true>, load_taps --: c_base is a global pointer on the other path, and one pointer that is either is FLAT)
+            x_tile = reinterpret_cast<const double*>(smem + ap->hdr_bytes) - p_lo;
+            e_base = x_tile;
+            c_base = regB;   // (not read on this path: one value on both, so that the reads on the other stay global loads)
+          } else {
             // the folded samples replace C in the tile; the few C values phase 3b needs come from the slab
             double* tile_e = reinterpret_cast<double*>(smem + ap->hdr_bytes);
             const int staged = ap->tile_len + ap->tile_halo;
@@ -804,6 +817,7 @@
             c_base = regB;
             __syncthreads();
             pc.mark(12);
+          }
         }
         // ---- pruning (exact): drop the units that cannot win before they reach phase 3b ------------
         // Worth its passes only when many cells passed the depth predicate (noisy light curves):
@@ -1129,7 +1143,9 @@
                     const int u = __shfl((int)my_unit, (idx / kR) & (kWave - 1), kWave) * kR + idx % kR;   // T0 position index
                     if (idx < n_tail * kR) {
                         const int i = u * xth;
-                        const double dX = c_base[i + d] - c_base[i];   // past the grid: sentinel
+                        double dX;
+                        if (x_dot) dX = x_load<true>(x_tile, i + d) - x_load<true>(x_tile, i);
+                        else dX = c_base[i + d] - c_base[i];   // past the grid: sentinel
                         bool und_w = false;
                         pass = depth_pass(dX, inv_d, dd, dmin, rule.eps, exact_mode, und_w);
                         if (und_w) band_window(rule, k, i, dX, undecided);
@@ -1220,11 +1236,12 @@
                 const unsigned int slot = (relisted ? in_row - chunk_batches : in_row) * kWave + lane;
                 const bool have = slot < (unsigned int)(relisted ? n_singles : n_live);
                 const int unit = have ? (int)active_list[list_base + (relisted ? n_live : 0) + slot] : 0;
-                const const_f64_ptr q = q_all + q_offset;
+                const const_f64_ptr q = (x_dot ? (const_f64_ptr)ap->g : q_all) + q_offset;
+                const int Lx = x_dot ? L + 1 : L;   // taps the dot product runs over (difference taps: one more)
                 const unsigned int evals_before = n_eval;
                 if (COUNTING && ap->counters) {   // what the loops below issue per lane, padding and idle lanes included
                     const int reach = (tiled && !relisted) ? (kR - 1) * xth : 0;
-                    n_issued += (unsigned long long)((L + reach + kU - 1) / kU * kU) * (reach ? kR : 1) * (UNIFORM_W ? 1 : 2);
+                    n_issued += (unsigned long long)((Lx + reach + kU - 1) / kU * kU) * (reach ? kR : 1) * (UNIFORM_W ? 1 : 2);
                 }
                 [[maybe_unused]] const double errB2 = SCR ? widths_c[k].screen_c * ap->e_abs_max + 1e-30 : 0.0;
                 if (SCR && tiled && !relisted) {
@@ -1259,12 +1276,12 @@
                     const int u0 = unit * kR;
                     const int b = u0 * xth;
                     // the unrolled loop reads samples b .. b + ceil((L + (kR-1)*xth) / kU) * kU - 1
-                    TLS_CHECK(*ap, !have || (b >= p_lo && b + (L + (kR - 1) * xth + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + ap->tile_len + ap->tile_halo)), kChkDotWindow);
+                    TLS_CHECK(*ap, !have || (b >= p_lo && b + (Lx + (kR - 1) * xth + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + ap->tile_len + ap->tile_halo)), kChkDotWindow);
                     const double* e = e_base + b;
                     double Bv[kR], Av[kR];
 #pragma unroll
                     for (int r = 0; r < kR; ++r) { Bv[r] = 0.0; Av[r] = 0.0; }
-                    const int Lr = L;
+                    const int Lr = Lx;
                     if constexpr (UNIFORM_W) {
                         switch (xth) {
                             case 1: dot_windows<true, 1>(e, q, Lr, Bv); break;
@@ -1290,8 +1307,10 @@
 #pragma unroll
                         for (int r = 0; r < kR; ++r) Av[r] = sum_q2;
                     }
-                    if (have)
-                        consider_cells<UNIFORM_W, !RESIDENT, kR, COUNTING>(lead, c_base, b, xth, d, inv_d, dd, rule, overshoot, Av, Bv, k, n_eval, undecided, widths_c, regB);
+                    if (have) {
+                        if (x_dot) consider_cells<UNIFORM_W, !RESIDENT, kR, COUNTING, true>(lead, x_tile, b, xth, d, inv_d, dd, rule, overshoot, Av, Bv, k, n_eval, undecided, widths_c, regB);
+                        else consider_cells<UNIFORM_W, !RESIDENT, kR, COUNTING>(lead, c_base, b, xth, d, inv_d, dd, rule, overshoot, Av, Bv, k, n_eval, undecided, widths_c, regB);
+                    }
                 } else {
                     // wide T0 strides and re-listed sparse rows: one window per lane
                     if (!RESIDENT && widths_c[k].oversize) {
@@ -1328,7 +1347,7 @@
                         continue;
                     }
                     const int i = unit * xth;
-                    TLS_CHECK(*ap, !have || (i >= p_lo && i + (L + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + ap->tile_len + ap->tile_halo)), kChkDotWindow);
+                    TLS_CHECK(*ap, !have || (i >= p_lo && i + (Lx + kU - 1) / kU * kU <= (RESIDENT ? M + 1 + region_pad : p_lo + ap->tile_len + ap->tile_halo)), kChkDotWindow);
                     if constexpr (SCR) {
                         float B1w[1];
                         B1w[0] = dot_window32(((i & 1) ? eh1_addr - 4u : eh_addr) + 4u * (unsigned)i, (const_f32_ptr)ap->q32 + q_offset, L);
@@ -1340,7 +1359,7 @@
                     const double* e = e_base + i;
                     double B0 = 0, B1 = 0, A0 = 0, A1 = 0;
                     if constexpr (UNIFORM_W) {
-                        for (int t0 = 0; t0 < L; t0 += kU) {
+                        for (int t0 = 0; t0 < Lx; t0 += kU) {
                             const const_f64_ptr qs = q + t0;
                             double taps[kU], x[kU];
 #pragma unroll
@@ -1366,7 +1385,12 @@
                             for (int u = 0; u < kU; ++u) { B0 = fma(qs[u], x[u], B0); A0 = fma(ps[u], z[u], A0); }
                         }
                     }
-                    if (have) consider<UNIFORM_W, !RESIDENT>(lead, c_base[i], c_base[i + d], i, inv_d, dd, rule, overshoot, A0 + A1, B0 + B1, k, n_eval, undecided, widths_c, regB);
+                    if (have) {
+                        double x0, x1;
+                        if (x_dot) { x0 = x_load<true>(x_tile, i); x1 = x_load<true>(x_tile, i + d); }
+                        else { x0 = c_base[i]; x1 = c_base[i + d]; }
+                        consider<UNIFORM_W, !RESIDENT>(lead, x0, x1, i, inv_d, dd, rule, overshoot, A0 + A1, B0 + B1, k, n_eval, undecided, widths_c, regB);
+                    }
                 }
                 if constexpr (COUNTING) n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
             }
