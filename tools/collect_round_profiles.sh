@@ -7,7 +7,8 @@ cd "$(dirname "$0")/.."
 COMMIT=$(git rev-parse --short=8 HEAD)
 TLS_COMMIT=$COMMIT python tools/summarize_profile.py $TAG > /dev/null
 cp gpurun_out/round_$TAG/phases.txt profiles/${TAG}_phase_cycles.txt
-cp gpurun_out/round_$TAG/pytest_debug.txt profiles/${TAG}_debug_checked_run.txt
+if [ -f gpurun_out/round_$TAG/pytest_debug.txt ]; then cp gpurun_out/round_$TAG/pytest_debug.txt profiles/${TAG}_debug_checked_run.txt; fi
+if [ -f gpurun_out/profile_post_$TAG.log ]; then grep -v "rocprofv3\]\|output_stream\|simple_timer" gpurun_out/profile_post_$TAG.log > profiles/${TAG}_post_search_kernels.txt; fi
 cp gpurun_out/prof_tess_27d_$TAG/trace/k_kernel_stats.csv profiles/${TAG}_tess_kernel_stats.csv
 cp gpurun_out/prof_kepler_${TAG}_default/trace/k_kernel_stats.csv profiles/${TAG}_kepler_sample_kernel_stats.csv
 python - <<PY
