@@ -3460,23 +3460,61 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a) {
     // round under this epoch, ties that reorder) sends the epoch through the sort, whose order is kept from then on.
     // stats.py:178-201 sorts N points for each of up to N epochs; here an epoch costs two folds per point.
     bool have_base = false;
-    for (;;) {
-        if (tid == 0) { s_work[0] = (int)atomicAdd(a.queue, 1u); s_work[1] = 0; s_work[2] = 0; }
+    // (the epochs of a fit cost the same: a workgroup takes every gridDim.x-th one -- no queue, no device-scope atomic and
+    // its round trip per epoch)
+    for (int work = blockIdx.x; work < a.n_epochs; work += gridDim.x) {
+        if (tid == 0) { s_work[1] = 0; s_work[2] = 0; }
         __syncthreads();
-        const int work = s_work[0];
-        __syncthreads();
-        if (work >= a.n_epochs) break;
         const double epoch = a.epochs[work];
         int start = 0;          // sorted position k holds the kept order's entry (k + start) mod n
         bool rotated = false;
         if constexpr (RESIDENT) {
             if (have_base) {
                 int descents = 0, where = 0;
-                for (int k = tid; k < n; k += nt) {
-                    const int kn = k + 1 < n ? k + 1 : 0;
-                    const int i0 = (int)perm[k], i1 = (int)perm[kn];
-                    const double p0 = fold_phase(a.t[i0], a.period, epoch), p1 = fold_phase(a.t[i1], a.period, epoch);
-                    if (p1 < p0 || (p1 == p0 && i1 < i0)) { ++descents; where = kn; }
+                // (a thread takes a run of consecutive entries of the kept order -- one fold per point and one more for the
+                // run's successor, their time stamps requested together --, eight at a time)
+                constexpr int kRun = 8;
+                const double inv_period = 1.0 / a.period;
+                const int per = (n + nt - 1) / nt;
+                const int k_lo = tid * per < n ? tid * per : n, k_hi = k_lo + per < n ? k_lo + per : n;
+                for (int k0 = k_lo; k0 < k_hi; k0 += kRun) {
+                    int idx[kRun + 1];
+                    double ph[kRun + 1];
+#pragma unroll
+                    for (int j = 0; j <= kRun; ++j) {
+                        int k = k0 + j < k_hi + 1 ? k0 + j : k_hi;   // (the run's successor included; past it: the successor again)
+                        if (k >= n) k -= n;
+                        idx[j] = (int)perm[k];
+                    }
+                    double tv[kRun + 1], margin[kRun + 1];
+#pragma unroll
+                    for (int j = 0; j <= kRun; ++j) tv[j] = a.t[idx[j]];
+                    // The order of two neighbours is read off phases formed with ONE multiplication by 1 / P instead of the
+                    // reference's division: q' = (t - T0) * fl(1 / P) is within 4 * 2^-53 |q| of the quotient the exact fold rounds,
+                    // so neighbours whose cheap phases differ by more than the margin (and lie off the wrap at 0 / 1 by it) compare
+                    // like the exact ones; any other pair (ties, near-ties, the wrap) is folded exactly.  The fp64 divisions of the
+                    // folds were most of an epoch: every workgroup of the fit divides at the same time.
+#pragma unroll
+                    for (int j = 0; j <= kRun; ++j) {
+                        const double qv = (tv[j] - epoch) * inv_period;
+                        ph[j] = qv - floor(qv);
+                        margin[j] = 1.0e-15 * (fabs(qv) + 1.0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kRun; ++j) {
+                        if (k0 + j < k_hi) {
+                            const double mg = margin[j] + margin[j + 1];
+                            const bool off_wrap = ph[j] > mg && ph[j] < 1.0 - mg && ph[j + 1] > mg && ph[j + 1] < 1.0 - mg;
+                            bool down;
+                            if (off_wrap && fabs(ph[j + 1] - ph[j]) > mg) {
+                                down = ph[j + 1] < ph[j];
+                            } else {
+                                const double e0 = fold_phase(tv[j], a.period, epoch), e1 = fold_phase(tv[j + 1], a.period, epoch);
+                                down = e1 < e0 || (e1 == e0 && idx[j + 1] < idx[j]);
+                            }
+                            if (down) { ++descents; where = k0 + j + 1 < n ? k0 + j + 1 : 0; }
+                        }
+                    }
                 }
                 if (descents) { atomicAdd(&s_work[1], descents); s_work[2] = where; }
                 __syncthreads();
