@@ -303,11 +303,9 @@ def run_shard(h, args, config, steps=None):
     t, flux, kw = synthetic.config(config, seed=0)
     inp = synthetic.search_inputs(t, flux, **kw)
     job = shard.ShardedSearch(h.rank, h.world)
-    lo, hi = job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"])
-    if h.channel is not None:   # every rank derived the boundaries itself: they must be the same boundaries
-        digests = h.channel.allgather_bytes(shard.bounds_digest(job.bounds))
-        if any(d != digests[0] for d in digests):
-            raise RuntimeError("rank %d: the ranks disagree on the period blocks of %s" % (h.rank, config))
+    # (every rank derives the boundaries itself, priced for its context's switches; plan() compares the digests of all ranks)
+    lo, hi = job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"], options=ctx.get_options(),
+                      allgather_digests=h.channel.allgather_bytes if h.channel is not None else None)
     ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"][lo:hi], inp["table"], inp["params"])
     c = job.count_per_rank
 
@@ -409,7 +407,7 @@ def shard_balance(ctx, name, n_blocks=8, reps=3):
     whole_ms = None
     for label in ("time_model", "cells_only"):
         job = shard.ShardedSearch(0, n_blocks)
-        job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"])
+        job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"], options=ctx.get_options())
         bounds = job.bounds if label == "time_model" else shard.partition_by_cost(job.costs, n_blocks)
         ms = []
         for r in range(n_blocks):
