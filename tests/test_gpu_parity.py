@@ -1092,3 +1092,58 @@ def test_post_search_kernels_at_kepler_and_tess_size(gpu, oracle_lib):
             numpy.testing.assert_allclose(x, y, rtol=1e-8, atol=1e-8)
         numpy.testing.assert_allclose(got[3:], want[3:], rtol=1e-9)
         assert int(numpy.argmax(got[2])) == int(numpy.argmax(want[2]))
+
+
+@pytest.mark.parametrize("outlier,weights", [(3.0e4, False), (3.0e4, True), (2.0e6, False)])
+def test_noted_band_windows_are_decided_on_the_exact_prefix_sum(gpu, oracle_lib, outlier, weights):
+    """Series in the HBM slab, fast prefix-sum mode: a window whose mean depth is too close to transit_depth_min for the
+    plain scan to call is NOTED and decided after the attempt on the period's exact prefix sum (band_window /
+    resolve_band).  Forced here: the band's half-width is 1.25 * 2^-53 * (N + W) * max|flux|, so ONE
+    wild flux value widens it until white noise puts windows inside -- at 3e4 a few dozen per period (noted, resolved by
+    one prefix pass), at 2e6 more than the list holds (256: the period is searched again in exact mode).  Either way the
+    evaluated cells, rows and winners are exact mode's and the oracle's; uniform and per-point weights; a batch of two
+    light curves equals its single searches bit for bit."""
+    n = 12000
+    rng = numpy.random.RandomState(11)
+    t = numpy.linspace(2.0, 62.0, n)
+    y = 1.0 + rng.normal(0, 2e-4, n)
+    y[(t % 7.3) < 0.2] -= 1.5e-3
+    y[137] = outlier
+    dy = rng.uniform(0.8, 1.3, n) * 2e-4 if weights else None
+    inp = synthetic.search_inputs(t, y, dy, period_min=5.0, period_max=30.0, oversampling_factor=1, transit_depth_min=1e-4)
+    sel = inp["periods"][:: max(1, len(inp["periods"]) // 60)]
+    gpu.set_options(prune=0, split=0, exact_prefix=1)
+    exact = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+    gpu.set_options(exact_prefix=None, band_max=1e9)      # (no period starts in exact mode for the hits it expects)
+    fast = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+    assert not gpu.plan_info()["resident"]
+    plain = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+    for a, b in zip(fast[:3], plain[:3]):
+        numpy.testing.assert_array_equal(a, b)
+    assert fast[3]["evaluated_cells"] == exact[3]["evaluated_cells"]
+    assert fast[3]["inner_steps"] == exact[3]["inner_steps"]
+    numpy.testing.assert_array_equal(fast[1], exact[1])
+    numpy.testing.assert_allclose(fast[0], exact[0], rtol=1e-9, atol=0)    # (the band, and with it the modes' distance, is wide here)
+    want = oracle_search(oracle_lib, inp, periods=sel)
+    assert fast[3]["evaluated_cells"] == int(want[3][1])
+    assert_parity(exact, want, n)
+    numpy.testing.assert_array_equal(fast[1], want[1])
+    numpy.testing.assert_allclose(fast[0], want[0], rtol=1e-9, atol=0)
+    gpu.execute(phase_clock=True)
+    stats = gpu.phase_cycles()
+    assert stats["stat_exact_retries"] >= len(sel) // 2          # periods that went through a second pass ...
+    if outlier < 1e6:
+        assert 0 < stats["stat_screen_parked"] <= 256 * len(sel)   # ... for their noted windows (this slot counts them)
+    else:
+        assert stats["stat_screen_parked"] < 256 * len(sel) // 2   # ... or, the list overflowing, through a second search
+    # a batch of two light curves: the same bits as the single searches
+    y2 = inp["y"] + rng.normal(0, 1e-5, n)
+    ys = numpy.stack([inp["y"], y2])
+    dys = numpy.stack([inp["dy"], inp["dy"]])
+    chi2, row, dep = gpu.search_batch(inp["t"], ys, dys, sel, inp["table"], inp["params"])
+    numpy.testing.assert_array_equal(chi2[0], fast[0])
+    numpy.testing.assert_array_equal(row[0], fast[1])
+    one = gpu.search(inp["t"], y2, inp["dy"], sel, inp["table"], inp["params"])
+    numpy.testing.assert_array_equal(chi2[1], one[0])
+    numpy.testing.assert_array_equal(row[1], one[1])
+    numpy.testing.assert_array_equal(dep[1], one[2])
