@@ -254,3 +254,22 @@ def test_power_with_a_devices_list_returns_the_one_device_results():
         assert list(other.keys()) == list(plain.keys())
         for k in plain.keys():
             numpy.testing.assert_array_equal(numpy.asarray(other[k], dtype=float), numpy.asarray(plain[k], dtype=float), err_msg=k)
+
+
+def test_survey_batches_over_a_devices_list_equal_the_one_device_batch():
+    """BASELINE config 5 inside one process: survey.search_batch / power_batch with devices=[...] deal contiguous slices
+    of the light curves to the contexts of a DeviceGroup (one host thread each, no collective); every light curve's
+    results are those of the one-device batch, bit for bit (two contexts on the one GPU of the box)."""
+    from tls_amd import survey
+    t, f0, kw = synthetic.config("k2_90d", seed=0)
+    fluxes = numpy.stack([synthetic.config("k2_90d", seed=s, sigma=(1 + s % 3) * 50e-6)[1] for s in range(70)])
+    kw = dict(kw, period_min=5.0, period_max=20.0)
+    one = survey.search_batch(t, fluxes, **kw)
+    two = survey.search_batch(t, fluxes, devices=[0, 0], **kw)
+    for a, b in zip(one, two):
+        numpy.testing.assert_array_equal(a, b)
+    s1, p1 = survey.power_batch(t, fluxes[:40], **kw)
+    s2, p2 = survey.power_batch(t, fluxes[:40], devices=[0, 0, 0], **kw)
+    numpy.testing.assert_array_equal(p1, p2)
+    for name in s1.dtype.names:
+        numpy.testing.assert_array_equal(s1[name], s2[name], err_msg=name)

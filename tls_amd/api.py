@@ -97,11 +97,13 @@ class transitleastsquares(object):
         # devices=[...]: the period grid sharded over several GPUs of this process (tls_amd.search.DeviceGroup: one context
         # and one host thread per device, blocks by modelled time, one RCCL all-gather) -- the counterpart of the
         # reference's use_threads pool over periods (main.py:140-163, validate.py:81)
-        group = None
-        if kwargs.get("devices") is not None and len(kwargs["devices"]) > 1:
-            group = _search.device_group(kwargs["devices"])
-        elif kwargs.get("devices") is not None and kwargs.get("device") is None and kwargs.get("context") is None:
-            kwargs = dict(kwargs, device=int(list(kwargs["devices"])[0]))
+        group, listed = None, kwargs.get("devices")
+        if isinstance(listed, _search.DeviceGroup):
+            group = listed
+        elif listed is not None and len(listed) > 1:
+            group = _search.device_group(listed)
+        elif listed is not None and kwargs.get("device") is None and kwargs.get("context") is None:
+            kwargs = dict(kwargs, device=int(list(listed)[0]))
         chi2, test_statistic_rows, test_statistic_depths = _search.search_periods(
             self.t, self.y, self.dy, test_statistic_periods, table,
             transit_depth_min=self.transit_depth_min,

@@ -3,7 +3,9 @@ template searched back to back on one GPU by ONE C-ABI call (`tls_search_batch`)
 list, duration windows, template rows, work queue order) is prepared once; per light curve only
 the flux (and weights) are re-uploaded before the search kernel runs again.
 
-Across GPUs the light curves are simply dealt to the ranks (one process per GPU); see bench.py.
+Across GPUs the light curves are simply dealt out: one process per GPU (bench.py), or `devices=[0, 1, ...]` on the
+calls below -- contiguous slices of the batch to the contexts of a `tls_amd.search.DeviceGroup`, one host thread each, no
+collective (every light curve's results come back over its own GPU's copy engine).
 """
 import numpy
 
@@ -34,7 +36,30 @@ def _batch_inputs(t, flux_batch, dy_batch, power_kwargs):
     return inp, y_rows, dy_rows
 
 
-def power_batch(t, flux_batch, dy_batch=None, context=None, device=None, with_arrays=False, **power_kwargs):
+def _slices(n_curves, n_parts):
+    """Contiguous, near-equal slices of the batch (whole launch groups of 32 where the batch allows it)."""
+    groups = -(-n_curves // 32)
+    bounds = [min(n_curves, 32 * ((groups * r) // n_parts)) for r in range(n_parts)] + [n_curves]
+    if groups < n_parts:
+        bounds = [(n_curves * r) // n_parts for r in range(n_parts)] + [n_curves]
+    return bounds
+
+
+def _on_devices(devices, call, n_curves):
+    """call(context, lo, hi) for every device's slice of the batch, on the group's host threads; the slices' results."""
+    group = devices if isinstance(devices, _search.DeviceGroup) else _search.device_group(devices)
+    bounds = _slices(n_curves, len(group.contexts))
+    parts = [None] * len(group.contexts)
+
+    def work(r):
+        if bounds[r + 1] > bounds[r]:
+            parts[r] = call(group.contexts[r], bounds[r], bounds[r + 1])
+
+    group._threads(work)
+    return [p for p in parts if p is not None]
+
+
+def power_batch(t, flux_batch, dy_batch=None, context=None, device=None, with_arrays=False, devices=None, **power_kwargs):
     """Survey-mode power(): for every light curve of `flux_batch` what `transitleastsquares(t, flux).power(**kwargs)`
     reports as SDE, SDE_raw, chi2_min, period, T0, depth and duration (fractional, lc_cache_overview["duration"] of
     the template row at the chi^2 minimum, main.py:199-200) -- search, SDE spectra and final T0 fit all on the
@@ -43,15 +68,26 @@ def power_batch(t, flux_batch, dy_batch=None, context=None, device=None, with_ar
     Returns (summary, periods[, chi2, row, depth, power]): summary is a numpy structured array with the fields of
     tls_power_summary plus "duration".  The per-transit statistics of power() (SNR, odd/even, counts) are host work
     on a handful of candidates and are not part of the batch call."""
-    ctx = context if context is not None else _search.default_context(device)
     inp, y_rows, dy_rows = _batch_inputs(t, flux_batch, dy_batch, power_kwargs)
     from . import constants as C
     osf = power_kwargs.get("oversampling_factor", C.OVERSAMPLING_FACTOR)
     kernel = osf * C.SDE_MEDIAN_KERNEL_SIZE
     if kernel != int(kernel):
         raise ValueError("oversampling_factor * %d must be an integer" % C.SDE_MEDIAN_KERNEL_SIZE)
-    raw, chi2, row, depth, power = ctx.power_batch(inp["t"], y_rows, dy_rows, inp["periods"], inp["table"], inp["params"],
-                                                   int(kernel), with_arrays=with_arrays, with_power=with_arrays)
+
+    def call(ctx, lo, hi):
+        return ctx.power_batch(inp["t"], y_rows[lo:hi], dy_rows[lo:hi], inp["periods"], inp["table"], inp["params"],
+                               int(kernel), with_arrays=with_arrays, with_power=with_arrays)
+
+    if devices is not None and (isinstance(devices, _search.DeviceGroup) or len(devices) > 1):
+        parts = _on_devices(devices, call, len(y_rows))
+        raw = numpy.concatenate([p[0] for p in parts])
+        chi2, row, depth, power = (numpy.concatenate([p[k] for p in parts]) if with_arrays else None for k in (1, 2, 3, 4))
+    else:
+        if devices is not None and device is None and context is None:
+            device = list(devices)[0]
+        ctx = context if context is not None else _search.default_context(device)
+        raw, chi2, row, depth, power = call(ctx, 0, len(y_rows))
     names = list(raw.dtype.names) + ["duration"]
     summary = numpy.zeros(len(raw), dtype=[(k, raw.dtype[k]) for k in raw.dtype.names] + [("duration", "f8")])
     for k in raw.dtype.names:
@@ -63,7 +99,7 @@ def power_batch(t, flux_batch, dy_batch=None, context=None, device=None, with_ar
     return summary, inp["periods"]
 
 
-def search_batch(t, flux_batch, dy_batch=None, context=None, device=None, **power_kwargs):
+def search_batch(t, flux_batch, dy_batch=None, context=None, device=None, devices=None, **power_kwargs):
     """Search every light curve of `flux_batch` (shape [n_curves, n_points]) on the grids that
     `transitleastsquares(t, flux).power(**power_kwargs)` would use.
 
@@ -71,7 +107,17 @@ def search_batch(t, flux_batch, dy_batch=None, context=None, device=None, **powe
     share `t` and be free of invalid points (clean them first); a `dy_batch` must have the same
     weight structure for every curve (all uniform or all per-point).
     """
-    ctx = context if context is not None else _search.default_context(device)
     inp, y_rows, dy_rows = _batch_inputs(t, flux_batch, dy_batch, power_kwargs)
-    chi2, row, depth = ctx.search_batch(inp["t"], y_rows, dy_rows, inp["periods"], inp["table"], inp["params"])
+
+    def call(ctx, lo, hi):
+        return ctx.search_batch(inp["t"], y_rows[lo:hi], dy_rows[lo:hi], inp["periods"], inp["table"], inp["params"])
+
+    if devices is not None and (isinstance(devices, _search.DeviceGroup) or len(devices) > 1):
+        parts = _on_devices(devices, call, len(y_rows))
+        chi2, row, depth = (numpy.concatenate([p[k] for p in parts]) for k in range(3))
+    else:
+        if devices is not None and device is None and context is None:
+            device = list(devices)[0]
+        ctx = context if context is not None else _search.default_context(device)
+        chi2, row, depth = call(ctx, 0, len(y_rows))
     return inp["periods"], chi2, row, depth
