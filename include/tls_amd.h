@@ -96,7 +96,7 @@ typedef struct tls_options {
     int32_t threads;        /* TLS_THREADS       threads per workgroup */
     int32_t blocks;         /* TLS_BLOCKS        workgroups in flight (at most) */
     int32_t plan_threads;   /* TLS_PLAN_THREADS  host threads of the per-period planning */
-    int32_t reserved_;
+    int32_t slim;           /* TLS_SLIM          0: never the four-slots-per-CU kernel of short LDS-resident series */
     int64_t prune_min_live; /* TLS_PRUNE_MIN_LIVE live units per period (tile) from which the pruning passes run */
     double band_max;        /* TLS_BAND_MAX      expected band hits above which a slab period starts in exact mode */
 } tls_options;
@@ -194,6 +194,10 @@ int tls_kernel_timing(tls_ctx *ctx, int reset, double *total_ms, int64_t *launch
 /* data-independent work of the prepared search (no device work needed). */
 int tls_plan_info(const tls_ctx *ctx, tls_counters *counters, int64_t *lds_bytes,
                   int64_t *n_blocks, int64_t *resident /* 1: folded series kept in LDS */);
+/* Which search kernel the context's last tls_execute launched: "resident" (LDS-resident series, two or one workgroups
+ * per CU), "resident+prune", "resident+screen32", "slim" (LDS-resident, four 256-thread workgroups per CU), "slab",
+ * "slab+prune", "slab+split"; "" before the first launch.  The string is static. */
+const char *tls_last_kernel(const tls_ctx *ctx);
 
 /* ---- final T0 fit: the batched counterpart of stats.py:135-204 ------------------------ */
 /* For every trial epoch: fold (t, y) at (period, epoch), stable sort by phase, roll the folded

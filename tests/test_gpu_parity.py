@@ -625,8 +625,11 @@ def test_search_batch_groups_weights_and_tiled_layout(gpu, name, n_curves, strid
     more curves than one group holds, per-point weights, and the HBM-slab layout all return what a
     search per light curve returns, bit for bit.  (Same kernel shape on both sides: a batch runs the
     one-workgroup-per-period kernel, so the single searches are kept from the two-role kernel, which a few dozen
-    periods of a long series would otherwise take and which runs exact prefix-sum mode only -- 1e-10 apart.)"""
-    gpu.set_options(split="0")
+    periods of a long series would otherwise take and which runs exact prefix-sum mode only -- 1e-10 apart.  Likewise the
+    four-slot kernel of short series is kept out: the curves here differ in noise, so a single search and its group may
+    take different kernels, and that one's values differ from the classic family's in the last bits; its own batch test is
+    test_four_slot_kernel_batches_ties_and_the_series_it_does_not_fit.)"""
+    gpu.set_options(split="0", slim="0")
     t, f0, kw = synthetic.config(name, seed=0)
     rng = numpy.random.RandomState(5)
     inputs = []
@@ -1151,3 +1154,91 @@ def test_noted_band_windows_are_decided_on_the_exact_prefix_sum(gpu, oracle_lib,
     numpy.testing.assert_array_equal(chi2[1], one[0])
     numpy.testing.assert_array_equal(row[1], one[1])
     numpy.testing.assert_array_equal(dep[1], one[2])
+
+
+@pytest.mark.parametrize("sigma,stride,outlier", [(None, 1, None), (300e-6, 11, None), (None, 7, 3.0e4), (100e-6, 13, 2.0e6)])
+def test_four_slot_kernel_searches_the_reference_cells(gpu, oracle_lib, sigma, stride, outlier):
+    """Short LDS-resident series, uniform weights: tls_slim_kernel (four 256-thread workgroups per CU, phase 3 on the
+    prefix sum X alone, dot products by summation by parts) against the classic LDS-resident kernel
+    in exact prefix-sum mode and the oracle.  Same evaluated cells and template taps, same rows; chi^2 and depth within
+    what the two prefix-sum modes differ by.  A window the plain scan cannot decide is noted and decided on the exact
+    prefix sum: ONE wild flux value widens the undecided band (1.25 * 2^-53 * (N + W) * max|flux|) until white noise puts
+    windows inside -- a few dozen per period at 3e4, more than the list of 256 holds at 2e6 (the period is searched again
+    in exact mode)."""
+    inp = _inputs("k2_90d") if sigma is None else _inputs("k2_90d", sigma=sigma)
+    if outlier is not None:
+        y = inp["y"].copy()
+        y[137] = outlier
+        t, _, kw = synthetic.config("k2_90d")
+        inp = synthetic.search_inputs(inp["t"], y, None, **kw)
+    sel = inp["periods"][::stride]
+    args = (inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])
+    gpu.set_options(slim=0, prune=0, screen32=0, exact_prefix=1)
+    classic = gpu.search(*args, count_work=True)
+    assert gpu.last_kernel() == "resident"
+    gpu.set_options(slim=1, exact_prefix=None)
+    slim = gpu.search(*args, count_work=True)
+    assert gpu.last_kernel() == "slim", gpu.plan_info()
+    plain = gpu.search(*args)
+    assert gpu.last_kernel() == "slim"
+    for a, b in zip(slim[:3], plain[:3]):
+        numpy.testing.assert_array_equal(a, b)       # counting and plain instantiation: the same bits
+    assert slim[3]["evaluated_cells"] == classic[3]["evaluated_cells"]
+    assert slim[3]["inner_steps"] == classic[3]["inner_steps"]
+    numpy.testing.assert_array_equal(slim[1], classic[1])
+    wide = outlier is not None     # (the band, and with it the modes' distance, is wide then)
+    numpy.testing.assert_allclose(slim[0], classic[0], rtol=1e-9 if wide else 1e-10, atol=0)
+    numpy.testing.assert_allclose(slim[2], classic[2], rtol=0, atol=1e-9 if wide else 1e-12)
+    want = oracle_search(oracle_lib, inp, periods=sel)
+    assert slim[3]["evaluated_cells"] == int(want[3][1])
+    if not wide:
+        assert_parity(slim, want, len(inp["t"]))
+    else:
+        numpy.testing.assert_array_equal(slim[1], want[1])
+        numpy.testing.assert_allclose(slim[0], want[0], rtol=1e-9, atol=0)
+
+
+def test_four_slot_kernel_batches_ties_and_the_series_it_does_not_fit(gpu, oracle_lib):
+    """tls_slim_kernel: a survey batch equals its single searches bit for bit (the sort of a period is shared, a light curve
+    with an undecided window goes through exact mode alone); duplicate and unsorted time stamps and a commensurate period
+    keep numpy's stable order (32-bit sort keys, ties by the exact phase and the index); per-point weights and a series
+    beyond a quarter of the LDS take the classic kernel."""
+    from tls_amd import survey
+    gpu.set_options(slim=1)
+    t, f0, kw = synthetic.config("k2_90d", seed=0)
+    fluxes = numpy.stack([synthetic.config("k2_90d", seed=s)[1] for s in range(5)])
+    periods, chi2, row, depth = survey.search_batch(t, fluxes, context=gpu, **kw)
+    assert gpu.last_kernel() == "slim"
+    for k in (0, 4):
+        inp = synthetic.search_inputs(t, fluxes[k], **kw)
+        one = gpu.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
+        assert gpu.last_kernel() == "slim"
+        numpy.testing.assert_array_equal(chi2[k], one[0])
+        numpy.testing.assert_array_equal(row[k], one[1])
+        numpy.testing.assert_array_equal(depth[k], one[2])
+    # ties: every time stamp twice, shuffled; periods that pile the phases up (cadence 0.02 d: 1.0 d = 50 cadences)
+    rng = numpy.random.RandomState(3)
+    tt = numpy.repeat(numpy.arange(1500) * 0.02 + 1.0, 2)
+    yy = 1.0 + rng.normal(0, 3e-4, tt.size)
+    yy[(tt % 2.7) < 0.12] -= 2e-3
+    sh = rng.permutation(tt.size)
+    inp = synthetic.search_inputs(tt[sh], yy[sh], None, period_min=0.9, period_max=9.0, oversampling_factor=2)
+    sel = numpy.concatenate([inp["periods"][::5], [1.0, 2.0, 3.0, 1.5, 1.0 + 1e-9]])
+    sel = sel[(sel >= inp["periods"].min()) & (sel <= inp["periods"].max())]
+    got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+    assert gpu.last_kernel() == "slim"
+    want = oracle_search(oracle_lib, inp, periods=sel)
+    assert got[3]["evaluated_cells"] == int(want[3][1])
+    assert_parity(got, want, tt.size)
+    # per-point weights: the classic kernel
+    dy = rng.uniform(0.7, 1.4, tt.size) * 3e-4
+    inp_w = synthetic.search_inputs(tt[sh], yy[sh], dy, period_min=0.9, period_max=9.0, oversampling_factor=1)
+    gpu.search(inp_w["t"], inp_w["y"], inp_w["dy"], inp_w["periods"][::9], inp_w["table"], inp_w["params"])
+    assert gpu.last_kernel() == "resident"
+    # 120 days at 30 min: one region no longer fits a quarter of the LDS
+    n = 5760
+    t2 = numpy.arange(n) / 48.0
+    y2 = 1.0 + rng.normal(0, 1e-4, n)
+    inp2 = synthetic.search_inputs(t2, y2, None, period_min=1.0, period_max=30.0, oversampling_factor=1)
+    gpu.search(inp2["t"], inp2["y"], inp2["dy"], inp2["periods"][::20], inp2["table"], inp2["params"])
+    assert gpu.last_kernel().startswith("resident")

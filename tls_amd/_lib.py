@@ -23,7 +23,7 @@ ABI_VERSION = 4   # include/tls_amd.h TLS_AMD_ABI_VERSION: checked against the l
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version", "tls_abi_version",
     "tls_device_name", "tls_get_options", "tls_set_options", "tls_search", "tls_search_batch", "tls_power_batch", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_period_cycles",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_last_kernel", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_period_cycles",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_info", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
     "tls_comm_barrier", "tls_comm_max",
@@ -48,11 +48,11 @@ class Options(ctypes.Structure):
     """tls_options: the switches of a context (include/tls_amd.h).  -1 / negative = the library decides."""
     _fields_ = [(name, ctypes.c_int32) for name in (
         "exact_prefix", "prune", "screen32", "no_screen", "fast_slab", "x_staged", "split", "split_batch", "sort2", "sort3",
-        "stage_c", "slab_wgs", "threads", "blocks", "plan_threads", "reserved_")] + [
+        "stage_c", "slab_wgs", "threads", "blocks", "plan_threads", "slim")] + [
         ("prune_min_live", ctypes.c_int64), ("band_max", ctypes.c_double)]
 
     NAMES = ("exact_prefix", "prune", "screen32", "no_screen", "fast_slab", "x_staged", "split", "split_batch", "sort2",
-             "sort3", "stage_c", "slab_wgs", "threads", "blocks", "plan_threads", "prune_min_live", "band_max")
+             "sort3", "stage_c", "slab_wgs", "threads", "blocks", "plan_threads", "slim", "prune_min_live", "band_max")
 
     def as_dict(self):
         return {k: getattr(self, k) for k in self.NAMES}
@@ -136,6 +136,8 @@ def load():
     lib.tls_fetch.argtypes = [vp, _c_double_p, _c_int64_p, _c_double_p, cp]
     lib.tls_execute_timed.restype = ci
     lib.tls_execute_timed.argtypes = [vp, ci, _c_double_p]
+    lib.tls_last_kernel.restype = ctypes.c_char_p
+    lib.tls_last_kernel.argtypes = [vp]
     lib.tls_plan_info.restype = ci
     lib.tls_plan_info.argtypes = [vp, cp, _c_int64_p, _c_int64_p, _c_int64_p]
     lib.tls_kernel_timing.restype = ci
@@ -492,6 +494,10 @@ class Context(object):
         d = c.as_dict()
         d.update(lds_bytes=lds.value, n_blocks=blocks.value, resident=bool(res.value))
         return d
+
+    def last_kernel(self):
+        """Name of the search kernel the last execute launched (include/tls_amd.h, tls_last_kernel)."""
+        return self._lib.tls_last_kernel(self._h).decode()
 
     # -- RCCL
     def comm_unique_id(self):

@@ -94,7 +94,7 @@ tls_options default_options() {
     std::memset(&o, 0, sizeof o);
     o.exact_prefix = o.prune = o.screen32 = o.no_screen = o.fast_slab = o.x_staged = o.split = o.split_batch = -1;
     o.sort2 = o.sort3 = o.stage_c = o.slab_wgs = o.threads = o.blocks = o.plan_threads = -1;
-    o.reserved_ = 0;
+    o.slim = -1;
     o.prune_min_live = -1;
     o.band_max = -1.0;
     return o;
@@ -111,7 +111,7 @@ const tls_options& process_options() {
         geti("TLS_FAST_SLAB", o.fast_slab); geti("TLS_X_STAGED", o.x_staged); geti("TLS_SPLIT", o.split);
         geti("TLS_SPLIT_BATCH", o.split_batch); geti("TLS_SORT2", o.sort2); geti("TLS_SORT3", o.sort3);
         geti("TLS_STAGE_C", o.stage_c); geti("TLS_SLAB_WGS", o.slab_wgs); geti("TLS_THREADS", o.threads);
-        geti("TLS_BLOCKS", o.blocks); geti("TLS_PLAN_THREADS", o.plan_threads);
+        geti("TLS_BLOCKS", o.blocks); geti("TLS_PLAN_THREADS", o.plan_threads); geti("TLS_SLIM", o.slim);
         if (const char* v = std::getenv("TLS_PRUNE_MIN_LIVE")) o.prune_min_live = std::atoll(v);
         if (const char* v = std::getenv("TLS_BAND_MAX")) o.band_max = std::atof(v);
         return o;
@@ -194,6 +194,9 @@ struct tls_ctx {
     bool uniform_w = true, resident = true;
     int n = 0, W = 0, M = 0, n_periods = 0, n_widths = 0, nb = 0;
     int threads = 512, blocks = 0;
+    const char* last_kernel = "";    // tls_last_kernel
+    int slim_blocks = 0;              // > 0: the plan fits the four-slots-per-CU kernel (tls_slim_kernel): its workgroups in flight
+    size_t slim_lds = 0;              // ... and its dynamic LDS
     int cumsum_round = 2 * tlsdev::kCumsumChunk;
     size_t lds_bytes = 0;
     double S0 = 0, w0 = 1, depth_min = 0;
@@ -722,7 +725,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.periods = ctx->d_periods.ptr; a.order = ctx->d_order.ptr; a.rows = ctx->d_rows.ptr;
     a.widths = ctx->d_widths.ptr; a.q = ctx->d_q.ptr; a.q2 = ctx->uniform_w ? nullptr : ctx->d_q2.ptr;
     a.q32 = ctx->uniform_w ? reinterpret_cast<const float*>(ctx->d_q2.ptr) : nullptr;
-    a.g = (ctx->resident || ctx->opt.x_staged == 2) ? nullptr : ctx->d_g.ptr;   // (x_staged = 2: A/B switch, X at staging time but the dot products on the re-staged samples)
+    a.g = ((ctx->resident && ctx->slim_blocks == 0) || (!ctx->resident && ctx->opt.x_staged == 2)) ? nullptr : ctx->d_g.ptr;   // (x_staged = 2: A/B switch, X at staging time but the dot products on the re-staged samples)
     a.split_lo = nullptr; a.park_cells = nullptr; a.e_abs_max = ctx->e_abs_max; a.q32_shifted = ctx->q_count;
     a.screens = ctx->d_screens.ptr;
     a.out_chi2 = ctx->over_chi2 ? ctx->over_chi2 : ctx->d_chi2.ptr;
@@ -850,7 +853,9 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     // work and the debug entries run the plain variant, whose bits it returns anyway
     const bool screen = ctx->screen_kernel && screen_admissible(ctx->resident, ctx->uniform_w, ctx->e_abs_max) && !prune &&
                         !count_work && !debug_folded && !debug_prefix;
+    const char* kernel_name = ctx->resident ? (prune ? "resident+prune" : "resident") : split ? "slab+split" : (prune ? "slab+prune" : "slab");
     if (screen) {
+        kernel_name = "resident+screen32";
         const size_t region = (size_t)ctx->M + 1 + (size_t)ctx->region_pad;
         hipError_t er = ctx->d_split.reserve((size_t)ctx->blocks * region);
         if (er != hipSuccess) { --ctx->ev_used; return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er)); }
@@ -859,6 +864,16 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         if (er != hipSuccess) { --ctx->ev_used; return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er)); }
         a.park_cells = ctx->d_park.ptr;
         e = launch_variant<true, true, false, unsigned short, false, false, true>(ctx, a, ctx->blocks);
+    } else if (ctx->slim_blocks > 0 && ctx->uniform_w && !prune && !debug_folded && !debug_prefix && !period_cycles) {
+        // four period slots per CU (tls_slim_kernel.hip.h): plain variant, uniform weights, 256-thread workgroups
+        kernel_name = "slim";
+        a.lds_bytes = (long long)ctx->slim_lds;
+        auto kernel = count_work ? tlsdev::tls_slim_kernel<true> : tlsdev::tls_slim_kernel<false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->slim_lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->slim_blocks), dim3((unsigned)tlsdev::kSlimThreads), ctx->slim_lds, ctx->stream, a);
+            e = hipGetLastError();
+        }
     } else if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short, ctx->blocks);
     else if (!split) {
         if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int, ctx->blocks);
@@ -887,6 +902,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     }
     ctx->executed = true;
     ctx->counted = count_work;
+    ctx->last_kernel = kernel_name;
     return TLS_OK;
 }
 
@@ -1001,7 +1017,6 @@ int tls_set_options(tls_ctx* ctx, const tls_options* opt) {
     if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
     if (!opt) return fail(ctx, TLS_E_ARG, "null options");
     tls_options o = *opt;
-    o.reserved_ = 0;
     if (std::memcmp(&o, &ctx->opt, sizeof o) == 0) return TLS_OK;
     ctx->opt = o;
     // a prepared plan was built for the old switches: the next tls_prepare plans again (the key holds them too)
@@ -1144,6 +1159,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     const size_t resident_bytes = hdr + regions * 8 * region_doubles;
     ctx->hdr_bytes = (int)hdr;
     ctx->resident = resident_bytes <= kLdsPerCU && n <= 65535;
+    ctx->slim_blocks = 0; ctx->slim_lds = 0;
     if (ctx->resident) {
         ctx->nb = (int)n;
         ctx->tile_len = 0; ctx->tile_halo = 0; ctx->sort2 = false; ctx->sort3 = false;
@@ -1154,6 +1170,21 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)ctx->threads);
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)wg_per_cu * ctx->n_cu);
         if (ctx->opt.blocks > 0) ctx->blocks = std::max(1, std::min(ctx->blocks, ctx->opt.blocks));   // developer switch
+        // Four 256-thread workgroups per CU, phase 3 on X alone (tls_slim_kernel.hip.h): uniform weights, and the period's
+        // one region + header within a quarter of the LDS.  (tls_options::slim = 0: never.)
+        // (auto: only while the library also decides between the classic kernel's variants -- an explicit tls_options::prune
+        // or ::screen32 selects among THOSE; slim = 1 forces this kernel wherever neither pruning nor the screen is taken)
+        // (exact prefix-sum mode throughout is the classic kernel's: this one values its cells on the plain scan, and keeps
+        // the exact prefix sum for the windows the plain scan cannot decide)
+        const bool slim_wanted = ctx->opt.exact_prefix != 1 && (ctx->opt.slim == 1 || (ctx->opt.slim < 0 && ctx->opt.prune < 0 && ctx->opt.screen32 < 0));
+        if (uniform && slim_wanted && ctx->opt.threads <= 0) {
+            const long long need = tlsdev::slim_lds_bytes((int)n, (int)M, ctx->region_pad, (int)widths.size());
+            if (need > 0 && 4 * (size_t)need <= kLdsPerCU) {
+                ctx->slim_lds = (size_t)need;
+                ctx->slim_blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)4 * ctx->n_cu);
+                if (ctx->opt.blocks > 0) ctx->slim_blocks = std::max(1, std::min(ctx->slim_blocks, ctx->opt.blocks));
+            }
+        }
     } else {
         // the folded series lives in a per-workgroup HBM slab; phase 3 stages it through LDS in
         // tiles of `tile_len` window-start positions plus a halo of the widest window
@@ -1335,7 +1366,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     }
     ctx->list_stride = (list_cap + 63) / 64 * 64;
     // three arrays per workgroup: the live units, (pruning) the bound of each, and the units the bound keeps
-    TLS_HIP(ctx, ctx->d_lists.reserve((size_t)std::max(ctx->blocks, (!ctx->resident && ctx->split) ? ctx->split_blocks : 0) * 3 * ctx->list_stride));
+    TLS_HIP(ctx, ctx->d_lists.reserve((size_t)std::max(std::max(ctx->blocks, ctx->slim_blocks), (!ctx->resident && ctx->split) ? ctx->split_blocks : 0) * 3 * ctx->list_stride));
+    if (ctx->slim_blocks > 0) TLS_HIP(ctx, ctx->d_perm.reserve((size_t)std::max(ctx->blocks, ctx->slim_blocks) * (size_t)n));   // (band resolution stashes the order of a period)
     ctx->prune_min_live = ctx->opt.prune_min_live >= 0 ? (long long)ctx->opt.prune_min_live : 256;
     ctx->p2_shift = 4;  // block length of the coarse prefix sum of e^2: at most kP2MaxBlocks blocks
     while ((((size_t)M + ((size_t)1 << ctx->p2_shift) - 1) >> ctx->p2_shift) > (size_t)tlsdev::kP2MaxBlocks) ++ctx->p2_shift;
@@ -1367,7 +1399,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         L.periods = place(np * 8); L.order = place(np * sizeof(int)); L.rows = place(np * sizeof(tlsdev::PeriodRows));
         L.widths = place(nw * sizeof(tlsdev::WidthEntry)); L.screens = place(nw * sizeof(tlsdev::RowScreen));
         L.q = place(nq * 8); L.q2 = place(nq * 8);   // (uniform weights: the fp32 rows of the screen instead of q^2)
-        L.g = place(ctx->resident ? 0 : nq * 8);       // (series in the HBM slab: the difference taps, dot products on X)
+        const bool with_g = !ctx->resident || ctx->slim_blocks > 0;   // the difference taps: dot products on X (HBM slab; four-slot kernel)
+        L.g = place(with_g ? nq * 8 : 0);
         const bool with_tiles = !ctx->resident && ctx->split;
         L.tile_prefix = place(with_tiles ? (np + 1) * sizeof(unsigned int) : 0);
         L.total = off;
@@ -1394,7 +1427,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             float* q32 = reinterpret_cast<float*>(h + L.q2);   // [nq] the rows | [nq] the rows one element later
             for (size_t j = 0; j < nq; ++j) { q32[j] = (float)q[j]; q32[nq + j] = j ? (float)q[j - 1] : 0.0f; }
         }
-        if (!ctx->resident) {
+        if (with_g) {
             // Difference taps of every row, same offsets: g_0 = -q_0, g_j = q_{j-1} - q_j, g_L = q_{L-1}.  With e_k =
             // X_{k+1} - X_k (X the running sum of e) a window's dot product is  sum_j q_j e_{i+j} = sum_{j<=L} g_j X_{i+j}
             // (summation by parts): the slab variant's fast mode evaluates it on the X a tile already holds in LDS for
@@ -1749,6 +1782,8 @@ int tls_kernel_timing(tls_ctx* ctx, int reset, double* total_ms, int64_t* launch
     return TLS_OK;
 }
 
+const char* tls_last_kernel(const tls_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
+
 int tls_plan_info(const tls_ctx* ctx, tls_counters* counters, int64_t* lds_bytes, int64_t* n_blocks, int64_t* resident) {
     if (!ctx || !ctx->prepared) return TLS_E_STATE;
     if (counters) { *counters = ctx->plan_counters; counters->evaluated_cells = -1; counters->inner_steps = -1; counters->issued_fma = -1; }
@@ -1814,7 +1849,7 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         TLS_HIP(ctx, sl.d_row.reserve((size_t)group * np));
         TLS_HIP(ctx, sl.d_depth.reserve((size_t)group * np));
     }
-    TLS_HIP(ctx, ctx->d_perm.reserve((size_t)ctx->blocks * nn));
+    TLS_HIP(ctx, ctx->d_perm.reserve((size_t)std::max(ctx->blocks, ctx->slim_blocks) * nn));
     const int64_t n_groups = (n_curves + group - 1) / group;
     auto drain = [&](int64_t g) -> int {   // results of group g: wait for its download, copy to the caller's arrays
         auto& sl = ctx->slot[g & 1];
@@ -1955,7 +1990,7 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
     TLS_HIP(ctx, sl.d_chi2.reserve((size_t)group * np));
     TLS_HIP(ctx, sl.d_row.reserve((size_t)group * np));
     TLS_HIP(ctx, sl.d_depth.reserve((size_t)group * np));
-    TLS_HIP(ctx, ctx->d_perm.reserve((size_t)ctx->blocks * nn));
+    TLS_HIP(ctx, ctx->d_perm.reserve((size_t)std::max(ctx->blocks, ctx->slim_blocks) * nn));
     const size_t spec_stride = 3 * np;                                  // SR | power_raw | power of one curve
     TLS_HIP(ctx, ctx->d_spec.reserve((size_t)group * spec_stride + 2 * (size_t)group + 8 * (size_t)group + (size_t)group));
     double* d_sde = ctx->d_spec.ptr + (size_t)group * spec_stride;      // [group][2]

@@ -3405,6 +3405,8 @@ tls_fold_search_kernel(const SearchArgs) {
     }
 }
 
+#include "tls_slim_kernel.hip.h"
+
 // ---------------------------------------------------------------------------------------
 // Final T0 fit (reference stats.py:135-204): for every trial epoch Tx fold the light curve at
 // (period, Tx), stable-sort, roll by `roll` cadences twice and sum the residuals of the

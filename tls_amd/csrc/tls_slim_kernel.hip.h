@@ -1,0 +1,686 @@
+// tls_slim_kernel.hip.h -- the LDS-resident search with FOUR period slots per CU (included by tls_kernels.hip.h, inside
+// namespace tlsdev).
+//
+// Why.  The LDS-resident kernel (tls_search_kernel<RESIDENT = true>) keeps e = 1 - flux and its running sum X side by side:
+// 16 bytes a sample, 81 KB for the 90-day configuration, two 512-thread workgroups per CU.  Round 5 measured what bounds it
+// (PERF_LOG.md): a workgroup alone on its CU issues 17 % of the time -- a period is a chain of dependent round trips --, and a
+// 42-day series, which fits the LDS four times, ran 11.5 % faster as four 256-thread workgroups per CU than as two 512-thread
+// ones: periods in flight hide each other's latency better than waves of one period do.  Four slots need <= 40 KB a period:
+//   * phase 3 runs on X ALONE.  The depth predicate reads X anyway; the dot products run on it too -- summation by parts,
+//     sum_j q_j e_{i+j} = sum_{j<=L} g_j X_{i+j} with the difference taps g (as the HBM-slab variant's fast mode does);
+//   * the sort orders 32-bit phase keys held in registers (ties: the exact phases, then the index -- numpy's stable order),
+//     two points to a bucket, its records inside the region X takes afterwards; the permutation waits in registers while
+//     the flux is gathered over its LDS home;
+//   * the prefix sum runs in place (fast mode: a plain scan; exact mode: exact_cumsum's aliased form, f shifted by one).
+// Uniform weights, no pruning, no fp32 screen (the host takes the other kernel for those); survey batches share the sort of a
+// period as there.  Cells, predicate, tie rule and reductions are the other kernel's code (consider_cells, settle_best, ...);
+// values differ from it by the rounding of the difference taps (chi^2 to ~1e-13).
+//
+// Reference mapping as tls_search_body.inc.h: core.py:15-18,113-188, helpers.py:70-73.
+constexpr int kSlimThreads = 256;
+constexpr int kSlimWaves = kSlimThreads / kWave;
+constexpr int kSlimPer = 20;          // samples of the folded order a thread keeps in registers across the gather
+constexpr int kSlimScratchBytes = 1328;   // >= sizeof(Cumsum2Scratch); the per-row tables share its first bytes
+constexpr int kSlimIdxBits = 13;      // a sort record: sub-bucket key (19 bits) | original index (13 bits)
+__host__ __device__ constexpr int slim_header_bytes() { return 128 + kSlimWaves * 24 + 48 + kSlimScratchBytes; }   // wsum | wbest | s_work | scratch
+static_assert(slim_header_bytes() % 16 == 0, "the region behind the header holds doubles read in pairs");
+static_assert(sizeof(Cumsum2Scratch) <= kSlimScratchBytes, "exact_cumsum's scratch does not fit the slim header");
+// sort buckets: as many as the region holds beside the records and the order, at most one per two points
+__host__ __device__ inline int slim_buckets(int n, int RS) {
+    const long long room = (8LL * RS - 6LL * n) / 4;   // records 4n | bucket counters 4nb | ... | order 2n (the region's last bytes)
+    const long long want = n / 2 > 16 ? n / 2 : 16;
+    return (int)(room < want ? room : want);
+}
+// what the kernel needs of the LDS for a plan, 0 when the plan does not fit it
+__host__ __device__ inline long long slim_lds_bytes(int n, int M, int region_pad, int n_widths) {
+    const int RS = M + 1 + region_pad;
+    if (n > kSlimThreads * kSlimPer || n >= (1 << kSlimIdxBits) || n < 64) return 0;
+    if (slim_buckets(n, RS) < n / 8 || slim_buckets(n, RS) < 16) return 0;
+    if (4LL * (3 * n_widths + 2) > kSlimScratchBytes) return 0;
+    return slim_header_bytes() + 8LL * RS;
+}
+
+// a value the compiler must not carry across phases in a register (or a spill slot): per-thread indices tid + j * nt are
+// cheaper to form again than to keep
+__device__ __forceinline__ int slim_fresh(int v) { asm volatile("" : "+v"(v)); return v; }
+// two sort records whose 19 key bits tie: the exact phases decide, then the index (out of line: one pair in 1e8)
+__device__ __noinline__ int slim_tie_before(const double* t, double period, int i_other, int i_mine) {
+    const double ph = fold_phase(t[i_mine], period, 0.0), ph2 = fold_phase(t[i_other], period, 0.0);
+    return (ph2 < ph || (ph2 == ph && i_other < i_mine)) ? 1 : 0;
+}
+
+template <bool COUNTING>
+__global__ void __launch_bounds__(kSlimThreads, 4)
+tls_slim_kernel(const SearchArgs) {
+    constexpr bool UNIFORM_W = true;
+    args_ptr ap = (args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    constexpr int nt = kSlimThreads, nw = kSlimWaves;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int n = ap->n, W = ap->W, M = ap->M;
+    const int region_pad = ap->region_pad;
+    const int RS = M + 1 + region_pad;
+
+    // ---- LDS carve-up ----------------------------------------------------------------------------
+    unsigned int* wsum = reinterpret_cast<unsigned int*>(smem);                       // 32 words
+    Best* wbest = reinterpret_cast<Best*>(smem + 128);                                 // kSlimWaves x 24 B
+    int* s_work = reinterpret_cast<int*>(smem + 128 + kSlimWaves * sizeof(Best));     // [12]
+    unsigned char* scratch = smem + 128 + kSlimWaves * sizeof(Best) + 48;             // kSlimScratchBytes
+    RowTables rt;   // (inside the scratch: written after the prefix sum, which is the scratch's other user)
+    rt.live = reinterpret_cast<unsigned int*>(scratch);
+    rt.singles = rt.live + ap->n_widths;
+    rt.batch_start = rt.singles + ap->n_widths;
+    rt.next_batch = rt.batch_start + (ap->n_widths + 1);
+    double* X = reinterpret_cast<double*>(smem + slim_header_bytes());                 // f, then X: RS doubles
+    const int nb = slim_buckets(n, RS);
+    unsigned int* recs = reinterpret_cast<unsigned int*>(X);                           // [n] sort records, bucket by bucket
+    unsigned int* cnt = recs + n;                                                      // [nb]
+    unsigned short* perm = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(X) + 8LL * RS) - n;   // [n], the region's last bytes
+    unsigned int* chunk_list = ap->chunk_lists + (long long)blockIdx.x * ap->list_stride;
+    if (tid == 0) {
+        TLS_CHECK(*ap, slim_lds_bytes(n, M, region_pad, ap->n_widths) != 0 && slim_lds_bytes(n, M, region_pad, ap->n_widths) <= ap->lds_bytes && 6LL * n + 4LL * nb <= 8LL * RS, kChkLdsCarve);
+    }
+    const const_width_ptr widths_c = (const_width_ptr)ap->widths;
+    const const_rows_ptr rows_c = (const_rows_ptr)ap->rows;
+    const const_f64_ptr g_all = (const_f64_ptr)ap->g;
+    const double dmin = ap->depth_min;
+
+    bool retry_exact = false;
+    // Fast mode: a window inside the undecided band of the depth predicate is NOTED (band_window) and decided after the
+    // attempt on the period's exact prefix sum -- the period loop is entered a second time for the sort, the gather and the
+    // exact prefix pass only (`resolve_band`); the lanes' leads and counts of the attempt are kept.  (Cells are VALUED on the
+    // plain scan throughout: the dot products by parts want a prefix sum rounded at the size of e, not of k.)
+    bool resolve_band = false;
+    Lead kept_lead = no_lead();
+    unsigned int kept_eval = 0;
+    unsigned long long kept_steps = 0, kept_issued = 0;
+    BandEntry* const band_list = reinterpret_cast<BandEntry*>(chunk_list + ap->list_cap);   // (the pruning variant's second list: idle here)
+    int work = 0;
+    for (;;) {
+        if (!retry_exact) {
+            if (tid == 0) { s_work[0] = (int)atomicAdd(ap->queue, 1u); s_work[1] = 0; s_work[2] = 0; s_work[4] = 0; }
+            __syncthreads();
+            work = __builtin_amdgcn_readfirstlane(s_work[0]);
+            __syncthreads();
+        } else if (tid == 0) {
+            s_work[1] = 0; s_work[2] = 0;
+        }
+        int flag_slot = 1;
+        const bool period_exact = retry_exact || ap->exact_prefix != 0;
+        retry_exact = false;
+        bool curve_exact = false;
+        if (work >= ap->n_periods) {
+            if (tid == 0) {   // the last workgroup to leave rewinds the queue for the next launch
+                __threadfence();
+                if (atomicAdd(ap->queue + 1, 1u) == gridDim.x - 1) { atomicExch(ap->queue, 0u); atomicExch(ap->queue + 1, 0u); }
+            }
+            break;
+        }
+        const int p = ap->order[work];
+        TLS_CHECK(*ap, p >= 0 && p < ap->n_periods, kChkWorkItem);
+        const double period = ap->periods[p];
+        PhaseClock pc;
+        pc.start(ap->phase_cycles);
+
+        // ---- phase 1: fold + stable sort by phase (core.py:119-120), on 32-bit keys -------------------
+        // A point's key stays in a register from the fold to its rank.  Bucket = floor(key * nb / 2^32); INSIDE a bucket the
+        // low word of key * nb is monotone in the key: its top 19 bits and the index make the point's sort record.  Records
+        // are scattered bucket by bucket (any order inside one); a point's place is its bucket's start plus the records of
+        // the bucket in front of it -- decided by the records, and by the exact phases (then the index: numpy's stable
+        // order) for the pairs whose 19 bits tie: two phases within 2^-30, or the piled-up phases of a commensurate period.
+        for (int b = tid; b < nb; b += nt) cnt[b] = 0;
+        __syncthreads();
+        unsigned int key[kSlimPer];
+        {
+            constexpr int kF = 5;
+            static_assert(kSlimPer % kF == 0, "the fold takes kF time stamps per step");
+#pragma unroll
+            for (int j0 = 0; j0 < kSlimPer; j0 += kF) {
+                const int base = slim_fresh(tid) + j0 * nt;
+                double tv[kF];
+#pragma unroll
+                for (int j = 0; j < kF; ++j) { const int i = base + j * nt; tv[j] = ap->t[i < n ? i : 0]; }
+#pragma unroll
+                for (int j = 0; j < kF; ++j) {
+                    const int i = base + j * nt;
+                    key[j0 + j] = phase_key(fold_phase(tv[j], period, 0.0));
+                    if (i < n) atomicAdd(&cnt[__umulhi(key[j0 + j], (unsigned int)nb)], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        pc.mark(0);
+        block_exclusive_scan(cnt, nb, wsum);
+        pc.mark(1);
+#pragma unroll
+        for (int j = 0; j < kSlimPer; ++j) {
+            const int i = slim_fresh(tid) + j * nt;
+            if (i < n) {
+                const unsigned int slot = atomicAdd(&cnt[__umulhi(key[j], (unsigned int)nb)], 1u);
+                recs[slot] = ((key[j] * (unsigned int)nb) & ~((1u << kSlimIdxBits) - 1u)) | (unsigned int)i;
+            }
+        }
+        __syncthreads();
+        pc.mark(2);
+        {
+            // (cnt[b] is now the END of bucket b)
+            auto before = [&](unsigned int other, unsigned int mine) -> int {
+                if (((other ^ mine) >> kSlimIdxBits) != 0u) return other < mine ? 1 : 0;
+                if (other == mine) return 0;
+                return slim_tie_before(ap->t, period, (int)(other & ((1u << kSlimIdxBits) - 1u)), (int)(mine & ((1u << kSlimIdxBits) - 1u)));
+            };
+            constexpr int kG = 5, kWin = 4;   // points ranked together; records of a bucket read up front
+            static_assert(kSlimPer % kG == 0, "the rank takes kG points per step");
+#pragma unroll
+            for (int j0 = 0; j0 < kSlimPer; j0 += kG) {
+                int lo[kG], hi[kG];
+                unsigned int mine[kG], win[kG][kWin];
+                const int base = slim_fresh(tid) + j0 * nt;
+#pragma unroll
+                for (int g = 0; g < kG; ++g) {
+                    const int i = base + g * nt;
+                    const unsigned int b = __umulhi(key[j0 + g], (unsigned int)nb);
+                    mine[g] = ((key[j0 + g] * (unsigned int)nb) & ~((1u << kSlimIdxBits) - 1u)) | (unsigned int)i;
+                    lo[g] = b ? (int)cnt[b - 1] : 0;
+                    hi[g] = i < n ? (int)cnt[b] : lo[g];
+                }
+#pragma unroll
+                for (int g = 0; g < kG; ++g)
+#pragma unroll
+                    for (int u = 0; u < kWin; ++u) win[g][u] = recs[lo[g] + u < hi[g] ? lo[g] + u : lo[g]];
+#pragma unroll
+                for (int g = 0; g < kG; ++g) {
+                    int rank = 0;
+#pragma unroll
+                    for (int u = 0; u < kWin; ++u) if (lo[g] + u < hi[g]) rank += before(win[g][u], mine[g]);
+                    for (int s2 = lo[g] + kWin; s2 < hi[g]; ++s2) rank += before(recs[s2], mine[g]);
+                    if (lo[g] < hi[g]) perm[lo[g] + rank] = (unsigned short)(mine[g] & ((1u << kSlimIdxBits) - 1u));
+                }
+            }
+        }
+        __syncthreads();
+        pc.mark(3);
+        // survey mode: the permutation outlives the light curves of the batch in global memory
+        const unsigned short* perm_g = nullptr;
+        if (ap->n_curves > 1 || resolve_band) {   // (resolution evaluates the few windows that pass from the flux in global memory)
+            unsigned short* pg = reinterpret_cast<unsigned short*>(ap->perm_scratch + (long long)blockIdx.x * n);
+            for (int k = tid; k < n; k += nt) pg[k] = perm[k];
+            perm_g = pg;
+            __syncthreads();
+        }
+        for (int curve = 0; curve < ap->n_curves; ++curve) {
+        const bool exact_mode = period_exact || curve_exact;
+        curve_exact = false;
+        DepthRule rule;
+        rule.dmin = ap->depth_min; rule.eps = exact_mode ? 1e-15 : ap->eps_fast; rule.exact_mode = exact_mode;
+        rule.band_count = nullptr; rule.band_list = nullptr;
+        if (!exact_mode && ap->list_cap >= 4 * kBandCap) {   // (16 bytes an entry in the idle list region)
+            rule.band_count = reinterpret_cast<unsigned int*>(&s_work[4]); rule.band_list = band_list;
+        }
+        const bool resolving = resolve_band;   // (exact mode: this pass decides the windows the attempt noted, nothing else)
+        resolve_band = false;
+        rule.reach = (rule.dmin - rule.eps > 4e-15) ? fmin(fmax(1e-9, 4e-15 / (rule.dmin - rule.eps)), 1.0) : 1.0;
+        bool undecided = false;
+        const double* y_c = ap->y + (long long)curve * n;
+        // ---- phase 2: gather (core.py:121-123), patch (core.py:126), prefix sum (helpers.py:72) -- all in the one region ----
+        {
+            // the folded order into registers first: the flux lands on the order's own LDS home
+            int idx[kSlimPer];
+            const int tid_g = slim_fresh(tid);
+#pragma unroll
+            for (int j = 0; j < kSlimPer; ++j) {
+                const int k = tid_g + j * nt;
+                idx[j] = k < n ? (perm_g ? (int)perm_g[k] : (int)perm[k]) : 0;
+            }
+            __syncthreads();   // (every thread has its part of the order; global reads of perm_g included)
+            double* fdst = exact_mode ? X + 1 : X;   // exact mode: C[k+1] goes over f[k] (exact_cumsum's aliased form)
+            double v[kSlimPer];
+#pragma unroll
+            for (int j = 0; j < kSlimPer; ++j) v[j] = y_c[idx[j]];
+#pragma unroll
+            for (int j = 0; j < kSlimPer; ++j) { const int k = tid_g + j * nt; if (k < n) fdst[k] = v[j]; }
+            __syncthreads();
+            for (int k = tid; k < W; k += nt) fdst[n + k] = fdst[k];   // core.py:126
+            __syncthreads();
+            pc.mark(4);
+            if (!exact_mode) {
+                // X[k] = sum of e over [0, k), e = 1 - f: a plain scan in place (every thread its own stretch)
+                double* wtot = reinterpret_cast<double*>(scratch);
+                int per = (M + nt - 1) / nt;
+                if ((per & 1) == 0) per += 1;
+                const int lo = tid * per < M ? tid * per : M;
+                const int hi = lo + per < M ? lo + per : M;
+                double local = 0.0;
+                for (int k = lo; k < hi; ++k) local += 1.0 - X[k];
+                const double incl = wave_inclusive_sum(local);
+                if (lane == kWave - 1) wtot[wave] = incl;
+                lds_barrier();
+                double run = 0.0, total = 0.0;
+                for (int u = 0; u < nw; ++u) { const double wv = wtot[u]; if (u < wave) run += wv; total += wv; }
+                run += incl - local;
+                for (int k = lo; k < hi; ++k) { const double e1 = 1.0 - X[k]; X[k] = run; run += e1; }
+                if (tid == nt - 1) X[M] = total;
+            } else {
+                if (tid == 0) X[0] = 0.0;
+                __syncthreads();
+                (void)exact_cumsum<true>(X + 1, X, M, reinterpret_cast<Cumsum2Scratch*>(scratch), ap->phase_cycles, 0.0);
+                __syncthreads();
+                for (int k = tid; k <= M; k += nt) X[k] = (double)k - X[k];   // X = k - numpy.cumsum: an exact subtraction
+            }
+            for (int k = tid; k < region_pad; k += nt) X[M + 1 + k] = -(double)(k + 1) * 1.0e300;   // sentinels (see the other kernel)
+            __syncthreads();
+            pc.mark(5);
+        }
+        const int k_lo = __builtin_amdgcn_readfirstlane(rows_c[p].k_lo);
+        const int k_hi = __builtin_amdgcn_readfirstlane(rows_c[p].k_hi);
+        const int k_x = __builtin_amdgcn_readfirstlane(rows_c[p].k_x);
+        const int n_rows = k_hi - k_lo;
+        for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;
+        if (tid == 0) { s_work[3] = 0; if (!resolving) s_work[4] = 0; }
+        __syncthreads();
+
+        Lead lead = resolving ? kept_lead : no_lead();
+        unsigned int n_eval = resolving ? kept_eval : 0u;
+        unsigned long long n_steps = resolving ? kept_steps : 0ull, n_issued = resolving ? kept_issued : 0ull;
+        const double* c_base = X;
+        if (!resolving) {
+        // ---- phase 3a: depth predicate over every trial cell -> lists of live units (core.py:58) ----------
+        const bool exact_u = __builtin_amdgcn_readfirstlane((int)exact_mode) != 0;
+        const double thr_hi = rule.dmin + rule.eps, thr_lo = rule.dmin - rule.eps;
+        if (k_x > k_lo) {
+            const int units0 = widths_c[k_lo].n_chunks;
+            const int n_dense = k_x - k_lo;
+            for (int tile = wave; tile * kWave < units0; tile += nw) {
+                const int unit = tile * kWave + lane;
+                const int u0 = unit * kR;
+                const int u0c = u0 < M + 1 ? u0 : M + 1;
+                double c_lo[kR];
+#pragma unroll
+                for (int r = 0; r < kR; ++r) c_lo[r] = c_base[u0c + r];
+                int row_lo = 0, row_hi = 0;
+                unsigned long long band_mask = 0ull;
+                const unsigned long long valid_mask = ballot64(unit < units0);
+                constexpr int kRowBatch = 2;
+                for (int k = k_lo; k < k_x; k += kRowBatch) {
+                    int dv[kRowBatch];
+                    double inv[kRowBatch], dC[kRowBatch];
+                    double c_hi[kRowBatch][kR];
+#pragma unroll
+                    for (int j = 0; j < kRowBatch; ++j) {
+                        const int kk = k + j < k_x ? k + j : k_x - 1;
+                        dv[j] = widths_c[kk].width;
+                        inv[j] = widths_c[kk].inv_d;
+                        const int hi0 = min(u0 + dv[j], M + 1);
+#pragma unroll
+                        for (int r = 0; r < kR; ++r) c_hi[j][r] = c_base[hi0 + r];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kRowBatch; ++j) {
+                        double m = c_hi[j][0] - c_lo[0];
+#pragma unroll
+                        for (int r = 1; r < kR; ++r) m = fmax(m, c_hi[j][r] - c_lo[r]);
+                        dC[j] = m;
+                    }
+#pragma unroll
+                    for (int j = 0; j < kRowBatch; ++j) {
+                        if (k + j < k_x) {
+                            unsigned long long mask;
+                            if (exact_u) {
+                                bool und_j = false;
+                                mask = ballot64(depth_pass(dC[j], inv[j], (double)dv[j], dmin, rule.eps, true, und_j));
+                            } else {
+                                const double m_fast = dC[j] * inv[j];
+                                mask = ballot64(m_fast > thr_hi);
+                                const unsigned long long band_j = ballot64(m_fast >= thr_lo) & ~mask & valid_mask;
+                                if (band_j != 0ull) {   // (a scalar branch, rarely taken)
+                                    if (rule.band_count != nullptr) {
+                                        // the unit's deepest window is inside the band: its windows there are noted one by one
+                                        if ((band_j >> lane) & 1ull) {
+#pragma unroll
+                                            for (int r = 0; r < kR; ++r) {
+                                                const double dXr = c_hi[j][r] - c_lo[r];
+                                                if (dXr * inv[j] >= thr_lo) band_window(rule, k + j, u0 + r, dXr, undecided);
+                                            }
+                                        }
+                                    } else {
+                                        band_mask |= band_j;
+                                    }
+                                }
+                            }
+                            mask &= valid_mask;
+                            if (n_dense <= kWave) {
+                                set_lane(row_lo, (int)(unsigned int)mask, k + j - k_lo);
+                                set_lane(row_hi, (int)(unsigned int)(mask >> 32), k + j - k_lo);
+                            } else {
+                                push_live(((mask >> lane) & 1ull) != 0ull, (unsigned int)unit, &rt.live[k + j - k_lo],
+                                          chunk_list + widths_c[k + j].list_base, lane);
+                            }
+                        }
+                    }
+                }
+                undecided |= (band_mask & valid_mask) != 0ull;
+                const unsigned long long row_mask = ((unsigned long long)(unsigned int)row_hi << 32) | (unsigned int)row_lo;
+                if (n_dense <= kWave) {
+                    unsigned int base = 0;
+                    const unsigned int mine = (unsigned int)__popcll(row_mask);
+                    if (mine) base = atomicAdd(&rt.live[lane], mine);
+                    const unsigned long long rows_hit = ballot64(mine != 0u);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    for (unsigned long long left = rows_hit; left; left &= left - 1ull) {
+                        const int j = __ffsll((long long)left) - 1;
+                        const unsigned long long mask = (unsigned long long)lane_value((long long)row_mask, j);
+                        const unsigned int b0 = (unsigned int)lane_value((int)base, j);
+                        TLS_CHECK(*ap, b0 + (unsigned int)__popcll(mask) <= (unsigned int)widths_c[k_lo + j].n_chunks, kChkListCap);
+                        if ((mask >> lane) & 1ull)
+                            chunk_list[widths_c[k_lo + j].list_base + b0 + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
+                    }
+                }
+            }
+        }
+        pc.mark(13);
+        // strided rows (long durations, core.py:50-58): one row per wave through a ticket counter
+        for (;;) {
+            int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(&s_work[3], 1);
+            const int k = (k_x > k_lo ? k_x : k_lo) + __builtin_amdgcn_readfirstlane(ticket);
+            if (k >= k_hi) break;
+            const int d = widths_c[k].width, xth = widths_c[k].xth, n_pos = widths_c[k].n_pos;
+            const int n_units = widths_c[k].n_chunks;
+            const double inv_d = widths_c[k].inv_d;
+            unsigned int* list = chunk_list + widths_c[k].list_base;
+            unsigned int n_listed = 0;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (widths_c[k].tiled) {
+                for (int tile = 0; tile * kWave < n_units; ++tile) {
+                    const int unit = tile * kWave + lane;
+                    const int uc = unit < n_units ? unit : n_units - 1;
+                    const double* c0 = c_base + uc * kR * xth;
+                    double c_lo[kR], c_hi[kR];
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) { c_lo[r] = c0[r * xth]; c_hi[r] = c0[r * xth + d]; }
+                    double dC = c_hi[0] - c_lo[0];
+#pragma unroll
+                    for (int r = 1; r < kR; ++r) dC = fmax(dC, c_hi[r] - c_lo[r]);
+                    bool live;
+                    if (exact_u) {
+                        bool und_u = false;
+                        live = depth_pass(dC, inv_d, (double)d, dmin, rule.eps, true, und_u);
+                    } else {
+                        const double m_fast = dC * inv_d;
+                        live = m_fast > thr_hi;
+                        if (!live && m_fast >= thr_lo && unit < n_units) {
+#pragma unroll
+                            for (int r = 0; r < kR; ++r) {
+                                const double dXr = c_hi[r] - c_lo[r];
+                                if (dXr * inv_d >= thr_lo) band_window(rule, k, (uc * kR + r) * xth, dXr, undecided);
+                            }
+                        }
+                    }
+                    live = live && unit < n_units;
+                    const unsigned long long mask = ballot64(live);
+                    if (live) list[n_listed + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
+                    n_listed += (unsigned int)__popcll(mask);
+                }
+            } else {
+                for (int tile = 0; tile * kWave < n_pos; ++tile) {
+                    const int unit = tile * kWave + lane;
+                    bool live = false;
+                    if (unit < n_pos) {
+                        const int i = unit * xth;
+                        const double dXw = c_base[i + d] - c_base[i];
+                        bool und_w = false;
+                        live = depth_pass(dXw, inv_d, (double)d, dmin, rule.eps, exact_mode, und_w);
+                        if (und_w) band_window(rule, k, i, dXw, undecided);
+                    }
+                    const unsigned long long mask = ballot64(live);
+                    if (live) list[n_listed + (unsigned int)__popcll(mask & below)] = (unsigned int)unit;
+                    n_listed += (unsigned int)__popcll(mask);
+                }
+            }
+            TLS_CHECK(*ap, n_listed <= (unsigned int)widths_c[k].n_chunks, kChkListCap);
+            rt.live[k - k_lo] = n_listed;   // (every lane stores the same value: see the other kernel on the ticket loop)
+        }
+        __syncthreads();
+        pc.mark(9);
+        // sparse rows and mostly empty last batches: re-listed one window per lane (as the other kernel)
+        for (int row = wave; row < n_rows; row += nw) {
+            const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
+            int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
+            const int xth = widths_c[k].xth, n_units = widths_c[k].n_chunks, tiled = widths_c[k].tiled;
+            const int d = widths_c[k].width, list_base = widths_c[k].list_base;
+            const double inv_d = widths_c[k].inv_d, dd = (double)d;
+            unsigned int* list = chunk_list + list_base;
+            unsigned int count = 0;
+            const bool sparse = n_live <= kSparseRow;
+            const int n_tail = sparse ? n_live : (TLS_TAIL_RELIST ? (n_live & (kWave - 1)) : 0);
+            const int first = n_live - n_tail;
+            if (tiled && n_tail > 0 && n_tail <= kTailMax && n_units >= (kR + 1) * kSparseRow && first + n_tail * kR <= n_units) {
+                const unsigned int my_unit = lane < n_tail ? list[first + lane] : 0u;
+#pragma unroll 1
+                for (int base = 0; base < n_tail * kR; base += kWave) {
+                    const int idx = base + lane;
+                    bool pass = false;
+                    const int u = __shfl((int)my_unit, (idx / kR) & (kWave - 1), kWave) * kR + idx % kR;
+                    if (idx < n_tail * kR) {
+                        const int i = u * xth;
+                        const double dXw = c_base[i + d] - c_base[i];
+                        // (fast mode: a window inside the band is listed, not noted -- phase 3b meets it again and notes it
+                        // there; a tail that goes back to chunk form would otherwise note its band windows twice)
+                        bool und_w = false;
+                        pass = exact_mode ? depth_pass(dXw, inv_d, dd, dmin, rule.eps, true, und_w) : dXw * inv_d >= thr_lo;
+                    }
+                    const unsigned long long mask = ballot64(pass);
+                    if (pass) list[first + count + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)u;
+                    count += (unsigned int)__popcll(mask);
+                }
+                if (sparse || count <= (unsigned int)kWave) {
+                    n_live = first;
+                } else {
+                    if (lane < n_tail) list[first + lane] = my_unit;
+                    count = 0;
+                }
+            }
+            TLS_CHECK(*ap, (unsigned int)n_live + count <= (unsigned int)n_units, kChkSinglesCap);
+            if (lane == 0) { rt.live[row] = (unsigned int)n_live; rt.singles[row] = count; }
+        }
+        pc.mark(25);
+        __syncthreads();
+        if (wave == 0) {   // exclusive scan of the batch counts over the rows
+            unsigned int carry = 0;
+            for (int r0 = 0; r0 < n_rows; r0 += kWave) {
+                const int row = r0 + lane;
+                unsigned int mine = 0;
+                if (row < n_rows) mine = (rt.live[row] + kWave - 1) / kWave + (rt.singles[row] + kWave - 1) / kWave;
+                const unsigned int incl = wave_inclusive_sum_u32(mine);
+                if (row < n_rows) rt.batch_start[row] = carry + incl - mine;
+                carry += (unsigned int)lane_value((int)incl, kWave - 1);
+            }
+            if (lane == 0) { rt.batch_start[n_rows] = carry; *rt.next_batch = 0; }
+            if (ap->phase_cycles && lane == 0) {
+                unsigned int kept = 0, singles = 0;
+                for (int row = 0; row < n_rows; ++row) { kept += rt.live[row]; singles += rt.singles[row]; }
+                atomicAdd(&ap->phase_cycles[33], (unsigned long long)kept);
+                atomicAdd(&ap->phase_cycles[34], (unsigned long long)singles);
+                atomicAdd(&ap->phase_cycles[35], (unsigned long long)carry);
+            }
+        }
+        __syncthreads();
+        pc.mark(6);
+
+        // ---- phase 3b: sliding dot products ON X, 64 live units of one duration per wave (core.py:59-74) ----
+        {
+            const unsigned int total_batches = (unsigned int)__builtin_amdgcn_readfirstlane((int)rt.batch_start[n_rows]);
+            int row = n_rows > 0 ? n_rows - 1 : 0;
+            for (;;) {
+                unsigned int gq = 0;
+                if (lane == 0) gq = atomicAdd(rt.next_batch, 1u);
+                gq = (unsigned int)__builtin_amdgcn_readfirstlane((int)gq);
+                if (gq >= total_batches) break;
+                const unsigned int gg = total_batches - 1 - gq;
+                while (gg < (unsigned int)__builtin_amdgcn_readfirstlane((int)rt.batch_start[row])) --row;
+                const int k = __builtin_amdgcn_readfirstlane(k_lo + row);
+                const int d = widths_c[k].width, L = widths_c[k].q_len, xth = widths_c[k].xth;
+                const int q_offset = widths_c[k].q_offset, list_base = widths_c[k].list_base;
+                const double overshoot = widths_c[k].overshoot, sum_q2 = widths_c[k].sum_q2;
+                const double inv_d = widths_c[k].inv_d, dd = (double)d;
+                const int tiled = widths_c[k].tiled;
+                const int n_singles = __builtin_amdgcn_readfirstlane((int)rt.singles[row]);
+                const int n_live = __builtin_amdgcn_readfirstlane((int)rt.live[row]);
+                const unsigned int in_row = gg - (unsigned int)__builtin_amdgcn_readfirstlane((int)rt.batch_start[row]);
+                const unsigned int chunk_batches = ((unsigned int)n_live + kWave - 1) / kWave;
+                const bool relisted = in_row >= chunk_batches;
+                const unsigned int slot = (relisted ? in_row - chunk_batches : in_row) * kWave + lane;
+                const bool have = slot < (unsigned int)(relisted ? n_singles : n_live);
+                const int unit = have ? (int)chunk_list[list_base + (relisted ? n_live : 0) + slot] : 0;
+                const const_f64_ptr g = g_all + q_offset;
+                const int Lx = L + 1;   // difference taps: one more than the row
+                const unsigned int evals_before = n_eval;
+                if (COUNTING && ap->counters) {
+                    const int reach = (tiled && !relisted) ? (kR - 1) * xth : 0;
+                    n_issued += (unsigned long long)((Lx + reach + kU - 1) / kU * kU) * (reach ? kR : 1);
+                }
+                if (tiled && !relisted) {
+                    const int b = unit * kR * xth;
+                    TLS_CHECK(*ap, !have || (b >= 0 && b + (Lx + (kR - 1) * xth + kU - 1) / kU * kU <= M + 1 + region_pad), kChkDotWindow);
+                    const double* e = X + b;
+                    double Bv[kR], Av[kR];
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) { Bv[r] = 0.0; Av[r] = sum_q2; }
+                    switch (xth) {
+                        case 1: dot_windows<true, 1>(e, g, Lx, Bv); break;
+                        case 2: dot_windows<true, 2>(e, g, Lx, Bv); break;
+                        case 3: dot_windows<true, 3>(e, g, Lx, Bv); break;
+                        case 4: dot_windows<true, 4>(e, g, Lx, Bv); break;
+                        case 5: dot_windows<true, 5>(e, g, Lx, Bv); break;
+                        default: dot_windows_rt<true>(e, g, Lx, xth, Bv); break;
+                    }
+                    if (have)
+                        consider_cells<UNIFORM_W, false, kR, COUNTING>(lead, c_base, b, xth, d, inv_d, dd, rule, overshoot, Av, Bv, k, n_eval, undecided, widths_c, X);
+                } else {
+                    const int i = unit * xth;
+                    TLS_CHECK(*ap, !have || (i >= 0 && i + (Lx + kU - 1) / kU * kU <= M + 1 + region_pad), kChkDotWindow);
+                    const double* e = X + i;
+                    double B0 = 0.0;
+                    for (int t0 = 0; t0 < Lx; t0 += kU) {
+                        const const_f64_ptr gs = g + t0;
+                        double taps[kU], x[kU];
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) taps[u] = gs[u];
+                        load_taps<true>(e + t0, x);
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) B0 = fma(taps[u], x[u], B0);   // one accumulator, taps in order: the tiled form's rounding
+                    }
+                    if (have) consider<UNIFORM_W, false>(lead, c_base[i], c_base[i + d], i, inv_d, dd, rule, overshoot, sum_q2, B0, k, n_eval, undecided, widths_c, X);
+                }
+                if constexpr (COUNTING) n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
+            }
+        }
+        pc.mark(7);
+        } else {
+            // The noted windows, one wavefront each: decided by the reference's expression on X = k - numpy.cumsum; a window
+            // that passes is evaluated -- lanes over the template taps, flux from global memory through the stashed order,
+            // the patch as an index mapping -- and meets lane 0's lead with the window sum of the plain scan it was noted with.
+            const int n_band = __builtin_amdgcn_readfirstlane(s_work[4]);
+            for (int e0 = wave; e0 < n_band; e0 += nw) {
+                const int k = __builtin_amdgcn_readfirstlane(band_list[e0].k);
+                const int i = __builtin_amdgcn_readfirstlane(band_list[e0].i);
+                const double dX_noted = band_list[e0].dX;
+                const int d = widths_c[k].width, L = widths_c[k].q_len, q_offset = widths_c[k].q_offset;
+                const double overshoot = widths_c[k].overshoot, sum_q2 = widths_c[k].sum_q2, inv_d = widths_c[k].inv_d;
+                const double dd = (double)d;
+                const double dX_exact = X[i + d] - X[i];
+                if (!((1.0 - (dd - dX_exact) / dd) > dmin)) continue;   // core.py:58 on the reference's bits
+                const double* qg = ap->q + q_offset;
+                double Bs = 0.0;
+                for (int tt = lane; tt < L; tt += kWave) {
+                    const int pp = i + tt, src = pp < n ? pp : pp - n;
+                    Bs = fma(qg[tt], 1.0 - y_c[perm_g[src]], Bs);
+                }
+#pragma unroll
+                for (int delta = kWave / 2; delta > 0; delta >>= 1) Bs += __shfl_down(Bs, delta, kWave);
+                if (lane == 0) {
+                    bool und_none = false;
+                    // (valued like every other cell of the period: on the plain scan's window sum)
+                    consider<UNIFORM_W, false, true>(lead, 0.0, dX_noted, i, inv_d, dd, rule, overshoot, sum_q2, Bs, k, n_eval, und_none, widths_c, X);
+                    if constexpr (COUNTING) n_steps += (unsigned long long)L;
+                }
+            }
+            if (ap->phase_cycles && tid == 0) atomicAdd(&ap->phase_cycles[38], (unsigned long long)n_band);
+        }
+        // fast mode: a window too close to transit_depth_min to call sends the period (this light curve) through exact mode
+        if (undecided) s_work[flag_slot] = 1;
+        __syncthreads();
+        const int any_undecided = __builtin_amdgcn_readfirstlane(s_work[flag_slot]);
+        if (tid == 0) s_work[3 - flag_slot] = 0;
+        flag_slot = 3 - flag_slot;
+        // noted band windows (and nothing that voids the attempt): the exact prefix pass and the resolution above; more of
+        // them than the list holds: a second search in exact mode
+        if (rule.band_count != nullptr && any_undecided == 0) {
+            const int n_band = __builtin_amdgcn_readfirstlane(s_work[4]);
+            if (n_band > 0) {
+                if (n_band <= kBandCap) {
+                    resolve_band = true;
+                    kept_lead = lead; kept_eval = n_eval; kept_steps = n_steps; kept_issued = n_issued;
+                }
+                if (ap->phase_cycles && tid == 0) atomicAdd(&ap->phase_cycles[37], 1ull);
+                if (ap->n_curves > 1) { curve_exact = true; --curve; continue; }
+                retry_exact = true;
+                break;
+            }
+        }
+        if (any_undecided != 0 && !exact_mode) {
+            if (ap->phase_cycles && tid == 0) atomicAdd(&ap->phase_cycles[37], 1ull);
+            if (ap->n_curves > 1) { curve_exact = true; --curve; continue; }
+            retry_exact = true;
+            break;
+        }
+        pc.mark(21);
+
+        // ---- phase 4: argmin over the workgroup (core.py:70-74, 183-188) ------------------------------
+        Best best = settle_best<UNIFORM_W, false>(lead, widths_c, X);
+#pragma unroll
+        for (int delta = kWave / 2; delta > 0; delta >>= 1) {
+            Best o = shfl_down_best(best, delta);
+            if (better(o, best)) best = o;
+        }
+        if (lane == 0) wbest[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            Best gb = wbest[0];
+            for (int u = 1; u < nw; ++u) if (better(wbest[u], gb)) gb = wbest[u];
+            const double datapoints = (double)n;
+            double chi2 = INFINITY, depth = 0.0;
+            long long row = 0;
+            if (n_rows > 0) {
+                const double w0_c = ap->n_curves > 1 ? ap->curve_w0[curve] : ap->w0;
+                const double S0_c = ap->n_curves > 1 ? ap->curve_S0[curve] : ap->S0;
+                const double stat = (gb.stat < INFINITY) ? S0_c + w0_c * gb.stat : INFINITY;
+                if (stat < datapoints) {
+                    chi2 = stat; row = ap->widths[gb.k].row; depth = 1.0 - gb.td;
+                } else {
+                    chi2 = datapoints; row = ap->widths[k_lo].row; depth = 0.0;
+                }
+            }
+            const long long o = (long long)curve * ap->n_periods + p;
+            ap->out_chi2[o] = chi2;
+            ap->out_row[o] = row;
+            ap->out_depth[o] = depth;
+        }
+        if (COUNTING && ap->counters) {
+#pragma unroll
+            for (int delta = kWave / 2; delta > 0; delta >>= 1) {
+                n_eval += __shfl_down(n_eval, delta, kWave);
+                n_steps += __shfl_down(n_steps, delta, kWave);
+            }
+            if (lane == 0 && n_eval) {
+                atomicAdd(&ap->counters[0], (unsigned long long)n_eval);
+                atomicAdd(&ap->counters[1], n_steps);
+            }
+            if (lane == 0 && n_issued) atomicAdd(&ap->counters[2], n_issued * kWave);
+        }
+        __syncthreads();
+        }  // light curves of the batch
+    }
+}
