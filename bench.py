@@ -290,6 +290,7 @@ def run_survey(h, args, inp):
             ctx.comm_allgather_staged(count_per_rank, n_slots)
 
     elapsed, kernel_ms = h.timed(step, finish, args.steps, args.warmup, prefill=n_slots if staged else 0)
+    h.timed_kernel = ctx.last_kernel()   # which search kernel the timed steps launched (roofline.kernel)
     if staged:  # outside the timed region: one gathered slot on the host
         g_chi2, g_row, g_depth = ctx.comm_fetch_staged(count_per_rank, n_slots, n_slots - 1, h.world)
         assert len(g_chi2) == count_per_rank * h.world
@@ -321,6 +322,8 @@ def run_shard(h, args, config, steps=None):
 
     n_steps = args.steps if steps is None else steps
     elapsed, kernel_ms = h.timed(step, lambda: None, n_steps, min(args.warmup, n_steps))
+    if not getattr(h, 'timed_kernel', None):
+        h.timed_kernel = ctx.last_kernel()
     own_kernel_ms = [h.own_kernel_ms]
     argmin = None
     if h.collective == "rccl":
@@ -659,7 +662,8 @@ def main():
         }
         out["roofline"].update({
             "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": "tls_search_kernel", "kernel_ms": 1e3 * kernel_s,
+            "kernel": "tls_slim_kernel" if getattr(h, "timed_kernel", "") == "slim" else "tls_search_kernel", "kernel_variant": getattr(h, "timed_kernel", ""),
+            "kernel_ms": 1e3 * kernel_s,
             "algorithmic_bytes_per_launch": algo_bytes,
             "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "note": "algorithmic bytes (24*N+24 B per period, SURVEY 8d) over the kernel time; nominal for the "

@@ -1787,8 +1787,12 @@ const char* tls_last_kernel(const tls_ctx* ctx) { return ctx ? ctx->last_kernel 
 int tls_plan_info(const tls_ctx* ctx, tls_counters* counters, int64_t* lds_bytes, int64_t* n_blocks, int64_t* resident) {
     if (!ctx || !ctx->prepared) return TLS_E_STATE;
     if (counters) { *counters = ctx->plan_counters; counters->evaluated_cells = -1; counters->inner_steps = -1; counters->issued_fma = -1; }
-    if (lds_bytes) *lds_bytes = (int64_t)ctx->lds_bytes;
-    if (n_blocks) *n_blocks = ctx->blocks;
+    // (the launch shape of the kernel a plain search of this plan takes: the four-slot kernel where the plan fits it and
+    // neither pruning nor the fp32 screen is the host's choice)
+    const bool slim = ctx->slim_blocks > 0 && ctx->uniform_w && !ctx->prune_kernel &&
+                      !(ctx->screen_kernel && screen_admissible(ctx->resident, ctx->uniform_w, ctx->e_abs_max));
+    if (lds_bytes) *lds_bytes = (int64_t)(slim ? ctx->slim_lds : ctx->lds_bytes);
+    if (n_blocks) *n_blocks = slim ? ctx->slim_blocks : ctx->blocks;
     if (resident) *resident = ctx->resident ? 1 : 0;
     return TLS_OK;
 }

@@ -21,6 +21,14 @@ constexpr int kSlimThreads = 256;
 constexpr int kSlimWaves = kSlimThreads / kWave;
 constexpr int kSlimPer = 20;          // samples of the folded order a thread keeps in registers across the gather
 constexpr int kSlimScratchBytes = 1328;   // >= sizeof(Cumsum2Scratch); the per-row tables share its first bytes
+#ifndef TLS_SLIM_TAIL_MAX
+#define TLS_SLIM_TAIL_MAX 20
+#endif
+#ifndef TLS_SLIM_TAIL_SINGLES
+#define TLS_SLIM_TAIL_SINGLES 64
+#endif
+constexpr int kSlimTailMax = TLS_SLIM_TAIL_MAX;          // a row's last, mostly empty batch is re-listed window by window up to this many units
+constexpr int kSlimTailSingles = TLS_SLIM_TAIL_SINGLES;  // ... if that leaves at most this many windows
 constexpr int kSlimIdxBits = 13;      // a sort record: sub-bucket key (19 bits) | original index (13 bits)
 __host__ __device__ constexpr int slim_header_bytes() { return 128 + kSlimWaves * 24 + 48 + kSlimScratchBytes; }   // wsum | wbest | s_work | scratch
 static_assert(slim_header_bytes() % 16 == 0, "the region behind the header holds doubles read in pairs");
@@ -134,7 +142,12 @@ tls_slim_kernel(const SearchArgs) {
         __syncthreads();
         unsigned int key[kSlimPer];
         {
-            constexpr int kF = 5;
+            // every time stamp of the thread is requested before the first is used: ONE L2 round trip per period, not one per
+            // group of divisions (nothing else is alive in registers at a period's start)
+#ifndef TLS_SLIM_FOLD_DEPTH
+#define TLS_SLIM_FOLD_DEPTH kSlimPer
+#endif
+            constexpr int kF = TLS_SLIM_FOLD_DEPTH;
             static_assert(kSlimPer % kF == 0, "the fold takes kF time stamps per step");
 #pragma unroll
             for (int j0 = 0; j0 < kSlimPer; j0 += kF) {
@@ -302,7 +315,10 @@ tls_slim_kernel(const SearchArgs) {
                 int row_lo = 0, row_hi = 0;
                 unsigned long long band_mask = 0ull;
                 const unsigned long long valid_mask = ballot64(unit < units0);
-                constexpr int kRowBatch = 2;
+#ifndef TLS_SLIM_ROW_BATCH
+#define TLS_SLIM_ROW_BATCH 2
+#endif
+                constexpr int kRowBatch = TLS_SLIM_ROW_BATCH;
                 for (int k = k_lo; k < k_x; k += kRowBatch) {
                     int dv[kRowBatch];
                     double inv[kRowBatch], dC[kRowBatch];
@@ -456,7 +472,7 @@ tls_slim_kernel(const SearchArgs) {
             const bool sparse = n_live <= kSparseRow;
             const int n_tail = sparse ? n_live : (TLS_TAIL_RELIST ? (n_live & (kWave - 1)) : 0);
             const int first = n_live - n_tail;
-            if (tiled && n_tail > 0 && n_tail <= kTailMax && n_units >= (kR + 1) * kSparseRow && first + n_tail * kR <= n_units) {
+            if (tiled && n_tail > 0 && n_tail <= kSlimTailMax && n_units >= (kR + 1) * kSparseRow && first + n_tail * kR <= n_units) {
                 const unsigned int my_unit = lane < n_tail ? list[first + lane] : 0u;
 #pragma unroll 1
                 for (int base = 0; base < n_tail * kR; base += kWave) {
@@ -475,7 +491,7 @@ tls_slim_kernel(const SearchArgs) {
                     if (pass) list[first + count + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned int)u;
                     count += (unsigned int)__popcll(mask);
                 }
-                if (sparse || count <= (unsigned int)kWave) {
+                if (sparse || count <= (unsigned int)kSlimTailSingles) {
                     n_live = first;
                 } else {
                     if (lane < n_tail) list[first + lane] = my_unit;

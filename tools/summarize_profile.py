@@ -31,7 +31,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if "tls_search_kernel" in r["Kernel_Name"]:
+        if "tls_search_kernel" in r["Kernel_Name"] or "tls_slim_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         means[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
