@@ -707,6 +707,8 @@ def test_randomised_configurations_vs_oracle(gpu, oracle_lib, seed):
         if os.environ.get("TLS_FUZZ_VERBOSE"):
             print("fuzz", seed, case, len(t), dy is not None, kwargs, int(inp["table"].width.max()), flush=True)
         got = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
+        if os.environ.get("TLS_FUZZ_VERBOSE"):
+            print("fuzz kernel", gpu.last_kernel(), flush=True)
         want = oracle_search(oracle_lib, inp, periods=sel)
         assert_parity(got, want, len(inp["t"]), allow_tie=True)
         assert got[3]["evaluated_cells"] == int(want[3][1]), (case, kwargs)

@@ -108,16 +108,19 @@ def test_sharded_search_equals_single_process(tmp_path, oracle_lib, world):
 
 
 @pytest.mark.parametrize("fixture,limit", [("k2_90d", 1.05), ("tess_27d", 1.06), ("kepler_4yr_8", 1.06), ("k2_90d_500", 1.05),
-                                           ("kepler_4yr_8_fast", 1.07)])
+                                           ("kepler_4yr_8_fast", 1.07), ("k2_90d_slim", 1.085)])
 def test_time_model_balances_measured_period_cycles(fixture, limit, monkeypatch):
     """The shard boundaries against MEASURED per-period shader cycles (tls_debug_period_cycles on an MI355X,
     tools/gpu_cost_model.py; committed as tests/golden/period_cycles_*.npz): blocks placed by the time model of
     tls_period_costs are balanced in measured time at 2, 4 and 8 ranks; blocks placed by trial cells alone (round 2)
     are not.  The round-3 fixtures of the long series were measured in exact prefix-sum mode (TLS_FAST_SLAB=0, which
     the model honours like the search: `options`); `kepler_4yr_8_fast` is the same grid in round 4's default: fast mode, second
-    attempts of the periods that hit the undecided band included, the expected hitters in exact mode from the start."""
+    attempts of the periods that hit the undecided band included, the expected hitters in exact mode from the start.
+    `k2_90d` is the classic LDS-resident kernel (`slim = 0`), `k2_90d_slim` round 5's default for that series: four workgroups
+    per CU share its SIMDs, a period's cycles depend on its three neighbours (fit residual 26 % rms), and cells alone already
+    balance it to 1.11."""
     from tls_amd import synthetic
-    options = {"fast_slab": 0} if fixture in ("tess_27d", "kepler_4yr_8") else None
+    options = {"fast_slab": 0} if fixture in ("tess_27d", "kepler_4yr_8") else {"slim": 0} if fixture == "k2_90d" else None
     g = numpy.load(os.path.join(os.path.dirname(__file__), "golden", "period_cycles_%s.npz" % fixture))
     sigma = float(g["sigma_ppm"]) * 1e-6 or None
     t, f, kw = synthetic.config(str(g["config"]), sigma=sigma)
@@ -127,7 +130,8 @@ def test_time_model_balances_measured_period_cycles(fixture, limit, monkeypatch)
     assert len(cycles) == len(periods)
     job = shard.ShardedSearch(0, 1)
     job.plan(inp["t"], periods, inp["table"], inp["params"], y=inp["y"], options=options)
-    assert job.slots in (256, 512)
+    assert job.slots in (256, 512, 1024)
+    assert (job.slots == 1024) == (fixture == "k2_90d_slim")
     worst_model = worst_cells = 0.0
     for ranks in (2, 4, 8):
         for cost, label in ((job.times, "model"), (job.costs.astype(float), "cells")):
@@ -139,7 +143,7 @@ def test_time_model_balances_measured_period_cycles(fixture, limit, monkeypatch)
             else:
                 worst_cells = max(worst_cells, imb)
     assert worst_model <= limit, (worst_model, worst_cells)
-    assert worst_cells >= 1.15, worst_cells   # what balancing cells alone leaves on the table
+    assert worst_cells >= (1.10 if fixture == "k2_90d_slim" else 1.15), worst_cells   # what balancing cells alone leaves on the table
 
 
 def test_partition_by_makespan_fills_whole_rounds():

@@ -864,7 +864,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         if (er != hipSuccess) { --ctx->ev_used; return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er)); }
         a.park_cells = ctx->d_park.ptr;
         e = launch_variant<true, true, false, unsigned short, false, false, true>(ctx, a, ctx->blocks);
-    } else if (ctx->slim_blocks > 0 && ctx->uniform_w && !prune && !debug_folded && !debug_prefix && !period_cycles) {
+    } else if (ctx->slim_blocks > 0 && ctx->uniform_w && !prune && !debug_folded && !debug_prefix) {
         // four period slots per CU (tls_slim_kernel.hip.h): plain variant, uniform weights, 256-thread workgroups
         kernel_name = "slim";
         a.lds_bytes = (long long)ctx->slim_lds;
@@ -2245,8 +2245,15 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         const bool resident = resident_bytes <= kLdsPerCU && n <= 65535;
         const bool two_per_cu = resident && kLdsPerCU / resident_bytes >= 2;
         const bool prune = pruning_pays(po, widths, sigma, params->transit_depth_min, resident);
+        // the four-slot kernel where tls_prepare takes it (a normalised flux admits the fp32 screen: the host's choice between
+        // plain and screen is the noise level's)
+        const long long slim_need = tlsdev::slim_lds_bytes((int)n, (int)M, tlsdev::region_pad_for(widest_stride), (int)widths.size());
+        const bool slim_wanted = po.exact_prefix != 1 && (po.slim == 1 || (po.slim < 0 && po.prune < 0 && po.screen32 < 0));
+        const bool slim = resident && slim_wanted && po.threads <= 0 && slim_need > 0 && 4 * (size_t)slim_need <= kLdsPerCU && !prune &&
+                          !screen_pays(po, widths, sigma, params->transit_depth_min, true);
         double a0, aN, b, c;
         if (!resident) { a0 = 458384.0; aN = 4.5716; b = 0.4604; c = 0.03275; }        // HBM slab variant (TESS 27 d + Kepler 4 yr)
+        else if (slim) { a0 = 59538.0; aN = 0.0; b = 1.553; c = 0.2125; }               // LDS-resident, four 256-thread workgroups per CU (90 d at 50 ppm, round 5)
         else if (prune) { a0 = 116100.0; aN = 0.0; b = 1.906; c = 0.0125; }             // LDS-resident, pruning kernel (90 d at 500 ppm)
         else if (two_per_cu) { a0 = 54603.0; aN = 0.0; b = 0.7823; c = 0.1888; }        // LDS-resident, two 512-thread workgroups per CU (90 d)
         else { a0 = 56564.0; aN = 0.0; b = 0.3189; c = 0.1267; }                        // LDS-resident, one 1024-thread workgroup per CU (100 d)
@@ -2272,7 +2279,7 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         // device is asked, a process without one plans for an MI355X), two workgroups per CU when two folded series fit
         // its LDS.  A block of n periods takes ceil(n / this) rounds, not n / this.  (The cycle coefficients above are
         // MI355X measurements; only their ratios matter.)
-        if (workgroups_in_flight) *workgroups_in_flight = (two_per_cu ? 2 : 1) * visible_compute_units();
+        if (workgroups_in_flight) *workgroups_in_flight = (slim ? 4 : two_per_cu ? 2 : 1) * visible_compute_units();
     } else if (workgroups_in_flight) {
         *workgroups_in_flight = visible_compute_units();
     }

@@ -129,6 +129,8 @@ tls_slim_kernel(const SearchArgs) {
         const int p = ap->order[work];
         TLS_CHECK(*ap, p >= 0 && p < ap->n_periods, kChkWorkItem);
         const double period = ap->periods[p];
+        long long t_period = 0;
+        if (ap->period_cycles && tid == 0) t_period = clock64();
         PhaseClock pc;
         pc.start(ap->phase_cycles);
 
@@ -698,5 +700,6 @@ tls_slim_kernel(const SearchArgs) {
         }
         __syncthreads();
         }  // light curves of the batch
+        if (ap->period_cycles && tid == 0) atomicAdd(&ap->period_cycles[p], (unsigned long long)(clock64() - t_period));
     }
 }

@@ -35,7 +35,7 @@ for case in cases:
     coef, *_ = numpy.linalg.lstsq(A, cyc, rcond=None)
     fit = A @ coef
     resid = (cyc - fit) / cyc
-    rec = {"points": n, "periods": len(periods), "resident": ctx.plan_info()["resident"],
+    rec = {"points": n, "periods": len(periods), "resident": ctx.plan_info()["resident"], "kernel": ctx.last_kernel(),
            "a_per_point": coef[0], "b_per_cell": coef[1], "c_per_tap": coef[2],
            "fixed_share": coef[0] * n * len(periods) / cyc.sum(), "cells_share": float((coef[1] * cells).sum() / cyc.sum()),
            "taps_share": float((coef[2] * taps).sum() / cyc.sum()),
@@ -48,7 +48,7 @@ for case in cases:
     out[case] = rec
     print(case, json.dumps(rec), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    numpy.savez_compressed("gpurun_out/cost_model_data_%s.npz" % case.replace("/", "_"), cycles=cyc, cells=cells, taps=taps,
+    numpy.savez_compressed("gpurun_out/cost_model_data_%s%s.npz" % (case.replace("/", "_"), ("_slim" + os.environ["TLS_SLIM"]) if os.environ.get("TLS_SLIM") else ""), cycles=cyc, cells=cells, taps=taps,
                            periods=periods, n=n, resident=rec["resident"], sigma=float(numpy.std(inp["y"])))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/cost_model_fit.json", "w"), indent=1)
