@@ -17,7 +17,7 @@ for d in ("p1","p2","p3","p4"):
     for f in glob.glob("$OUT/%s/*counter_collection.csv" % d):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "tls_search" in r["Kernel_Name"]:
+            if "tls_search" in r["Kernel_Name"] or "tls_slim" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in sorted(agg.items()):
             print("%-28s %.4g" % (k, sum(v)/len(v)))
