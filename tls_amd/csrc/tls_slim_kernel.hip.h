@@ -29,13 +29,16 @@ constexpr int kSlimScratchBytes = 1328;   // >= sizeof(Cumsum2Scratch); the per-
 #endif
 constexpr int kSlimTailMax = TLS_SLIM_TAIL_MAX;          // a row's last, mostly empty batch is re-listed window by window up to this many units
 constexpr int kSlimTailSingles = TLS_SLIM_TAIL_SINGLES;  // ... if that leaves at most this many windows
+constexpr int kSlimBig = 24;           // a bucket beyond this many points (a commensurate period's pile) is ranked by the workgroup on exact phases
+constexpr int kSlimStageBytes = 2048;  // at least this much of the region stays free for the phases of such a pile
 constexpr int kSlimIdxBits = 13;      // a sort record: sub-bucket key (19 bits) | original index (13 bits)
 __host__ __device__ constexpr int slim_header_bytes() { return 128 + kSlimWaves * 24 + 48 + kSlimScratchBytes; }   // wsum | wbest | s_work | scratch
 static_assert(slim_header_bytes() % 16 == 0, "the region behind the header holds doubles read in pairs");
 static_assert(sizeof(Cumsum2Scratch) <= kSlimScratchBytes, "exact_cumsum's scratch does not fit the slim header");
 // sort buckets: as many as the region holds beside the records and the order, at most one per two points
+// (measured: giving the pile stage 4800 bytes at the price of 3 % fewer buckets cost the ordinary periods 2 %)
 __host__ __device__ inline int slim_buckets(int n, int RS) {
-    const long long room = (8LL * RS - 6LL * n) / 4;   // records 4n | bucket counters 4nb | ... | order 2n (the region's last bytes)
+    const long long room = (8LL * RS - 6LL * n - kSlimStageBytes) / 4;   // records 4n | bucket counters 4nb | pile stage | order 2n (the region's last bytes)
     const long long want = n / 2 > 16 ? n / 2 : 16;
     return (int)(room < want ? room : want);
 }
@@ -48,6 +51,90 @@ __host__ __device__ inline long long slim_lds_bytes(int n, int M, int region_pad
     return slim_header_bytes() + 8LL * RS;
 }
 
+// The piles of a commensurate period: buckets beyond kSlimBig points whose records tie on their key bits (slim_is_pile).
+// Every member's exact phase is formed ONCE into a stage, then every member counts the members in front of it -- (phase,
+// index), numpy's stable order.  Four, two or one pile at a time (what the largest one leaves of the stage), a group of threads
+// each.  Out of line: its registers are its own (called by every thread of the workgroup: it holds barriers).
+__device__ __forceinline__ bool slim_is_pile(const unsigned int* recs, int lo, int hi, int stage_cap) {
+    const int size = hi - lo;
+    if (size <= kSlimBig || size > stage_cap) return false;
+    const unsigned int r0 = recs[lo] >> kSlimIdxBits, rm = recs[lo + size / 2] >> kSlimIdxBits, r1 = recs[hi - 1] >> kSlimIdxBits;
+    return r0 == rm || rm == r1;
+}
+// (the pointers are kept in their address spaces by TYPE: through generic pointers the member loops came out as FLAT loads)
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) T* slim_lds_ptr(T* p) {
+    typedef __attribute__((address_space(3))) T* lds_t;
+    const unsigned int v = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(uintptr_t)(lds_t)p);
+    return (lds_t)(uintptr_t)v;
+}
+__device__ __noinline__ void slim_rank_piles(const double* t_, double period_, const unsigned int* recs_, const unsigned int* cnt_,
+                                             unsigned short* perm_, double* stage_, int stage_cap_, const unsigned short* big_list_, int n_big_, int* flags_) {
+    typedef __attribute__((address_space(1))) const double* glob_f64;
+    typedef __attribute__((address_space(3))) const unsigned int* lds_u32;
+    typedef __attribute__((address_space(3))) unsigned short* lds_u16;
+    typedef __attribute__((address_space(3))) const unsigned short* lds_cu16;
+    typedef __attribute__((address_space(3))) double* lds_f64;
+    typedef __attribute__((address_space(3))) const unsigned long long* lds_cu64;
+    const glob_f64 t = (glob_f64)global_arg(t_);
+    const double period = uniform_f64(period_);
+    const lds_u32 recs = slim_lds_ptr(recs_);
+    const lds_u32 cnt = slim_lds_ptr(cnt_);
+    const lds_u16 perm = slim_lds_ptr(perm_);
+    const lds_f64 stage = slim_lds_ptr(stage_);
+    const lds_cu16 big_list = slim_lds_ptr(big_list_);
+    __attribute__((address_space(3))) int* const flags = slim_lds_ptr(flags_);
+    const int stage_cap = uniform_i32(stage_cap_), n_big = uniform_i32(n_big_);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    constexpr unsigned int kIdx = (1u << kSlimIdxBits) - 1u;
+    // the largest pile decides how many are ranked side by side: 4, 2 or 1 groups of threads, each with its share of the stage
+    // (every thread looks at its share of the list; the verdicts meet in an LDS word the caller has zeroed)
+    int wide = 0;
+    for (int gb = tid; gb < n_big; gb += nt) {
+        const int b = (int)big_list[gb];
+        const int m = (int)cnt[b] - (b ? (int)cnt[b - 1] : 0);
+        wide |= m > stage_cap / 4 ? (m > stage_cap / 2 ? 3 : 1) : 0;
+    }
+    if (wide) __hip_atomic_fetch_or(flags, wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    const int verdict = __builtin_amdgcn_readfirstlane(*flags);
+    const int groups = verdict == 0 ? 4 : verdict == 1 ? 2 : 1;
+    const int per = nt / groups, group = tid / per, first = tid - group * per;
+    const lds_f64 mine = stage + group * (stage_cap / groups);
+    const lds_cu64 bits = (lds_cu64)mine;
+    for (int g0 = 0; g0 < n_big; g0 += groups) {   // (the same trips for every thread: the barriers below are the workgroup's)
+        const int gb = g0 + group;
+        int lo = 0, m = 0;
+        if (gb < n_big) {
+            const int b = (int)big_list[gb];
+            lo = b ? (int)cnt[b - 1] : 0;
+            m = (int)cnt[b] - lo;
+        }
+        // (a phase is >= 0: its bit pattern orders like its value, and two integer compares take no branch)
+        for (int j = first; j < m; j += per) mine[j] = fold_phase(t[recs[lo + j] & kIdx], period, 0.0);
+        __syncthreads();
+        for (int j = first; j < m; j += per) {
+            const unsigned int i = recs[lo + j] & kIdx;
+            const unsigned long long ph = bits[j];
+            unsigned int rank = 0;
+            constexpr int kB = 8;   // members read per step (the lanes of a group read the same words: broadcasts)
+            for (int u0 = 0; u0 < m; u0 += kB) {
+                unsigned long long ph2[kB];
+                unsigned int r2[kB];
+#pragma unroll
+                for (int u = 0; u < kB; ++u) { const int uu = u0 + u < m ? u0 + u : m - 1; ph2[u] = bits[uu]; r2[u] = recs[lo + uu] & kIdx; }
+#pragma unroll
+                for (int u = 0; u < kB; ++u) {
+                    const unsigned int before = (unsigned int)(ph2[u] < ph) | ((unsigned int)(ph2[u] == ph) & (unsigned int)(r2[u] < i));
+                    rank += before & (unsigned int)(u0 + u < m);
+                }
+            }
+            perm[lo + rank] = (unsigned short)i;
+        }
+        __syncthreads();   // (the next piles' phases go over these)
+    }
+}
+
 // a value the compiler must not carry across phases in a register (or a spill slot): per-thread indices tid + j * nt are
 // cheaper to form again than to keep
 __device__ __forceinline__ int slim_fresh(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -55,6 +142,131 @@ __device__ __forceinline__ int slim_fresh(int v) { asm volatile("" : "+v"(v)); r
 __device__ __noinline__ int slim_tie_before(const double* t, double period, int i_other, int i_mine) {
     const double ph = fold_phase(t[i_mine], period, 0.0), ph2 = fold_phase(t[i_other], period, 0.0);
     return (ph2 < ph || (ph2 == ph && i_other < i_mine)) ? 1 : 0;
+}
+
+// Phase 1 of a period: fold + stable sort by phase (core.py:119-120) -> perm[k] = original index of the k-th folded point, in
+// the last 2n bytes of the region.
+__device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, double period, int RS, double* X, unsigned int* wsum, int* s_work,
+                                                unsigned char* scratch, PhaseClock& pc) {
+    constexpr int nt = kSlimThreads;
+    const int tid = threadIdx.x;
+    const int nb = slim_buckets(n, RS);
+    unsigned int* recs = reinterpret_cast<unsigned int*>(X);                           // [n] sort records, bucket by bucket
+    unsigned int* cnt = recs + n;                                                      // [nb]
+    unsigned short* perm = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(X) + 8LL * RS) - n;   // [n], the region's last bytes
+    // ---- phase 1: fold + stable sort by phase (core.py:119-120), on 32-bit keys -------------------
+    // A point's key stays in a register from the fold to its rank.  Bucket = floor(key * nb / 2^32); INSIDE a bucket the
+    // low word of key * nb is monotone in the key: its top 19 bits and the index make the point's sort record.  Records
+    // are scattered bucket by bucket (any order inside one); a point's place is its bucket's start plus the records of
+    // the bucket in front of it -- decided by the records, and by the exact phases (then the index: numpy's stable
+    // order) for the pairs whose 19 bits tie: two phases within 2^-30, or the piled-up phases of a commensurate period.
+    for (int b = tid; b < nb; b += nt) cnt[b] = 0;
+    if (tid == 0) { s_work[5] = 0; s_work[6] = 0; }
+    __syncthreads();
+    unsigned int key[kSlimPer];
+    {
+        // every time stamp of the thread is requested before the first is used: ONE L2 round trip per period, not one per
+        // group of divisions (nothing else is alive in registers at a period's start)
+#ifndef TLS_SLIM_FOLD_DEPTH
+#define TLS_SLIM_FOLD_DEPTH kSlimPer
+#endif
+        constexpr int kF = TLS_SLIM_FOLD_DEPTH;
+        static_assert(kSlimPer % kF == 0, "the fold takes kF time stamps per step");
+#pragma unroll
+        for (int j0 = 0; j0 < kSlimPer; j0 += kF) {
+            const int base = slim_fresh(tid) + j0 * nt;
+            double tv[kF];
+#pragma unroll
+            for (int j = 0; j < kF; ++j) { const int i = base + j * nt; tv[j] = t[i < n ? i : 0]; }
+#pragma unroll
+            for (int j = 0; j < kF; ++j) {
+                const int i = base + j * nt;
+                key[j0 + j] = phase_key(fold_phase(tv[j], period, 0.0));
+                if (i < n) atomicAdd(&cnt[__umulhi(key[j0 + j], (unsigned int)nb)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    pc.mark(0);
+    block_exclusive_scan(cnt, nb, wsum);
+    pc.mark(1);
+#pragma unroll
+    for (int j = 0; j < kSlimPer; ++j) {
+        const int i = slim_fresh(tid) + j * nt;
+        if (i < n) {
+            const unsigned int slot = atomicAdd(&cnt[__umulhi(key[j], (unsigned int)nb)], 1u);
+            recs[slot] = ((key[j] * (unsigned int)nb) & ~((1u << kSlimIdxBits) - 1u)) | (unsigned int)i;
+        }
+    }
+    __syncthreads();
+    pc.mark(2);
+    // piles: a period commensurate with the cadence folds the series onto a few dozen phase values; ranking a pile record
+    // by record would be quadratic in exact-phase comparisons (two divisions each).  A bucket beyond kSlimBig points whose
+    // records tie on their key bits (slim_is_pile: every member evaluates the same test) is left out here, listed by the
+    // member whose record heads it, and ranked below on exact phases formed once (slim_rank_piles).  A bucket that is merely
+    // full -- a NEARLY commensurate period: many points, distinct keys -- is ranked here like any other.
+    unsigned short* big_list = reinterpret_cast<unsigned short*>(scratch);
+    const int stage_off = (4 * n + 4 * nb + 7) & ~7;
+    const int stage_cap = (8 * RS - 2 * n - stage_off) / 8;
+    double* stage = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(X) + stage_off);
+    {
+        // (cnt[b] is now the END of bucket b)
+        auto before = [&](unsigned int other, unsigned int mine) -> int {
+            if (((other ^ mine) >> kSlimIdxBits) != 0u) return other < mine ? 1 : 0;
+            if (other == mine) return 0;
+            return slim_tie_before(t, period, (int)(other & ((1u << kSlimIdxBits) - 1u)), (int)(mine & ((1u << kSlimIdxBits) - 1u)));
+        };
+        constexpr int kG = 5, kWin = 4;   // points ranked together; records of a bucket read up front
+        static_assert(kSlimPer % kG == 0, "the rank takes kG points per step");
+        static_assert(kSlimPer <= 32, "one bit per point of the thread");
+        unsigned int heads = 0;
+#pragma unroll
+        for (int j0 = 0; j0 < kSlimPer; j0 += kG) {
+            int lo[kG], hi[kG];
+            unsigned int mine[kG], win[kG][kWin];
+            const int base = slim_fresh(tid) + j0 * nt;
+#pragma unroll
+            for (int g = 0; g < kG; ++g) {
+                const int i = base + g * nt;
+                const unsigned int b = __umulhi(key[j0 + g], (unsigned int)nb);
+                mine[g] = ((key[j0 + g] * (unsigned int)nb) & ~((1u << kSlimIdxBits) - 1u)) | (unsigned int)i;
+                lo[g] = b ? (int)cnt[b - 1] : 0;
+                hi[g] = i < n ? (int)cnt[b] : lo[g];
+                if (hi[g] - lo[g] > kSlimBig) {   // (rare)
+                    if (slim_is_pile(recs, lo[g], hi[g], stage_cap)) {
+                        if (recs[lo[g]] == mine[g]) heads |= 1u << (j0 + g);   // the member whose record heads the bucket lists it
+                        hi[g] = lo[g];   // ranked below: nothing to do here
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < kG; ++g)
+#pragma unroll
+                for (int u = 0; u < kWin; ++u) win[g][u] = recs[lo[g] + u < hi[g] ? lo[g] + u : lo[g]];
+#pragma unroll
+            for (int g = 0; g < kG; ++g) {
+                int rank = 0;
+#pragma unroll
+                for (int u = 0; u < kWin; ++u) if (lo[g] + u < hi[g]) rank += before(win[g][u], mine[g]);
+                for (int s2 = lo[g] + kWin; s2 < hi[g]; ++s2) rank += before(recs[s2], mine[g]);
+                if (lo[g] < hi[g]) perm[lo[g] + rank] = (unsigned short)(mine[g] & ((1u << kSlimIdxBits) - 1u));
+            }
+        }
+        if (heads != 0u) {   // (rare)
+#pragma unroll
+            for (int j = 0; j < kSlimPer; ++j) {
+                if ((heads >> j) & 1u) {
+                    const int at = atomicAdd(&s_work[5], 1);
+                    if (at < kSlimScratchBytes / 2) big_list[at] = (unsigned short)__umulhi(key[j], (unsigned int)nb);   // (n / kSlimBig < 664 piles: always)
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int n_big = __builtin_amdgcn_readfirstlane(s_work[5]);
+        if (n_big > 0) slim_rank_piles(t, period, recs, cnt, perm, stage, stage_cap, big_list, n_big, &s_work[6]);
+    }
 }
 
 template <bool COUNTING>
@@ -82,13 +294,10 @@ tls_slim_kernel(const SearchArgs) {
     rt.batch_start = rt.singles + ap->n_widths;
     rt.next_batch = rt.batch_start + (ap->n_widths + 1);
     double* X = reinterpret_cast<double*>(smem + slim_header_bytes());                 // f, then X: RS doubles
-    const int nb = slim_buckets(n, RS);
-    unsigned int* recs = reinterpret_cast<unsigned int*>(X);                           // [n] sort records, bucket by bucket
-    unsigned int* cnt = recs + n;                                                      // [nb]
     unsigned short* perm = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(X) + 8LL * RS) - n;   // [n], the region's last bytes
     unsigned int* chunk_list = ap->chunk_lists + (long long)blockIdx.x * ap->list_stride;
     if (tid == 0) {
-        TLS_CHECK(*ap, slim_lds_bytes(n, M, region_pad, ap->n_widths) != 0 && slim_lds_bytes(n, M, region_pad, ap->n_widths) <= ap->lds_bytes && 6LL * n + 4LL * nb <= 8LL * RS, kChkLdsCarve);
+        TLS_CHECK(*ap, slim_lds_bytes(n, M, region_pad, ap->n_widths) != 0 && slim_lds_bytes(n, M, region_pad, ap->n_widths) <= ap->lds_bytes && 6LL * n + 4LL * slim_buckets(n, RS) <= 8LL * RS, kChkLdsCarve);
     }
     const const_width_ptr widths_c = (const_width_ptr)ap->widths;
     const const_rows_ptr rows_c = (const_rows_ptr)ap->rows;
@@ -134,88 +343,8 @@ tls_slim_kernel(const SearchArgs) {
         PhaseClock pc;
         pc.start(ap->phase_cycles);
 
-        // ---- phase 1: fold + stable sort by phase (core.py:119-120), on 32-bit keys -------------------
-        // A point's key stays in a register from the fold to its rank.  Bucket = floor(key * nb / 2^32); INSIDE a bucket the
-        // low word of key * nb is monotone in the key: its top 19 bits and the index make the point's sort record.  Records
-        // are scattered bucket by bucket (any order inside one); a point's place is its bucket's start plus the records of
-        // the bucket in front of it -- decided by the records, and by the exact phases (then the index: numpy's stable
-        // order) for the pairs whose 19 bits tie: two phases within 2^-30, or the piled-up phases of a commensurate period.
-        for (int b = tid; b < nb; b += nt) cnt[b] = 0;
-        __syncthreads();
-        unsigned int key[kSlimPer];
-        {
-            // every time stamp of the thread is requested before the first is used: ONE L2 round trip per period, not one per
-            // group of divisions (nothing else is alive in registers at a period's start)
-#ifndef TLS_SLIM_FOLD_DEPTH
-#define TLS_SLIM_FOLD_DEPTH kSlimPer
-#endif
-            constexpr int kF = TLS_SLIM_FOLD_DEPTH;
-            static_assert(kSlimPer % kF == 0, "the fold takes kF time stamps per step");
-#pragma unroll
-            for (int j0 = 0; j0 < kSlimPer; j0 += kF) {
-                const int base = slim_fresh(tid) + j0 * nt;
-                double tv[kF];
-#pragma unroll
-                for (int j = 0; j < kF; ++j) { const int i = base + j * nt; tv[j] = ap->t[i < n ? i : 0]; }
-#pragma unroll
-                for (int j = 0; j < kF; ++j) {
-                    const int i = base + j * nt;
-                    key[j0 + j] = phase_key(fold_phase(tv[j], period, 0.0));
-                    if (i < n) atomicAdd(&cnt[__umulhi(key[j0 + j], (unsigned int)nb)], 1u);
-                }
-            }
-        }
-        __syncthreads();
-        pc.mark(0);
-        block_exclusive_scan(cnt, nb, wsum);
-        pc.mark(1);
-#pragma unroll
-        for (int j = 0; j < kSlimPer; ++j) {
-            const int i = slim_fresh(tid) + j * nt;
-            if (i < n) {
-                const unsigned int slot = atomicAdd(&cnt[__umulhi(key[j], (unsigned int)nb)], 1u);
-                recs[slot] = ((key[j] * (unsigned int)nb) & ~((1u << kSlimIdxBits) - 1u)) | (unsigned int)i;
-            }
-        }
-        __syncthreads();
-        pc.mark(2);
-        {
-            // (cnt[b] is now the END of bucket b)
-            auto before = [&](unsigned int other, unsigned int mine) -> int {
-                if (((other ^ mine) >> kSlimIdxBits) != 0u) return other < mine ? 1 : 0;
-                if (other == mine) return 0;
-                return slim_tie_before(ap->t, period, (int)(other & ((1u << kSlimIdxBits) - 1u)), (int)(mine & ((1u << kSlimIdxBits) - 1u)));
-            };
-            constexpr int kG = 5, kWin = 4;   // points ranked together; records of a bucket read up front
-            static_assert(kSlimPer % kG == 0, "the rank takes kG points per step");
-#pragma unroll
-            for (int j0 = 0; j0 < kSlimPer; j0 += kG) {
-                int lo[kG], hi[kG];
-                unsigned int mine[kG], win[kG][kWin];
-                const int base = slim_fresh(tid) + j0 * nt;
-#pragma unroll
-                for (int g = 0; g < kG; ++g) {
-                    const int i = base + g * nt;
-                    const unsigned int b = __umulhi(key[j0 + g], (unsigned int)nb);
-                    mine[g] = ((key[j0 + g] * (unsigned int)nb) & ~((1u << kSlimIdxBits) - 1u)) | (unsigned int)i;
-                    lo[g] = b ? (int)cnt[b - 1] : 0;
-                    hi[g] = i < n ? (int)cnt[b] : lo[g];
-                }
-#pragma unroll
-                for (int g = 0; g < kG; ++g)
-#pragma unroll
-                    for (int u = 0; u < kWin; ++u) win[g][u] = recs[lo[g] + u < hi[g] ? lo[g] + u : lo[g]];
-#pragma unroll
-                for (int g = 0; g < kG; ++g) {
-                    int rank = 0;
-#pragma unroll
-                    for (int u = 0; u < kWin; ++u) if (lo[g] + u < hi[g]) rank += before(win[g][u], mine[g]);
-                    for (int s2 = lo[g] + kWin; s2 < hi[g]; ++s2) rank += before(recs[s2], mine[g]);
-                    if (lo[g] < hi[g]) perm[lo[g] + rank] = (unsigned short)(mine[g] & ((1u << kSlimIdxBits) - 1u));
-                }
-            }
-        }
-        __syncthreads();
+        // ---- phase 1: fold + stable sort by phase (core.py:119-120), on 32-bit keys (slim_fold_and_sort) -------------------
+        slim_fold_and_sort(ap->t, n, period, RS, X, wsum, s_work, scratch, pc);
         pc.mark(3);
         // survey mode: the permutation outlives the light curves of the batch in global memory
         const unsigned short* perm_g = nullptr;
