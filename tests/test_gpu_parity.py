@@ -187,6 +187,20 @@ def test_plain_and_counting_kernels_agree_bit_for_bit(gpu, name, stride):
     assert counted[3]["evaluated_cells"] > 0 and counted[3]["inner_steps"] > counted[3]["evaluated_cells"]
 
 
+def test_counting_search_runs_the_kernel_family_of_the_plain_search(gpu):
+    """Which kernel a search takes is the plan's choice (series, noise level) -- not changed by asking for the work counters:
+    at 200 ppm the host takes the fp32 screen of the classic kernel, the counting search its counting instantiation (not the
+    four-slot kernel, whose values differ from the classic family's in the last bits), and both return the same bits."""
+    inp = _inputs("k2_90d", sigma=200e-6)
+    p = inp["periods"][::7]
+    plain = gpu.search(inp["t"], inp["y"], inp["dy"], p, inp["table"], inp["params"])
+    assert gpu.last_kernel() in ("resident+screen32", "resident+prune")
+    counted = gpu.search(inp["t"], inp["y"], inp["dy"], p, inp["table"], inp["params"], count_work=True)
+    assert gpu.last_kernel() == "resident"
+    for x, y in zip(counted[:3], plain[:3]):
+        numpy.testing.assert_array_equal(x, y)
+
+
 def test_chi2_bounds_and_flat_light_curve(gpu):
     """chi2 <= N everywhere; a light curve with nothing deeper than transit_depth_min
     returns exactly N, depth 0 (core.py:46-48; tests/test_transit_depth_min.py:62-70)."""
@@ -1209,7 +1223,7 @@ def test_four_slot_kernel_batches_ties_and_the_series_it_does_not_fit(gpu, oracl
     keep numpy's stable order (32-bit sort keys, ties by the exact phase and the index); per-point weights and a series
     beyond a quarter of the LDS take the classic kernel."""
     from tls_amd import survey
-    gpu.set_options(slim=1)
+    gpu.set_options(slim=1, prune=0, screen32=0)      # (at 300 ppm the host would take the fp32 screen of the classic kernel)
     t, f0, kw = synthetic.config("k2_90d", seed=0)
     fluxes = numpy.stack([synthetic.config("k2_90d", seed=s)[1] for s in range(5)])
     periods, chi2, row, depth = survey.search_batch(t, fluxes, context=gpu, **kw)

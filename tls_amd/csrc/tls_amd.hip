@@ -864,7 +864,10 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         if (er != hipSuccess) { --ctx->ev_used; return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er)); }
         a.park_cells = ctx->d_park.ptr;
         e = launch_variant<true, true, false, unsigned short, false, false, true>(ctx, a, ctx->blocks);
-    } else if (ctx->slim_blocks > 0 && ctx->uniform_w && !prune && !debug_folded && !debug_prefix) {
+    } else if (ctx->slim_blocks > 0 && ctx->uniform_w && !ctx->prune_kernel &&
+               !(ctx->screen_kernel && screen_admissible(ctx->resident, ctx->uniform_w, ctx->e_abs_max)) && !debug_folded && !debug_prefix) {
+        // (by the plan's choice, not this launch's: a search that counts its work runs the counting instantiation of the kernel
+        // the plain search takes -- the classic family where pruning or the screen is the host's choice -- and returns its bits)
         // four period slots per CU (tls_slim_kernel.hip.h): plain variant, uniform weights, 256-thread workgroups
         kernel_name = "slim";
         a.lds_bytes = (long long)ctx->slim_lds;
