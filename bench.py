@@ -389,7 +389,18 @@ def large_config(ctx, name, reps, warm=0):
     algo = n_per * (24 * n + 24)
     achieved = algo / (ms * 1e-3) / 1e9
     traffic, source = recorded_traffic(name, n_per)
-    return {"points": n, "periods": n_per, "trial_cells": info["grid_cells"], "kernel_ms": ms,
+    # what the dot products of this launch come to against the fp64 vector rate (the slab variant's chi^2 phase is most of a
+    # TESS-size period: the honest second ceiling beside HBM); one more launch, counting, outside the timed ones
+    ctx.execute(count_work=True)
+    c = ctx.fetch(with_counters=True)[3]
+    fp64 = {"peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "useful": 2.0 * c["inner_steps"] / (ms * 1e-3) / 1e12,
+            "issued": 2.0 * c["issued_fma"] / (ms * 1e-3) / 1e12,
+            "useful_frac": 2.0 * c["inner_steps"] / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF,
+            "issued_frac": 2.0 * c["issued_fma"] / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF,
+            "lane_efficiency": c["inner_steps"] / max(c["issued_fma"], 1), "inner_steps": c["inner_steps"],
+            "evaluated_fraction": c["evaluated_cells"] / max(c["grid_cells"], 1),
+            "note": "one FMA per template tap of an evaluated cell (useful) / FMAs issued, over the kernel time of the plain launch"}
+    return {"points": n, "periods": n_per, "trial_cells": info["grid_cells"], "kernel_ms": ms, "fp64": fp64,
             "trial_cells_per_s": info["grid_cells"] / (ms * 1e-3), "host_prepare_ms": 1e3 * prep_s,
             "host_prepare_first_call_ms": 1e3 * first_s,
             "lds_resident": info["resident"], "argmin_period_index": int(numpy.argmin(chi2)),

@@ -1175,20 +1175,21 @@ def test_noted_band_windows_are_decided_on_the_exact_prefix_sum(gpu, oracle_lib,
     numpy.testing.assert_array_equal(dep[1], one[2])
 
 
-@pytest.mark.parametrize("sigma,stride,outlier", [(None, 1, None), (300e-6, 11, None), (None, 7, 3.0e4), (100e-6, 13, 2.0e6)])
-def test_four_slot_kernel_searches_the_reference_cells(gpu, oracle_lib, sigma, stride, outlier):
+@pytest.mark.parametrize("sigma,stride,outlier,name", [(None, 1, None, "k2_90d"), (300e-6, 11, None, "k2_90d"), (None, 7, 3.0e4, "k2_90d"),
+                                                       (100e-6, 13, 2.0e6, "k2_90d"), (None, 3, None, "tutorial01")])
+def test_four_slot_kernel_searches_the_reference_cells(gpu, oracle_lib, sigma, stride, outlier, name):
     """Short LDS-resident series, uniform weights: tls_slim_kernel (four 256-thread workgroups per CU, phase 3 on the
     prefix sum X alone, dot products by summation by parts) against the classic LDS-resident kernel
     in exact prefix-sum mode and the oracle.  Same evaluated cells and template taps, same rows; chi^2 and depth within
     what the two prefix-sum modes differ by.  A window the plain scan cannot decide is noted and decided on the exact
     prefix sum: ONE wild flux value widens the undecided band (1.25 * 2^-53 * (N + W) * max|flux|) until white noise puts
     windows inside -- a few dozen per period at 3e4, more than the list of 256 holds at 2e6 (the period is searched again
-    in exact mode)."""
-    inp = _inputs("k2_90d") if sigma is None else _inputs("k2_90d", sigma=sigma)
+    in exact mode).  Tutorial 01 (100 d): three workgroups per CU."""
+    inp = _inputs(name) if sigma is None else _inputs(name, sigma=sigma)
     if outlier is not None:
         y = inp["y"].copy()
         y[137] = outlier
-        t, _, kw = synthetic.config("k2_90d")
+        t, _, kw = synthetic.config(name)
         inp = synthetic.search_inputs(inp["t"], y, None, **kw)
     sel = inp["periods"][::stride]
     args = (inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"])

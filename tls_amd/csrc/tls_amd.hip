@@ -36,6 +36,14 @@ constexpr double kFracDurationMax = 0.12;
 constexpr double kPi = 3.141592653589793;
 
 constexpr size_t kLdsPerCU = 160 * 1024;
+// The four-slot kernel is taken when at least this many periods fit a CU's LDS.  Three (Tutorial 01: 100 d, 43.8 KB a period)
+// already beat the classic kernel's ONE 1024-thread workgroup per CU by 18 % (1.47 against 1.79 ms, same box); in the narrow
+// band where the classic kernel still fits two workgroups and this one only three, the classic one is 4 % faster (a 42-day
+// probe: 0.371 against 0.386 ms) -- a series length of one day in a hundred, not special-cased.
+#ifndef TLS_SLIM_MIN_SLOTS
+#define TLS_SLIM_MIN_SLOTS 3
+#endif
+constexpr size_t kSlimMinSlots = TLS_SLIM_MIN_SLOTS;
 constexpr size_t kEventRing = 64;   // launch-timing event pairs kept per context
 
 std::string g_create_error;  // tls_last_error(NULL)
@@ -1173,8 +1181,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)ctx->threads);
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)wg_per_cu * ctx->n_cu);
         if (ctx->opt.blocks > 0) ctx->blocks = std::max(1, std::min(ctx->blocks, ctx->opt.blocks));   // developer switch
-        // Four 256-thread workgroups per CU, phase 3 on X alone (tls_slim_kernel.hip.h): uniform weights, and the period's
-        // one region + header within a quarter of the LDS.  (tls_options::slim = 0: never.)
+        // Four (at least three) 256-thread workgroups per CU, phase 3 on X alone (tls_slim_kernel.hip.h): uniform weights, and
+        // the period's one region + header within a quarter (a third) of the LDS.  (tls_options::slim = 0: never.)
         // (auto: only while the library also decides between the classic kernel's variants -- an explicit tls_options::prune
         // or ::screen32 selects among THOSE; slim = 1 forces this kernel wherever neither pruning nor the screen is taken)
         // (exact prefix-sum mode throughout is the classic kernel's: this one values its cells on the plain scan, and keeps
@@ -1182,9 +1190,9 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         const bool slim_wanted = ctx->opt.exact_prefix != 1 && (ctx->opt.slim == 1 || (ctx->opt.slim < 0 && ctx->opt.prune < 0 && ctx->opt.screen32 < 0));
         if (uniform && slim_wanted && ctx->opt.threads <= 0) {
             const long long need = tlsdev::slim_lds_bytes((int)n, (int)M, ctx->region_pad, (int)widths.size());
-            if (need > 0 && 4 * (size_t)need <= kLdsPerCU) {
+            if (need > 0 && kSlimMinSlots * (size_t)need <= kLdsPerCU) {
                 ctx->slim_lds = (size_t)need;
-                ctx->slim_blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)4 * ctx->n_cu);
+                ctx->slim_blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)std::min<size_t>(4, kLdsPerCU / (size_t)need) * ctx->n_cu);
                 if (ctx->opt.blocks > 0) ctx->slim_blocks = std::max(1, std::min(ctx->slim_blocks, ctx->opt.blocks));
             }
         }
@@ -2252,7 +2260,7 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         // plain and screen is the noise level's)
         const long long slim_need = tlsdev::slim_lds_bytes((int)n, (int)M, tlsdev::region_pad_for(widest_stride), (int)widths.size());
         const bool slim_wanted = po.exact_prefix != 1 && (po.slim == 1 || (po.slim < 0 && po.prune < 0 && po.screen32 < 0));
-        const bool slim = resident && slim_wanted && po.threads <= 0 && slim_need > 0 && 4 * (size_t)slim_need <= kLdsPerCU && !prune &&
+        const bool slim = resident && slim_wanted && po.threads <= 0 && slim_need > 0 && kSlimMinSlots * (size_t)slim_need <= kLdsPerCU && !prune &&
                           !screen_pays(po, widths, sigma, params->transit_depth_min, true);
         double a0, aN, b, c;
         if (!resident) { a0 = 458384.0; aN = 4.5716; b = 0.4604; c = 0.03275; }        // HBM slab variant (TESS 27 d + Kepler 4 yr)
@@ -2282,7 +2290,7 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         // device is asked, a process without one plans for an MI355X), two workgroups per CU when two folded series fit
         // its LDS.  A block of n periods takes ceil(n / this) rounds, not n / this.  (The cycle coefficients above are
         // MI355X measurements; only their ratios matter.)
-        if (workgroups_in_flight) *workgroups_in_flight = (slim ? 4 : two_per_cu ? 2 : 1) * visible_compute_units();
+        if (workgroups_in_flight) *workgroups_in_flight = (slim ? (int)std::min<size_t>(4, kLdsPerCU / (size_t)slim_need) : two_per_cu ? 2 : 1) * visible_compute_units();
     } else if (workgroups_in_flight) {
         *workgroups_in_flight = visible_compute_units();
     }
