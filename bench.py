@@ -407,7 +407,10 @@ def large_config(ctx, name, reps, warm=0):
             "best_period": float(inp["periods"][int(numpy.argmin(chi2))]),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo,
-                         "traffic": traffic, "traffic_source": source}}
+                         "traffic": traffic, "traffic_source": source,
+                         # which ceiling is nearer: measured HBM traffic against 8 TB/s, or issued fp64 FMAs against 78.6 TF
+                         "nearer_ceiling": ("fp64" if fp64["issued_frac"] > (traffic or algo) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS else "hbm"),
+                         "traffic_frac": (traffic or algo) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "fp64_issued_frac": fp64["issued_frac"]}}
 
 
 def shard_balance(ctx, name, n_blocks=8, reps=3):
