@@ -1044,7 +1044,7 @@ def test_commensurate_periods_cost_no_more_than_their_neighbours(gpu, oracle_lib
     the bucket sort's in-bucket ranking by counting was quadratic in the pile (one such period of the Kepler-size grid:
     29 ms in one workgroup, 85x its neighbours).  Piled-up buckets now go through the workgroup's bitonic sort
     (sort_big_bucket): every commensurate period of the LDS-resident configuration within 3x the median period of the
-    same search (5x under the four-slot kernel, whose pile path is quadratic in the pile), a Kepler-size one below 5 ms and within 10x; results unchanged (oracle)."""
+    same search (4x under the four-slot kernel, whose pile path is quadratic in the pile), a Kepler-size one below 5 ms and within 10x; results unchanged (oracle)."""
     t = 3.0 + numpy.arange(n) / float(cadences_per_day)       # exact binary cadence
     y = 1 + numpy.random.RandomState(5).normal(0, 5e-5, n)
     kw = dict(period_min=0.5, period_max=400) if n > 10000 else {}
@@ -1064,10 +1064,12 @@ def test_commensurate_periods_cost_no_more_than_their_neighbours(gpu, oracle_lib
         assert worst < 4e-3 * 2.4e9            # shader cycles at <= 2.4 GHz: below 4 ms (round 1: 29 ms)
         assert worst <= 10.0 * median, (worst, median, periods[special][numpy.argmax(cycles[special])])
     else:
-        # the four-slot kernel ranks a pile (its records tie on their key bits) on exact phases formed once, four piles side
-        # by side: quadratic in the pile, 30 piles of 144 points (30 cadences) cost 3.5-4.5 x an ordinary period, 120 piles
-        # of 36 1.7 x; the classic kernel's bitonic network (`slim = 0`) stays within 3 x.  Before the pile path: 16 x.
-        assert worst <= (5.0 if gpu.last_kernel() == "slim" else 3.0) * median, (worst, median, periods[special][numpy.argmax(cycles[special])])
+        # the four-slot kernel ranks a pile (a bucket beyond 8 points whose records tie on their key bits) on 64-bit keys formed
+        # once per member, up to 16 piles side by side: quadratic in the pile -- 30 piles of 144 points (30 cadences) cost
+        # 2.1-2.8 x an ordinary period, 120 piles of 36 1.4 x; before the pile path: 16 x.  (The classic kernel's bitonic
+        # network, `slim = 0`: 1.7 x.)
+        print("commensurate: worst %.0f cycles = %.2f x the median %.0f (%s)" % (worst, worst / median, median, gpu.last_kernel()))
+        assert worst <= (4.0 if gpu.last_kernel() == "slim" else 3.0) * median, (worst, median, periods[special][numpy.argmax(cycles[special])])
     sel = numpy.nonzero(special)[0]
     want = oracle_search(oracle_lib, inp, periods=periods[sel])
     assert_parity(tuple(a[sel] for a in got[:3]), want, n)

@@ -29,7 +29,8 @@ constexpr int kSlimScratchBytes = 1328;   // >= sizeof(Cumsum2Scratch); the per-
 #endif
 constexpr int kSlimTailMax = TLS_SLIM_TAIL_MAX;          // a row's last, mostly empty batch is re-listed window by window up to this many units
 constexpr int kSlimTailSingles = TLS_SLIM_TAIL_SINGLES;  // ... if that leaves at most this many windows
-constexpr int kSlimBig = 24;           // a bucket beyond this many points (a commensurate period's pile) is ranked by the workgroup on exact phases
+constexpr int kSlimBig = 8;            // a bucket beyond this many points (a commensurate period's pile) is ranked by the workgroup on exact phases
+constexpr int kSlimPileMembers = 3;     // members of one pile a thread ranks, at most
 constexpr int kSlimStageBytes = 2048;  // at least this much of the region stays free for the phases of such a pile
 constexpr int kSlimIdxBits = 13;      // a sort record: sub-bucket key (19 bits) | original index (13 bits)
 __host__ __device__ constexpr int slim_header_bytes() { return 128 + kSlimWaves * 24 + 48 + kSlimScratchBytes; }   // wsum | wbest | s_work | scratch
@@ -69,13 +70,12 @@ __device__ __forceinline__ __attribute__((address_space(3))) T* slim_lds_ptr(T* 
     return (lds_t)(uintptr_t)v;
 }
 __device__ __noinline__ void slim_rank_piles(const double* t_, double period_, const unsigned int* recs_, const unsigned int* cnt_,
-                                             unsigned short* perm_, double* stage_, int stage_cap_, const unsigned short* big_list_, int n_big_, int* flags_) {
+                                             unsigned short* perm_, double* stage_, int stage_cap_, const unsigned short* big_list_, int n_big_, int* flags_, int nb_, unsigned long long* clk_) {
     typedef __attribute__((address_space(1))) const double* glob_f64;
     typedef __attribute__((address_space(3))) const unsigned int* lds_u32;
     typedef __attribute__((address_space(3))) unsigned short* lds_u16;
     typedef __attribute__((address_space(3))) const unsigned short* lds_cu16;
     typedef __attribute__((address_space(3))) double* lds_f64;
-    typedef __attribute__((address_space(3))) const unsigned long long* lds_cu64;
     const glob_f64 t = (glob_f64)global_arg(t_);
     const double period = uniform_f64(period_);
     const lds_u32 recs = slim_lds_ptr(recs_);
@@ -84,54 +84,121 @@ __device__ __noinline__ void slim_rank_piles(const double* t_, double period_, c
     const lds_f64 stage = slim_lds_ptr(stage_);
     const lds_cu16 big_list = slim_lds_ptr(big_list_);
     __attribute__((address_space(3))) int* const flags = slim_lds_ptr(flags_);
-    const int stage_cap = uniform_i32(stage_cap_), n_big = uniform_i32(n_big_);
+    const int stage_cap = uniform_i32(stage_cap_), n_big = uniform_i32(n_big_), nb = uniform_i32(nb_);
     const int tid = threadIdx.x, nt = blockDim.x;
     constexpr unsigned int kIdx = (1u << kSlimIdxBits) - 1u;
-    // the largest pile decides how many are ranked side by side: 4, 2 or 1 groups of threads, each with its share of the stage
-    // (every thread looks at its share of the list; the verdicts meet in an LDS word the caller has zeroed)
-    int wide = 0;
+    // the largest pile decides how many are ranked side by side, a group of threads and a share of the stage each
+    // (every thread looks at its share of the list; the sizes meet in an LDS word the caller has zeroed)
+#if TLS_PHASE_CLOCKS
+    long long c_last = clock64();
+#define SLIM_PILE_MARK(slot) do { if (clk_ && threadIdx.x == 0) { const long long now_ = clock64(); atomicAdd(&clk_[slot], (unsigned long long)(now_ - c_last)); c_last = now_; } } while (0)
+#else
+#define SLIM_PILE_MARK(slot) do { } while (0)
+#endif
+    int m_mine = 0;
     for (int gb = tid; gb < n_big; gb += nt) {
         const int b = (int)big_list[gb];
-        const int m = (int)cnt[b] - (b ? (int)cnt[b - 1] : 0);
-        wide |= m > stage_cap / 4 ? (m > stage_cap / 2 ? 3 : 1) : 0;
+        m_mine = max(m_mine, (int)cnt[b] - (b ? (int)cnt[b - 1] : 0));
     }
-    if (wide) __hip_atomic_fetch_or(flags, wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (m_mine) __hip_atomic_fetch_max(flags, m_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
-    const int verdict = __builtin_amdgcn_readfirstlane(*flags);
-    const int groups = verdict == 0 ? 4 : verdict == 1 ? 2 : 1;
+    const int m_max = __builtin_amdgcn_readfirstlane(*flags);
+    // as many piles side by side as the largest leaves room for: its members fit the group's share of the stage and its
+    // threads' registers (a round is a chain of dependent round trips whatever it ranks: few rounds matter more than wide groups)
+    int groups = 16;
+    while (groups > 1 && (m_max > stage_cap / groups || m_max > kSlimPileMembers * (nt / groups))) groups >>= 1;
     const int per = nt / groups, group = tid / per, first = tid - group * per;
     const lds_f64 mine = stage + group * (stage_cap / groups);
-    const lds_cu64 bits = (lds_cu64)mine;
-    for (int g0 = 0; g0 < n_big; g0 += groups) {   // (the same trips for every thread: the barriers below are the workgroup's)
+    const __attribute__((address_space(3))) unsigned long long* const keys = (const __attribute__((address_space(3))) unsigned long long*)mine;
+    // A phase is >= 0: its bit pattern orders like its value.  Every phase of bucket b is >= b / nb, and from the eighth
+    // bucket on the patterns of a bucket span less than 2^50: (pattern - pattern of a double just below b / nb) and the
+    // 13-bit index make ONE 64-bit sort key, distinct for every member -- one compare a pair.  The first buckets (phases
+    // down to 0: patterns of every exponent) compare pattern and index separately.
+    // The keys of the NEXT round's piles are formed (global loads, divisions) while this round's are ranked.
+    constexpr int kMine = kSlimPileMembers;   // members of a pile per thread, at most (the caller caps the stage at kMine * nt entries)
+    unsigned long long ahead[kMine];
+    double ahead_t[kMine];
+    unsigned int ahead_rec[kMine];
+    // (in two halves around the ranking: a wavefront issues in order, so the time stamps are REQUESTED before it and first
+    // touched behind it)
+    auto request = [&](int g0, int& lo, int& m, int& b) {
         const int gb = g0 + group;
-        int lo = 0, m = 0;
+        b = 0; lo = 0; m = 0;
         if (gb < n_big) {
-            const int b = (int)big_list[gb];
+            b = (int)big_list[gb];
             lo = b ? (int)cnt[b - 1] : 0;
             m = (int)cnt[b] - lo;
         }
-        // (a phase is >= 0: its bit pattern orders like its value, and two integer compares take no branch)
-        for (int j = first; j < m; j += per) mine[j] = fold_phase(t[recs[lo + j] & kIdx], period, 0.0);
-        __syncthreads();
-        for (int j = first; j < m; j += per) {
-            const unsigned int i = recs[lo + j] & kIdx;
-            const unsigned long long ph = bits[j];
-            unsigned int rank = 0;
-            constexpr int kB = 8;   // members read per step (the lanes of a group read the same words: broadcasts)
-            for (int u0 = 0; u0 < m; u0 += kB) {
-                unsigned long long ph2[kB];
-                unsigned int r2[kB];
 #pragma unroll
-                for (int u = 0; u < kB; ++u) { const int uu = u0 + u < m ? u0 + u : m - 1; ph2[u] = bits[uu]; r2[u] = recs[lo + uu] & kIdx; }
-#pragma unroll
-                for (int u = 0; u < kB; ++u) {
-                    const unsigned int before = (unsigned int)(ph2[u] < ph) | ((unsigned int)(ph2[u] == ph) & (unsigned int)(r2[u] < i));
-                    rank += before & (unsigned int)(u0 + u < m);
-                }
-            }
-            perm[lo + rank] = (unsigned short)i;
+        for (int a = 0; a < kMine; ++a) {
+            const int j = first + a * per;
+            ahead_rec[a] = j < m ? recs[lo + j] : 0u;
+            ahead_t[a] = t[ahead_rec[a] & kIdx];
         }
-        __syncthreads();   // (the next piles' phases go over these)
+    };
+    auto form_keys = [&](int b, bool& packed) {
+        packed = b >= 8;
+        const unsigned long long base = packed ? (unsigned long long)__double_as_longlong((double)b / (double)nb) - 4ull : 0ull;
+#pragma unroll
+        for (int a = 0; a < kMine; ++a) {
+            const unsigned long long pattern = (unsigned long long)__double_as_longlong(fold_phase(ahead_t[a], period, 0.0));
+            ahead[a] = packed ? ((pattern - base) << kSlimIdxBits) | (ahead_rec[a] & kIdx) : pattern;
+        }
+    };
+    int lo = 0, m = 0, lo_next = 0, m_next = 0, b_next = 0;
+    bool packed = false, packed_next = false;
+    SLIM_PILE_MARK(14);
+    request(0, lo_next, m_next, b_next);
+    form_keys(b_next, packed_next);
+    SLIM_PILE_MARK(15);
+    for (int g0 = 0; g0 < n_big; g0 += groups) {   // (the same trips for every thread: the barriers below are the workgroup's)
+        lo = lo_next; m = m_next; packed = packed_next;
+#pragma unroll
+        for (int a = 0; a < kMine; ++a) {
+            const int j = first + a * per;
+            if (j < m) ((__attribute__((address_space(3))) unsigned long long*)mine)[j] = ahead[a];
+        }
+        lds_barrier();
+        const bool more = g0 + groups < n_big;
+        if (more) request(g0 + groups, lo_next, m_next, b_next);   // (in flight across the ranking below)
+        SLIM_PILE_MARK(15);
+        constexpr int kB = 16;   // members read per step (the lanes of a group read the same words: broadcasts)
+        if (packed) {
+            for (int j = first; j < m; j += per) {
+                const unsigned long long key = keys[j];
+                unsigned int rank = 0;
+                for (int u0 = 0; u0 < m; u0 += kB) {
+                    unsigned long long k2[kB];
+#pragma unroll
+                    for (int u = 0; u < kB; ++u) k2[u] = keys[u0 + u < m ? u0 + u : j];   // (past the pile: the member itself, never in front of itself)
+#pragma unroll
+                    for (int u = 0; u < kB; ++u) rank += (unsigned int)(k2[u] < key);
+                }
+                perm[lo + rank] = (unsigned short)(key & kIdx);
+            }
+        } else {
+            for (int j = first; j < m; j += per) {
+                const unsigned int i = recs[lo + j] & kIdx;
+                const unsigned long long ph = keys[j];
+                unsigned int rank = 0;
+                for (int u0 = 0; u0 < m; u0 += kB) {
+                    unsigned long long ph2[kB];
+                    unsigned int r2[kB];
+#pragma unroll
+                    for (int u = 0; u < kB; ++u) { const int uu = u0 + u < m ? u0 + u : m - 1; ph2[u] = keys[uu]; r2[u] = recs[lo + uu] & kIdx; }
+#pragma unroll
+                    for (int u = 0; u < kB; ++u) {
+                        const unsigned int before = (unsigned int)(ph2[u] < ph) | ((unsigned int)(ph2[u] == ph) & (unsigned int)(r2[u] < i));
+                        rank += before & (unsigned int)(u0 + u < m);
+                    }
+                }
+                perm[lo + rank] = (unsigned short)i;
+            }
+        }
+        SLIM_PILE_MARK(16);
+        if (more) form_keys(b_next, packed_next);
+        lds_barrier();   // (the next piles' keys go over these)
+        SLIM_PILE_MARK(17);
     }
 }
 
@@ -207,7 +274,8 @@ __device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, doubl
     // full -- a NEARLY commensurate period: many points, distinct keys -- is ranked here like any other.
     unsigned short* big_list = reinterpret_cast<unsigned short*>(scratch);
     const int stage_off = (4 * n + 4 * nb + 7) & ~7;
-    const int stage_cap = (8 * RS - 2 * n - stage_off) / 8;
+    const int stage_room = (8 * RS - 2 * n - stage_off) / 8;
+    const int stage_cap = stage_room < kSlimPileMembers * nt ? stage_room : kSlimPileMembers * nt;   // (a thread keeps that many keys in registers)
     double* stage = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(X) + stage_off);
     {
         // (cnt[b] is now the END of bucket b)
@@ -265,7 +333,8 @@ __device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, doubl
     __syncthreads();
     {
         const int n_big = __builtin_amdgcn_readfirstlane(s_work[5]);
-        if (n_big > 0) slim_rank_piles(t, period, recs, cnt, perm, stage, stage_cap, big_list, n_big, &s_work[6]);
+        pc.mark(8);
+        if (n_big > 0) slim_rank_piles(t, period, recs, cnt, perm, stage, stage_cap, big_list, n_big, &s_work[6], nb, pc.out);
     }
 }
 

@@ -8,7 +8,7 @@ n = 4320
 t = 3.0 + numpy.arange(n) / 48.0
 y = 1 + numpy.random.RandomState(5).normal(0, 5e-5, n)
 inp = synthetic.search_inputs(t, y)
-for P in (0.625, 2.5):
+for P in (0.625, 2.5, 10.0, 7.123):
     periods = numpy.full(256, P)
     ctx.prepare(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
     ctx.execute(); ctx.synchronize()
