@@ -1264,3 +1264,46 @@ def test_four_slot_kernel_batches_ties_and_the_series_it_does_not_fit(gpu, oracl
     inp2 = synthetic.search_inputs(t2, y2, None, period_min=1.0, period_max=30.0, oversampling_factor=1)
     gpu.search(inp2["t"], inp2["y"], inp2["dy"], inp2["periods"][::20], inp2["table"], inp2["params"])
     assert gpu.last_kernel().startswith("resident")
+
+
+def test_results_do_not_depend_on_what_the_lds_held_before(gpu):
+    """No kernel may read LDS it has not written: on a fresh box the LDS holds whatever the previous tenant left, later
+    processes mostly find their own data there -- which is how an unset entry (the weights' entry M of the classic
+    LDS-resident kernel, read against a zero tap: 0 * NaN) survived four rounds and failed one test run in thirty.
+    tls_debug_poison_lds fills every CU's LDS with NaN / -inf / all-ones words; searches before and after agree bit for
+    bit -- every kernel variant, uniform and per-point weights, the post-search kernels through power()."""
+    import tls_amd
+    cases = []
+    for name in SEARCH_GOLDENS:
+        g, table, params = load_search_golden(name)
+        cases.append((name, (g["t"], g["y"], g["dy"], g["periods"], table, params)))
+    for name, sigma, stride, weights in (("k2_90d", None, 40, False), ("k2_90d", 200e-6, 40, False), ("k2_90d", 500e-6, 40, False),
+                                         ("k2_90d", None, 40, True), ("tutorial01", None, 60, False), ("tess_27d", None, 120, False),
+                                         ("tess_27d", None, 120, True), ("kepler_4yr", None, 9000, False)):
+        t, f, kw = synthetic.config(name, sigma=sigma)
+        dy = numpy.random.RandomState(5).uniform(0.7, 1.5, len(f)) * synthetic.CONFIGS[name][2] if weights else None
+        inp = synthetic.search_inputs(t, f, dy, **kw)
+        cases.append(("%s %s %s" % (name, sigma, weights), (inp["t"], inp["y"], inp["dy"], inp["periods"][::stride], inp["table"], inp["params"])))
+    for label, args in cases:
+        for word in (0x7ff80000, 0xfff00000, 0xffffffff):
+            for count in (False, True):
+                before = gpu.search(*args, count_work=count)
+                gpu.poison_lds(word)
+                after = gpu.search(*args, count_work=count)
+                for x, y in zip(before[:3], after[:3]):
+                    numpy.testing.assert_array_equal(x, y, err_msg="%s after LDS words %#x (%s)" % (label, word, gpu.last_kernel()))
+    t, f, kw = synthetic.config("k2_90d")
+    model = tls_amd.transitleastsquares(t, f, verbose=False)
+    first = model.power(verbose=False, show_progress_bar=False, context=gpu, **kw)
+    gpu.poison_lds(0x7ff80000)
+    second = model.power(verbose=False, show_progress_bar=False, context=gpu, **kw)
+    for key in ("SDE", "period", "T0", "depth", "duration", "snr", "chi2_min"):
+        assert first[key] == second[key], key
+    numpy.testing.assert_array_equal(first["power"], second["power"])
+    from tls_amd import survey
+    fluxes = numpy.stack([synthetic.config("k2_90d", seed=s)[1] for s in range(3)])
+    one = survey.power_batch(t, fluxes, context=gpu, **kw)
+    gpu.poison_lds(0xfff00000)
+    two = survey.power_batch(t, fluxes, context=gpu, **kw)
+    for x, y in zip(one, two):
+        numpy.testing.assert_array_equal(x, y)

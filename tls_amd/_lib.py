@@ -23,7 +23,7 @@ ABI_VERSION = 4   # include/tls_amd.h TLS_AMD_ABI_VERSION: checked against the l
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version", "tls_abi_version",
     "tls_device_name", "tls_get_options", "tls_set_options", "tls_search", "tls_search_batch", "tls_power_batch", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_last_kernel", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_period_cycles",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_last_kernel", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_poison_lds", "tls_debug_period_cycles",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_info", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
     "tls_comm_barrier", "tls_comm_max",
@@ -144,6 +144,8 @@ def load():
     lib.tls_kernel_timing.argtypes = [vp, ci, _c_double_p, _c_int64_p]
     lib.tls_debug_phase_cycles.restype = ci
     lib.tls_debug_phase_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ci]
+    lib.tls_debug_poison_lds.restype = ci
+    lib.tls_debug_poison_lds.argtypes = [vp, ctypes.c_uint32]
     lib.tls_debug_check_counts.restype = ci
     lib.tls_debug_check_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ci]
     lib.tls_t0_fit.restype = ci
@@ -456,6 +458,10 @@ class Context(object):
         names = ("lds_carve", "list_capacity", "dot_window", "predicate_read", "sort_window", "work_item",
                  "singles_capacity", "tile_stage", "screen_split")
         return bool(rc), dict(zip(names, [int(v) for v in arr]))
+
+    def poison_lds(self, word=0x7ff80000):
+        """Test entry: every CU's LDS filled with `word` (default: fp64 NaNs) on the context's stream."""
+        self._check(self._lib.tls_debug_poison_lds(self._h, int(word)))
 
     def synchronize(self):
         self._check(self._lib.tls_synchronize(self._h))

@@ -1698,6 +1698,27 @@ int tls_debug_phase_cycles(tls_ctx* ctx, uint64_t* cycles, int n) {
     return TLS_OK;
 }
 
+namespace {
+// test entry: every byte of every CU's LDS set to a pattern (one workgroup with all 160 KB per CU, a few rounds of them)
+__global__ void __launch_bounds__(1024) tls_poison_lds_kernel(unsigned int word, unsigned int* sink) {
+    extern __shared__ unsigned int lds_words[];
+    const unsigned int total = 160u * 1024u / 4u;
+    for (unsigned int k = threadIdx.x; k < total; k += blockDim.x) lds_words[k] = word;
+    __syncthreads();
+    if (lds_words[(threadIdx.x * 97u) % total] != word && sink) sink[0] = 1u;   // (keeps the stores alive)
+}
+}  // namespace
+
+int tls_debug_poison_lds(tls_ctx* ctx, uint32_t word) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    TLS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tls_poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(tls_poison_lds_kernel, dim3((unsigned)(4 * ctx->n_cu)), dim3(1024), 160 * 1024, ctx->stream, (unsigned int)word,
+                       static_cast<unsigned int*>(nullptr));
+    TLS_HIP(ctx, hipGetLastError());
+    return TLS_OK;
+}
+
 int tls_debug_check_counts(tls_ctx* ctx, uint64_t* counts, int n) {
     if (!ctx || !counts || n < 1) return fail(ctx, TLS_E_ARG, "bad argument");
     for (int i = 0; i < n; ++i) counts[i] = 0;

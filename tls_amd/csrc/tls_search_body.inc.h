@@ -290,7 +290,14 @@
                 regA[n + k] = regA[k];
                 if constexpr (!UNIFORM_W) regW[n + k] = regW[k];
             }
-            if (tid == 0) regA[M] = 0.0;
+            if (tid == 0) {
+                regA[M] = 0.0;
+                // (entry M of the weights too: the unrolled dot products of the last windows read it against a zero tap, and
+                // whatever a previous tenant left in the LDS may be a NaN -- 0 * NaN made A of those cells NaN and lost them
+                // the comparison: one period of golden `weights` 0.26 % off on the first launch of a fresh box, round 5;
+                // tests: tls_debug_poison_lds)
+                if constexpr (!UNIFORM_W) regW[M] = 0.0;
+            }
         }
         __syncthreads();
         pc.mark(4);
