@@ -178,9 +178,10 @@ int tls_debug_period_cycles(tls_ctx *ctx, uint64_t *cycles, int64_t capacity);
  * bound of the search kernel on the device and counts violations per check (names in
  * tls_amd/_lib.py::check_counts); returns 1 from a checked build, 0 (all counts zero) otherwise. */
 int tls_debug_check_counts(tls_ctx *ctx, uint64_t *counts, int n);
-/* Test entry: fills the LDS of every CU with `word` (0x7ff80000 pairs read as fp64 NaNs) on the context's stream -- what a
- * previous tenant of the GPU may have left there.  A search after it must return the bits of a search before it
- * (tests/test_gpu_parity.py: no kernel reads LDS it has not written). */
+/* Test entry: fills the LDS of every CU with `word` (0x7ff80000 pairs read as fp64 NaNs) and the context's per-workgroup
+ * scratch in HBM (slabs, lists, stashed orders) with all-ones bytes, on the context's stream -- what a previous tenant of
+ * the GPU may have left there.  A search after it must return the bits of a search before it
+ * (tests/test_gpu_parity.py: no kernel reads memory it has not written). */
 int tls_debug_poison_lds(tls_ctx *ctx, uint32_t word);
 /* block until the stream is idle */
 int tls_synchronize(tls_ctx *ctx);

@@ -1716,6 +1716,17 @@ int tls_debug_poison_lds(tls_ctx* ctx, uint32_t word) {
     hipLaunchKernelGGL(tls_poison_lds_kernel, dim3((unsigned)(4 * ctx->n_cu)), dim3(1024), 160 * 1024, ctx->stream, (unsigned int)word,
                        static_cast<unsigned int*>(nullptr));
     TLS_HIP(ctx, hipGetLastError());
+    // ... and the per-workgroup scratch in HBM (slabs, live-unit lists, stashed orders, the screen's and the sorts' scratch, the
+    // T0 fit's slabs): all ones -- NaNs as doubles -- as fresh device memory may be.  (Not the queues and counters, whose zero
+    // state between launches is the kernels' own invariant, nor the plan and the results.)
+    auto smear = [&](void* ptr, size_t bytes) -> hipError_t { return ptr && bytes ? hipMemsetAsync(ptr, 0xFF, bytes, ctx->stream) : hipSuccess; };
+    TLS_HIP(ctx, smear(ctx->d_scratch.ptr, ctx->d_scratch.cap * sizeof(double)));
+    TLS_HIP(ctx, smear(ctx->d_lists.ptr, ctx->d_lists.cap * sizeof(unsigned int)));
+    TLS_HIP(ctx, smear(ctx->d_perm.ptr, ctx->d_perm.cap * sizeof(unsigned int)));
+    TLS_HIP(ctx, smear(ctx->d_split.ptr, ctx->d_split.cap * sizeof(float)));
+    TLS_HIP(ctx, smear(ctx->d_park.ptr, ctx->d_park.cap * sizeof(double)));
+    TLS_HIP(ctx, smear(ctx->d_sort3.ptr, ctx->d_sort3.cap * sizeof(unsigned long long)));
+    TLS_HIP(ctx, smear(ctx->d_fscratch.ptr, ctx->d_fscratch.cap * sizeof(double)));
     return TLS_OK;
 }
 
