@@ -1133,11 +1133,15 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         if (regular) {
             for (int64_t p = 0; p < n_periods; ++p) {
                 const double r = periods[p] / dt;                 // samples per period
-                for (int k = 1; k <= 4; ++k) {
+                // (the four-slot kernel ranks piles from 9 points on by themselves, 2-3 x an ordinary period: a short
+                // series looks for smaller piles and higher resonances -- flagging too many only reorders the queue)
+                const bool fine_piles = uniform && n <= (int64_t)tlsdev::kSlimThreads * tlsdev::kSlimPer;
+                for (int k = 1; k <= (fine_piles ? 12 : 4); ++k) {
                     const double a = std::round(r * k);           // r ~ a / k: `a` distinct phase values
-                    if (a < 1 || (double)n / a < 48) continue;
+                    if (a < 1 || (double)n / a < (fine_piles ? 9 : 48)) continue;
                     const double width = (double)n * std::fabs((double)k / a - 1.0 / r);   // phase range of one pile
-                    if (width * (double)ctx_nb_for(n, widths.size()) < 4.0) { queue_cost[(size_t)p] += 50 * cost[(size_t)p]; break; }
+                    const double n_buckets = fine_piles ? 0.5 * (double)n : (double)ctx_nb_for(n, widths.size());
+                    if (width * n_buckets < (fine_piles ? 8.0 : 4.0)) { queue_cost[(size_t)p] += 50 * cost[(size_t)p]; break; }
                 }
             }
         }

@@ -29,7 +29,10 @@ constexpr int kSlimScratchBytes = 1328;   // >= sizeof(Cumsum2Scratch); the per-
 #endif
 constexpr int kSlimTailMax = TLS_SLIM_TAIL_MAX;          // a row's last, mostly empty batch is re-listed window by window up to this many units
 constexpr int kSlimTailSingles = TLS_SLIM_TAIL_SINGLES;  // ... if that leaves at most this many windows
-constexpr int kSlimBig = 8;            // a bucket beyond this many points (a commensurate period's pile) is ranked by the workgroup on exact phases
+#ifndef TLS_SLIM_BIG
+#define TLS_SLIM_BIG 8
+#endif
+constexpr int kSlimBig = TLS_SLIM_BIG;            // a bucket beyond this many points (a commensurate period's pile) is ranked by the workgroup on exact phases
 constexpr int kSlimPileMembers = 3;     // members of one pile a thread ranks, at most
 constexpr int kSlimStageBytes = 2048;  // at least this much of the region stays free for the phases of such a pile
 constexpr int kSlimIdxBits = 13;      // a sort record: sub-bucket key (19 bits) | original index (13 bits)
