@@ -1131,17 +1131,22 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             for (int64_t i = 1; i < n && regular; ++i) regular = std::fabs((t[i] - t[i - 1]) - dt) <= 1e-3 * dt;
         }
         if (regular) {
+            // (the four-slot kernel ranks piles from 9 points on by themselves, 2-3 x an ordinary period: a short series
+            // looks for smaller piles and higher resonances -- flagging too many only reorders the queue)
+            const bool fine_piles = uniform && n <= (int64_t)tlsdev::kSlimThreads * tlsdev::kSlimPer;
+            const int k_max = fine_piles ? 8 : 4;
+            const double a_max = (double)n / (fine_piles ? 9.0 : 48.0);       // `a` distinct phase values: piles of n / a points
+            const double n_buckets = fine_piles ? 0.5 * (double)n : (double)ctx_nb_for(n, widths.size());
+            const double drift = (fine_piles ? 8.0 : 4.0) / ((double)n * n_buckets);   // a pile's phase range, in buckets, over the series
+            const double inv_dt = 1.0 / dt;
             for (int64_t p = 0; p < n_periods; ++p) {
-                const double r = periods[p] / dt;                 // samples per period
-                // (the four-slot kernel ranks piles from 9 points on by themselves, 2-3 x an ordinary period: a short
-                // series looks for smaller piles and higher resonances -- flagging too many only reorders the queue)
-                const bool fine_piles = uniform && n <= (int64_t)tlsdev::kSlimThreads * tlsdev::kSlimPer;
-                for (int k = 1; k <= (fine_piles ? 12 : 4); ++k) {
-                    const double a = std::round(r * k);           // r ~ a / k: `a` distinct phase values
-                    if (a < 1 || (double)n / a < (fine_piles ? 9 : 48)) continue;
-                    const double width = (double)n * std::fabs((double)k / a - 1.0 / r);   // phase range of one pile
-                    const double n_buckets = fine_piles ? 0.5 * (double)n : (double)ctx_nb_for(n, widths.size());
-                    if (width * n_buckets < (fine_piles ? 8.0 : 4.0)) { queue_cost[(size_t)p] += 50 * cost[(size_t)p]; break; }
+                const double r = periods[p] * inv_dt;             // samples per period
+                for (int k = 1; k <= k_max; ++k) {
+                    const double rk = r * k, a = std::floor(rk + 0.5);   // r ~ a / k
+                    if (a > a_max) break;
+                    if (a < 1) continue;
+                    // n |k/a - 1/r| n_buckets < limit  <=>  |r k - a| < limit a r / (n n_buckets)
+                    if (std::fabs(rk - a) < drift * a * r) { queue_cost[(size_t)p] += 50 * cost[(size_t)p]; break; }
                 }
             }
         }
