@@ -184,13 +184,15 @@ class transitleastsquares(object):
          transit_depths_uncertainties) = intransit_stats(
             self.t, self.y, transit_times, transit_duration_in_days, chunks=chunks)
         all_flux_intransit = numpy.concatenate([all_flux_intransit_odd, all_flux_intransit_even])
+        std_ootr = numpy.std(flux_ootr)   # (once: the per-epoch SNR and the overall one share it)
         snr_per_transit, snr_pink_per_transit = snr_stats(
             t=self.t, y=self.y, period=period, duration=duration, T0=T0,
             transit_times=transit_times, transit_duration_in_days=transit_duration_in_days,
-            per_transit_count=per_transit_count, chunks=chunks, flux_ootr=flux_ootr)
+            per_transit_count=per_transit_count, chunks=chunks, flux_ootr=flux_ootr,
+            mean_flux=transit_depths, std_ootr=std_ootr)
         depth_mean = numpy.mean(all_flux_intransit)
         depth_mean_std = numpy.std(all_flux_intransit) / numpy.sum(per_transit_count) ** (0.5)
-        snr = ((1 - depth_mean) / numpy.std(flux_ootr)) * len(all_flux_intransit) ** (0.5)
+        snr = ((1 - depth_mean) / std_ootr) * len(all_flux_intransit) ** (0.5)
         rp_rs = rp_rs_from_depth(depth=1 - depth, law=self.limb_dark, params=self.u)
 
         in_transit_count, after_transit_count, before_transit_count = count_stats(

@@ -327,18 +327,25 @@ def intransit_stats(t, y, transit_times, transit_duration_in_days, chunks=None):
 
 
 def snr_stats(t, y, period, duration, T0, transit_times, transit_duration_in_days,
-              per_transit_count, chunks=None, flux_ootr=None):
-    """Per-epoch white-noise and pink-noise SNR (reference stats.py:419-469)."""
+              per_transit_count, chunks=None, flux_ootr=None, mean_flux=None, std_ootr=None):
+    """Per-epoch white-noise and pink-noise SNR (reference stats.py:419-469).  `mean_flux` (the per-epoch means
+    intransit_stats has just formed from the same chunks) and `std_ootr` (numpy.std(flux_ootr)) may be handed in."""
     if flux_ootr is None:
         flux_ootr = y[~transit_mask(t, period, 2 * duration, T0)]
     try:
         pinknoise = pink_noise(flux_ootr, int(numpy.mean(per_transit_count)))
     except Exception:
         pinknoise = numpy.nan
-    std = numpy.std(flux_ootr) if len(flux_ootr) > 0 else numpy.nan
-    if chunks is None:
-        chunks = _intransit_fluxes(t, y, transit_times, transit_duration_in_days)
-    sizes, mean_flux, _ = _segment_means_and_stds(chunks)
+    if std_ootr is not None and len(flux_ootr) > 0:
+        std = std_ootr
+    else:
+        std = numpy.std(flux_ootr) if len(flux_ootr) > 0 else numpy.nan
+    if mean_flux is not None:
+        sizes = numpy.asarray(per_transit_count).astype(numpy.int64)
+    else:
+        if chunks is None:
+            chunks = _intransit_fluxes(t, y, transit_times, transit_duration_in_days)
+        sizes, mean_flux, _ = _segment_means_and_stds(chunks)
     with numpy.errstate(invalid="ignore", divide="ignore"):
         snr_pink = (1 - mean_flux) / pinknoise
         snr_white = (1 - mean_flux) / (std / numpy.sqrt(sizes.astype(float)))
