@@ -173,6 +173,13 @@
         const int p = ap->order[work];
         TLS_CHECK(*ap, p >= 0 && p < ap->n_periods, kChkWorkItem);
         const double period = ap->periods[p];
+#ifndef TLS_BODY_PRIO
+#define TLS_BODY_PRIO 1
+#endif
+#if TLS_BODY_PRIO
+        // (wave priority as in tls_slim_kernel: the round-trip-bound phases ahead of the partner workgroup's dot products)
+        if constexpr (RESIDENT) __builtin_amdgcn_s_setprio(1);
+#endif
         long long t_period = 0;
         if (ap->period_cycles && tid == 0) t_period = clock64();
         PhaseClock pc;
@@ -1212,6 +1219,9 @@
         pc.mark(6);
 
         // ---- phase 3b: sliding dot products, 64 live units of one duration per wave ----
+#if TLS_BODY_PRIO
+        if constexpr (RESIDENT) __builtin_amdgcn_s_setprio(0);   // (see the period's start)
+#endif
         {
             // batches are numbered from the widest row down (long templates first) and handed out
             // dynamically through an LDS ticket counter
@@ -1402,6 +1412,9 @@
                 if constexpr (COUNTING) n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
             }
         }
+#if TLS_BODY_PRIO
+        if constexpr (RESIDENT) __builtin_amdgcn_s_setprio(1);
+#endif
         pc.mark(7);
         }  // position tiles
         if constexpr (BAND) {

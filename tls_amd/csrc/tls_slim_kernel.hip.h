@@ -410,6 +410,11 @@ tls_slim_kernel(const SearchArgs) {
         const int p = ap->order[work];
         TLS_CHECK(*ap, p >= 0 && p < ap->n_periods, kChkWorkItem);
         const double period = ap->periods[p];
+        // Wave priority: the phases that are chains of round trips (sort, gather, prefix sum, predicate, argmin) issue ahead of
+        // the other workgroups' dot products, which fill whatever slots are left -- a latency-bound wave that waits for an
+        // issue slot behind four FMAs a cycle loses more than the FMA-bound one that lets it pass.  Same box: 1.079 -> 1.046 ms
+        // (the other way round: 1.103; the predicate at low priority too: 1.061).
+        __builtin_amdgcn_s_setprio(1);
         long long t_period = 0;
         if (ap->period_cycles && tid == 0) t_period = clock64();
         PhaseClock pc;
@@ -730,6 +735,7 @@ tls_slim_kernel(const SearchArgs) {
 
         // ---- phase 3b: sliding dot products ON X, 64 live units of one duration per wave (core.py:59-74) ----
         {
+            __builtin_amdgcn_s_setprio(0);   // (the FMA-bound phase yields the issue slots: see the period's start)
             const unsigned int total_batches = (unsigned int)__builtin_amdgcn_readfirstlane((int)rt.batch_start[n_rows]);
             int row = n_rows > 0 ? n_rows - 1 : 0;
             for (;;) {
@@ -796,6 +802,7 @@ tls_slim_kernel(const SearchArgs) {
                 if constexpr (COUNTING) n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
             }
         }
+        __builtin_amdgcn_s_setprio(1);
         pc.mark(7);
         } else {
             // The noted windows, one wavefront each: decided by the reference's expression on X = k - numpy.cumsum; a window
