@@ -298,16 +298,16 @@ def run_survey(h, args, inp):
 
 
 def run_shard(h, args, config, steps=None):
-    """Period-shard layout: ONE light curve per step, its period grid block-partitioned by cumulative
-    trial-cell cost (tls_amd/shard.py), one all-gather per light curve."""
+    """Period-shard layout: ONE light curve per step, its period grid dealt out over the ranks (cyclic shares,
+    tls_amd/shard.py: rank r searches periods[r::world]), one all-gather per light curve."""
     ctx = h.ctx
     t, flux, kw = synthetic.config(config, seed=0)
     inp = synthetic.search_inputs(t, flux, **kw)
     job = shard.ShardedSearch(h.rank, h.world)
-    # (every rank derives the boundaries itself, priced for its context's switches; plan() compares the digests of all ranks)
-    lo, hi = job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"], options=ctx.get_options(),
-                      allgather_digests=h.channel.allgather_bytes if h.channel is not None else None)
-    ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"][lo:hi], inp["table"], inp["params"])
+    # (every rank derives the shares itself; plan() compares the digests of all ranks)
+    mine = job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"], options=ctx.get_options(),
+                    allgather_digests=h.channel.allgather_bytes if h.channel is not None else None)
+    ctx.prepare(inp["t"], inp["y"], inp["dy"], numpy.ascontiguousarray(inp["periods"][mine]), inp["table"], inp["params"])
     c = job.count_per_rank
 
     def step(i):
@@ -328,11 +328,11 @@ def run_shard(h, args, config, steps=None):
     argmin = None
     if h.collective == "rccl":
         g = ctx.comm_fetch_gathered(c, h.world)
-        chi2 = shard.assemble(g[0], job.bounds, c)
+        chi2 = job.assemble(g[0])
         assert len(chi2) == len(inp["periods"])
         argmin = int(numpy.argmin(chi2))
-    cells = numpy.array([numpy.sum(job.costs[job.bounds[r]:job.bounds[r + 1]]) for r in range(h.world)], dtype=float)
-    model = numpy.array([numpy.sum(job.times[job.bounds[r]:job.bounds[r + 1]]) for r in range(h.world)], dtype=float)
+    cells = numpy.array([numpy.sum(job.costs[job.indices(r)]) for r in range(h.world)], dtype=float)
+    model = numpy.array([numpy.sum(job.times[job.indices(r)]) for r in range(h.world)], dtype=float)
     total = float(numpy.sum(job.costs))
     # measured balance: every rank's own kernel time per step (HIP events), gathered over the host channel
     kernel_ms_ranks = None
@@ -349,7 +349,7 @@ def run_shard(h, args, config, steps=None):
             "kernel_ms_per_rank": kernel_ms_ranks,
             "measured_time_imbalance_max_over_mean": (float(max(kernel_ms_ranks) / (sum(kernel_ms_ranks) / len(kernel_ms_ranks)))
                                                       if kernel_ms_ranks else None),
-            "periods_per_rank": [int(job.bounds[r + 1] - job.bounds[r]) for r in range(h.world)],
+            "layout": job.layout, "periods_per_rank": [int(len(job.indices(r))) for r in range(h.world)],
             "argmin_period_index": argmin}
 
 
@@ -414,25 +414,32 @@ def large_config(ctx, name, reps, warm=0):
 
 
 def shard_balance(ctx, name, n_blocks=8, reps=3):
-    """The period-shard layout measured on ONE GPU: the grid cut into `n_blocks` contiguous blocks by the time
-    model (tls_amd/shard.py), every block searched alone -- what each of `n_blocks` ranks would run -- and its kernel
-    time taken with HIP events.  max/mean of those times is the balance an 8-GPU run would see (the all-gather of
-    24 B per period aside); the same for blocks placed by trial cells alone is what round 2 shipped."""
+    """The period-shard layout measured on ONE GPU: the grid cut into the `n_blocks` shares the ranks of an 8-GPU search
+    would take (tls_amd/shard.py: cyclic, rank r searches periods[r::8]), every share searched alone -- what each rank
+    would run, in the kernel a launch of that size takes -- and its kernel time taken with HIP events.  whole-grid time /
+    slowest share = the speed-up 8 ranks would see (the all-gather of 24 B per period aside).  Beside it the layouts of
+    earlier rounds: contiguous blocks placed by the fitted time model (rounds 3-5) and by trial cells alone (round 2)."""
     t, flux, kw = synthetic.config(name, seed=0)
     inp = synthetic.search_inputs(t, flux, **kw)
     out = {"config": name, "blocks": n_blocks, "periods": len(inp["periods"])}
-    whole_ms = None
-    for label in ("time_model", "cells_only"):
-        job = shard.ShardedSearch(0, n_blocks)
-        job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"], options=ctx.get_options())
-        bounds = job.bounds if label == "time_model" else shard.partition_by_cost(job.costs, n_blocks)
-        ms = []
+    job = shard.ShardedSearch(0, n_blocks, layout="blocks")
+    job.plan(inp["t"], inp["periods"], inp["table"], inp["params"], y=inp["y"], options=ctx.get_options())
+    n_per = len(inp["periods"])
+    layouts = (("cyclic", [shard.cyclic_indices(n_per, n_blocks, r) for r in range(n_blocks)]),
+               ("time_model", [numpy.arange(job.bounds[r], job.bounds[r + 1]) for r in range(n_blocks)]),
+               ("cells_only", None))
+    for label, shares in layouts:
+        if shares is None:
+            b = shard.partition_by_cost(job.costs, n_blocks)
+            shares = [numpy.arange(b[r], b[r + 1]) for r in range(n_blocks)]
+        ms, kernels = [], set()
         for r in range(n_blocks):
-            ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"][bounds[r]:bounds[r + 1]], inp["table"], inp["params"])
+            ctx.prepare(inp["t"], inp["y"], inp["dy"], numpy.ascontiguousarray(inp["periods"][shares[r]]), inp["table"], inp["params"])
             ctx.execute()
             ctx.synchronize()
             ms.append(ctx.execute_timed(reps))
-        out[label] = {"periods_per_block": [int(bounds[r + 1] - bounds[r]) for r in range(n_blocks)],
+            kernels.add(ctx.last_kernel())
+        out[label] = {"periods_per_block": [int(len(ix)) for ix in shares], "kernel": sorted(kernels),
                       "kernel_ms_per_block": ms, "max_over_mean": max(ms) / (sum(ms) / len(ms)),
                       "slowest_block_ms": max(ms)}
     ctx.prepare(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
@@ -440,7 +447,9 @@ def shard_balance(ctx, name, n_blocks=8, reps=3):
     ctx.synchronize()
     whole_ms = ctx.execute_timed(reps)
     out["whole_grid_kernel_ms"] = whole_ms
-    out["speedup_if_ranks_ran_the_blocks"] = whole_ms / out["time_model"]["slowest_block_ms"]
+    out["layout"] = "cyclic"
+    out["speedup_if_ranks_ran_the_blocks"] = whole_ms / out["cyclic"]["slowest_block_ms"]
+    out["speedup_contiguous_time_model"] = whole_ms / out["time_model"]["slowest_block_ms"]
     return out
 
 

@@ -31,9 +31,10 @@ extern "C" {
 #endif
 
 /* Bumped whenever a struct of this header changes its layout or an entry point its signature (3: tls_counters has
- * five fields, tls_period_costs / tls_power_batch exist; 4: tls_options, tls_get_options / tls_set_options).  A binding
- * compares it with tls_abi_version(). */
-#define TLS_AMD_ABI_VERSION 4
+ * five fields, tls_period_costs / tls_power_batch exist; 4: tls_options, tls_get_options / tls_set_options; 5: tls_options
+ * keeps the two caller-facing switches, the developer switches moved behind tls_debug_set_switch, tls_period_costs takes
+ * them as text).  A binding compares it with tls_abi_version(). */
+#define TLS_AMD_ABI_VERSION 5
 
 #define TLS_OK 0
 #define TLS_E_ARG (-1)      /* invalid argument */
@@ -73,32 +74,14 @@ typedef struct tls_params {
     double T0_fit_margin;
 } tls_params;
 
-/* Switches of a context: the prefix-sum mode a caller may ask for, and the developer / test switches that select
- * kernel variants and launch shapes for A/B runs.  Every field: -1 (band_max, prune_min_live: negative) = the library
- * decides.  They are resolved ONCE per process from the TLS_* environment variables named beside them (so that the
- * A/B tools keep working), copied into every context at tls_ctx_create, and changed afterwards only through
- * tls_set_options: no call of this library reads the environment after that.  The options are part of what a
- * prepared plan is keyed by (tls_prepare plans again when they change); none of them changes a result beyond the
- * 1e-10 (relative, chi^2) between the two prefix-sum modes that DESIGN.md section 3 describes. */
+/* Switches of a context a caller may set: -1 = the library decides.  They are part of what a prepared plan is keyed by
+ * (tls_prepare plans again when they change).  Neither changes a result beyond the distance between the two prefix-sum
+ * modes that DESIGN.md section 3 describes (1e-10 relative on chi^2 for a normalised flux; it scales with
+ * max|flux| (N + W) 2^-53 / transit depth otherwise).  The developer / test switches that select kernel variants and
+ * launch shapes for A/B runs are NOT part of this struct: tls_debug_set_switch below. */
 typedef struct tls_options {
-    int32_t exact_prefix;   /* TLS_EXACT_PREFIX  1: every period in exact prefix-sum mode (X = k - numpy.cumsum, bit for bit) */
-    int32_t prune;          /* TLS_PRUNE         0 / 1: never / always the pruning kernel variant */
-    int32_t screen32;       /* TLS_SCREEN32      0 / 1: never / always (where admissible) the fp32-screen variant */
-    int32_t no_screen;      /* TLS_NO_SCREEN     1: pruning with the one-segment bound only */
-    int32_t fast_slab;      /* TLS_FAST_SLAB     0: series in the HBM slab always in exact prefix-sum mode */
-    int32_t x_staged;       /* TLS_X_STAGED      0: slab variant, fast mode: keep the prefix-sum pass */
-    int32_t split;          /* TLS_SPLIT         0 / 1: never / always the two-role slab kernel (exact mode only) */
-    int32_t split_batch;    /* TLS_SPLIT_BATCH   periods per batch of the two-role kernel */
-    int32_t sort2;          /* TLS_SORT2         0: slab variant without the two-level sort */
-    int32_t sort3;          /* TLS_SORT3         1: slab variant with the fused partition + per-bin sort + prefix sum */
-    int32_t stage_c;        /* TLS_STAGE_C       0 / 1: slab tiles without / with X staged beside the samples */
-    int32_t slab_wgs;       /* TLS_SLAB_WGS      2: two 512-thread workgroups per CU in the slab variant */
-    int32_t threads;        /* TLS_THREADS       threads per workgroup */
-    int32_t blocks;         /* TLS_BLOCKS        workgroups in flight (at most) */
-    int32_t plan_threads;   /* TLS_PLAN_THREADS  host threads of the per-period planning */
-    int32_t slim;           /* TLS_SLIM          0: never the four-slots-per-CU kernel of short LDS-resident series */
-    int64_t prune_min_live; /* TLS_PRUNE_MIN_LIVE live units per period (tile) from which the pruning passes run */
-    double band_max;        /* TLS_BAND_MAX      expected band hits above which a slab period starts in exact mode */
+    int32_t exact_prefix;   /* 1: every period in exact prefix-sum mode (X = k - numpy.cumsum, bit for bit) */
+    int32_t slim;           /* 0: never the four-slots-per-CU kernel of short LDS-resident series (the classic kernel instead) */
 } tls_options;
 
 /* ---- context ------------------------------------------------------------------- */
@@ -113,6 +96,15 @@ const char *tls_device_name(const tls_ctx *ctx);
 /* the context's switches (see tls_options); tls_set_options drops a prepared plan (the next tls_prepare plans again) */
 int tls_get_options(const tls_ctx *ctx, tls_options *out);
 int tls_set_options(tls_ctx *ctx, const tls_options *opt);
+/* Developer / test switches, by name (not part of the stable ABI; negative value = the library decides): exact_prefix, slim
+ * (the two of tls_options), prune, screen32, no_screen (kernel variant of an LDS-resident series), fast_slab, x_staged,
+ * sort2, split, split_batch, parts (series in the HBM slab: prefix-sum mode, sort, two-role kernel, sub-period work items),
+ * threads, blocks, plan_threads (launch shape, host planning), prune_min_live, band_max.  A context starts with the values
+ * of the TLS_<NAME> environment variables, read once per process; no call reads the environment after that.
+ * tls_debug_get_switches writes all of them as "name=value,name=value" (ctx NULL: the process's) -- the text
+ * tls_period_costs takes, so that the planning call prices the kernel the searching context will run. */
+int tls_debug_set_switch(tls_ctx *ctx, const char *name, double value);
+int tls_debug_get_switches(const tls_ctx *ctx, char *out, int64_t capacity);
 
 /* ---- one-shot search: replaces main.py:140-196 for one light curve -------------- */
 /* out_chi2/out_row/out_depth have n_periods entries, index i belongs to periods[i].
@@ -201,7 +193,7 @@ int tls_plan_info(const tls_ctx *ctx, tls_counters *counters, int64_t *lds_bytes
                   int64_t *n_blocks, int64_t *resident /* 1: folded series kept in LDS */);
 /* Which search kernel the context's last tls_execute launched: "resident" (LDS-resident series, two or one workgroups
  * per CU), "resident+prune", "resident+screen32", "slim" (LDS-resident, four 256-thread workgroups per CU), "slab",
- * "slab+prune", "slab+split"; "" before the first launch.  The string is static. */
+ * "slab+split"; "" before the first launch.  The string is static. */
 const char *tls_last_kernel(const tls_ctx *ctx);
 
 /* ---- final T0 fit: the batched counterpart of stats.py:135-204 ------------------------ */
@@ -261,8 +253,8 @@ int tls_period_costs(const double *t, int64_t n, const double *periods, int64_t 
                      const tls_template *tmpl, const tls_params *params, double sigma,
                      int64_t *cells_per_period, double *taps_per_period, double *time_per_period,
                      int64_t *workgroups_in_flight /* periods one MI355X searches side by side, may be NULL */,
-                     const tls_options *options /* the switches of the context that will search (tls_get_options): the
-                                                   kernel variant and prefix-sum mode follow them; NULL: the process's */);
+                     const char *switches /* "name=value,..." of the context that will search (tls_debug_get_switches):
+                                             the kernel variant and prefix-sum mode follow them; NULL: the process's */);
 
 /* ---- multi-GPU: period grid sharded over ranks, one RCCL all-gather at the end --- */
 /* rank 0 creates the 128-byte id and hands it to the other ranks by any host channel */

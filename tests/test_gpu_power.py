@@ -232,8 +232,8 @@ def test_devices_list_shards_the_period_grid_bit_for_bit(name, devices):
     try:
         got = group.search(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], inp["params"])
         assert group.last_collective == "host_concatenate"
-        blocks = numpy.diff(group.last_blocks)
-        assert len(blocks) == len(devices) and blocks.sum() == len(inp["periods"]) and blocks.min() > 0
+        blocks = numpy.asarray(group.last_blocks)   # periods per context: the grid dealt out cyclically
+        assert len(blocks) == len(devices) and blocks.sum() == len(inp["periods"]) and blocks.max() - blocks.min() <= 1
         for a, b in zip(got, want[:3]):
             numpy.testing.assert_array_equal(a, b)
         assert int(numpy.argmin(got[0])) == int(numpy.argmin(want[0]))
@@ -254,6 +254,28 @@ def test_power_with_a_devices_list_returns_the_one_device_results():
         assert list(other.keys()) == list(plain.keys())
         for k in plain.keys():
             numpy.testing.assert_array_equal(numpy.asarray(other[k], dtype=float), numpy.asarray(plain[k], dtype=float), err_msg=k)
+
+
+def test_auto_devices_on_a_one_gpu_box_is_the_one_device_search():
+    """power()'s default devices="auto" (reference: use_threads = cpu_count(), validate.py:81): with one visible GPU it is the
+    plain one-device call -- same context, same bits -- and an explicit device= or devices=[0] changes nothing."""
+    from tls_amd import _lib, search as tsearch
+    t, f = synthetic.light_curve(30.0, 48, 2e-4, per=4.321, rp=0.05, a=12)
+    kw = dict(period_min=1.0, period_max=9.0, oversampling_factor=2, show_progress_bar=False, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        auto = tls_amd.transitleastsquares(t, f, verbose=False).power(**kw)
+        named = tls_amd.transitleastsquares(t, f, verbose=False).power(devices="auto", **kw)
+        single = tls_amd.transitleastsquares(t, f, verbose=False).power(device=0, **kw)
+    for other in (named, single):
+        for k in auto.keys():
+            numpy.testing.assert_array_equal(numpy.asarray(other[k], dtype=float), numpy.asarray(auto[k], dtype=float), err_msg=k)
+    if _lib.device_count() == 1:
+        inp = synthetic.search_inputs(t, f, period_min=1.0, period_max=9.0, oversampling_factor=2)
+        assert tsearch.auto_devices(inp["t"], inp["y"], inp["periods"], inp["table"], inp["params"]) is None
+        used = {}
+        tsearch.search_periods(inp["t"], inp["y"], inp["dy"], inp["periods"], inp["table"], devices="auto", used=used, **inp["params"])
+        assert used["context"] is tsearch.default_context(None) and used["devices"] == [0]
 
 
 def test_survey_batches_over_a_devices_list_equal_the_one_device_batch():

@@ -17,12 +17,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtls_amd.so")
 if os.environ.get("TLS_AMD_DEBUG") == "1" and os.environ.get("TLS_AMD_LIB"):
     LIB_PATH = os.environ["TLS_AMD_LIB"]
-ABI_VERSION = 4   # include/tls_amd.h TLS_AMD_ABI_VERSION: checked against the library at load time
+ABI_VERSION = 5   # include/tls_amd.h TLS_AMD_ABI_VERSION: checked against the library at load time
 
 # every symbol include/tls_amd.h declares (tests check the export list against the header)
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version", "tls_abi_version",
-    "tls_device_name", "tls_get_options", "tls_set_options", "tls_search", "tls_search_batch", "tls_power_batch", "tls_prepare", "tls_update_flux", "tls_execute",
+    "tls_device_name", "tls_get_options", "tls_set_options", "tls_debug_set_switch", "tls_debug_get_switches", "tls_search", "tls_search_batch", "tls_power_batch", "tls_prepare", "tls_update_flux", "tls_execute",
     "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_last_kernel", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_poison_lds", "tls_debug_period_cycles",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_info", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
@@ -45,17 +45,23 @@ class _Params(ctypes.Structure):
 
 
 class Options(ctypes.Structure):
-    """tls_options: the switches of a context (include/tls_amd.h).  -1 / negative = the library decides."""
-    _fields_ = [(name, ctypes.c_int32) for name in (
-        "exact_prefix", "prune", "screen32", "no_screen", "fast_slab", "x_staged", "split", "split_batch", "sort2", "sort3",
-        "stage_c", "slab_wgs", "threads", "blocks", "plan_threads", "slim")] + [
-        ("prune_min_live", ctypes.c_int64), ("band_max", ctypes.c_double)]
+    """tls_options: the two switches of a context a caller may set (include/tls_amd.h).  -1 = the library decides."""
+    _fields_ = [("exact_prefix", ctypes.c_int32), ("slim", ctypes.c_int32)]
 
-    NAMES = ("exact_prefix", "prune", "screen32", "no_screen", "fast_slab", "x_staged", "split", "split_batch", "sort2",
-             "sort3", "stage_c", "slab_wgs", "threads", "blocks", "plan_threads", "slim", "prune_min_live", "band_max")
+    NAMES = ("exact_prefix", "slim")
 
-    def as_dict(self):
-        return {k: getattr(self, k) for k in self.NAMES}
+
+# every switch tls_debug_set_switch knows (the two public ones included): Context.set_options(**switches) takes them all
+SWITCH_NAMES = ("exact_prefix", "slim", "prune", "screen32", "no_screen", "fast_slab", "x_staged", "split", "split_batch", "sort2",
+                "threads", "blocks", "plan_threads", "parts", "prune_min_live", "band_max")
+
+
+def switches_text(switches):
+    """"name=value,..." (what tls_period_costs and tls_debug_get_switches speak) from a dict; None values are left out."""
+    unknown = set(switches or {}) - set(SWITCH_NAMES)
+    if unknown:
+        raise TypeError("unknown switches %s" % sorted(unknown))
+    return ",".join("%s=%.17g" % (k, float(v)) for k, v in sorted((switches or {}).items()) if v is not None)
 
 
 class PowerSummary(ctypes.Structure):
@@ -112,6 +118,10 @@ def load():
     lib.tls_get_options.argtypes = [vp, ctypes.POINTER(Options)]
     lib.tls_set_options.restype = ci
     lib.tls_set_options.argtypes = [vp, ctypes.POINTER(Options)]
+    lib.tls_debug_set_switch.restype = ci
+    lib.tls_debug_set_switch.argtypes = [vp, ctypes.c_char_p, dbl]
+    lib.tls_debug_get_switches.restype = ci
+    lib.tls_debug_get_switches.argtypes = [vp, ctypes.c_char_p, i64]
     tp, pp = ctypes.POINTER(_Template), ctypes.POINTER(_Params)
     cp = ctypes.POINTER(Counters)
     lib.tls_search.restype = ci
@@ -165,7 +175,7 @@ def load():
     lib.tls_grid_cells.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, _c_int64_p]
     lib.tls_period_costs.restype = ci
     lib.tls_period_costs.argtypes = [_c_double_p, i64, _c_double_p, i64, tp, pp, dbl, _c_int64_p, _c_double_p, _c_double_p,
-                                     _c_int64_p, ctypes.POINTER(Options)]
+                                     _c_int64_p, ctypes.c_char_p]
     lib.tls_comm_unique_id.restype = ci
     lib.tls_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.tls_comm_init.restype = ci
@@ -248,27 +258,39 @@ class Context(object):
     # -- switches (tls_options): the environment is read once per process, when the library is first used; a context
     #    starts with those values and changes them only through these calls
     def get_options(self):
-        o = Options()
-        rc = self._lib.tls_get_options(self._h, ctypes.byref(o))
+        """Every switch of the context by name (the public tls_options and the developer switches): -1 = the library decides."""
+        buf = ctypes.create_string_buffer(1024)
+        rc = self._lib.tls_debug_get_switches(self._h, buf, len(buf))
         if rc != 0:
-            raise RuntimeError("tls_amd error %d: tls_get_options" % rc)
-        return o.as_dict()
+            raise RuntimeError("tls_amd error %d: tls_debug_get_switches" % rc)
+        out = {}
+        for item in buf.value.decode().split(","):
+            k, _, v = item.partition("=")
+            out[k] = float(v) if k == "band_max" else int(float(v))
+        return out
 
     def set_options(self, **switches):
         """Set the named switches (None: back to "the library decides"); the others keep their values.  Drops a
-        prepared plan: the next prepare()/search() plans again."""
-        o = Options()
-        self._check(self._lib.tls_get_options(self._h, ctypes.byref(o)))
+        prepared plan: the next prepare()/search() plans again.  exact_prefix and slim go through the public
+        tls_set_options, the developer switches through tls_debug_set_switch."""
+        for k in switches:
+            if k not in SWITCH_NAMES:
+                raise TypeError("unknown switch %r (known: %s)" % (k, ", ".join(SWITCH_NAMES)))
+        self._invalidate_results()
+        public = {k: v for k, v in switches.items() if k in Options.NAMES}
+        if public:
+            o = Options()
+            self._check(self._lib.tls_get_options(self._h, ctypes.byref(o)))
+            for k, v in public.items():
+                setattr(o, k, -1 if v is None else int(v))
+            self._check(self._lib.tls_set_options(self._h, ctypes.byref(o)))
         for k, v in switches.items():
             if k not in Options.NAMES:
-                raise TypeError("unknown switch %r (known: %s)" % (k, ", ".join(Options.NAMES)))
-            setattr(o, k, (-1.0 if k == "band_max" else -1) if v is None else (float(v) if k == "band_max" else int(v)))
-        self._invalidate_results()
-        self._check(self._lib.tls_set_options(self._h, ctypes.byref(o)))
+                self._check(self._lib.tls_debug_set_switch(self._h, k.encode(), -1.0 if v is None else float(v)))
 
     def reset_options(self):
         """Every switch back to "the library decides" (NOT to the process environment's values)."""
-        self.set_options(**{k: None for k in Options.NAMES})
+        self.set_options(**{k: None for k in SWITCH_NAMES})
 
     @staticmethod
     def _pack(table, params):
@@ -591,18 +613,6 @@ def grid_cells(t, periods, table, params):
     return out
 
 
-def options_struct(switches):
-    """tls_options from a dict of switches (missing / None: the library decides)."""
-    o = Options()
-    for k in Options.NAMES:
-        v = (switches or {}).get(k)
-        setattr(o, k, (-1.0 if k == "band_max" else -1) if v is None else (float(v) if k == "band_max" else int(v)))
-    unknown = set(switches or {}) - set(Options.NAMES)
-    if unknown:
-        raise TypeError("unknown switches %s" % sorted(unknown))
-    return o
-
-
 def period_costs(t, periods, table, params, sigma, with_slots=False, options=None):
     """(trial cells, expected template taps, modelled search time) of every period: what the shard
     boundaries are placed by (host-only planning call, needs no GPU).  options: the switches of the context
@@ -615,7 +625,7 @@ def period_costs(t, periods, table, params, sigma, with_slots=False, options=Non
     taps = numpy.zeros(len(periods), dtype=numpy.float64)
     time = numpy.zeros(len(periods), dtype=numpy.float64)
     slots = ctypes.c_int64(0)
-    opt = None if options is None else ctypes.byref(options_struct(options))
+    opt = None if options is None else switches_text({k: v for k, v in options.items() if v is not None and float(v) >= 0}).encode()
     rc = lib.tls_period_costs(_dp(t), len(t), _dp(periods), len(periods), ctypes.byref(tm), ctypes.byref(pr),
                               float(sigma), _ip(cells), _dp(taps), _dp(time), ctypes.byref(slots), opt)
     if rc != 0:

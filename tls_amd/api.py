@@ -94,26 +94,24 @@ class transitleastsquares(object):
         # back ordered like the ascending period grid (main.py:190-196)
         test_statistic_periods = numpy.sort(numpy.asarray(periods, dtype=numpy.float64))
         table = TemplateTable(lc_cache_overview, lc_arr)
-        # devices=[...]: the period grid sharded over several GPUs of this process (tls_amd.search.DeviceGroup: one context
-        # and one host thread per device, blocks by modelled time, one RCCL all-gather) -- the counterpart of the
-        # reference's use_threads pool over periods (main.py:140-163, validate.py:81)
-        group, listed = None, kwargs.get("devices")
-        if isinstance(listed, _search.DeviceGroup):
-            group = listed
-        elif listed is not None and len(listed) > 1:
-            group = _search.device_group(listed)
-        elif listed is not None and kwargs.get("device") is None and kwargs.get("context") is None:
-            kwargs = dict(kwargs, device=int(list(listed)[0]))
+        # devices: the period grid sharded over several GPUs of this process (tls_amd.search.DeviceGroup: one context and
+        # one host thread per device, blocks by modelled time, one RCCL all-gather) -- the counterpart of the reference's
+        # use_threads pool over periods (main.py:140-163).  Default "auto", like use_threads = cpu_count()
+        # (validate.py:81): every visible GPU when the modelled one-GPU time exceeds the overhead of sharding, one GPU
+        # otherwise (search.auto_devices); a list names the GPUs; device= / context= keep the search on one.
+        # (resolved inside search_periods, the one function that knows the HIP library; `used` brings back the context the
+        # rest of power() -- spectra, final T0 fit -- runs on: the single device's, or the group's first)
+        used = {}
         chi2, test_statistic_rows, test_statistic_depths = _search.search_periods(
             self.t, self.y, self.dy, test_statistic_periods, table,
             transit_depth_min=self.transit_depth_min,
             R_star_min=self.R_star_min, R_star_max=self.R_star_max,
             M_star_min=self.M_star_min, M_star_max=self.M_star_max,
             T0_fit_margin=self.T0_fit_margin,
-            context=kwargs.get("context"), device=kwargs.get("device"), devices=group,
-            verbose=self.verbose)
-        if group is not None:   # (what follows -- spectra, final T0 fit -- runs on the group's first device)
-            kwargs = dict(kwargs, context=group.contexts[0])
+            context=kwargs.get("context"), device=kwargs.get("device"), devices=kwargs.get("devices", "auto"),
+            verbose=self.verbose, used=used)
+        if used.get("context") is not None:
+            kwargs = dict(kwargs, context=used["context"], device=None)
 
         idx_best = numpy.argmin(chi2)
         best_row = test_statistic_rows[idx_best]

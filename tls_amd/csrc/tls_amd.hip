@@ -80,11 +80,88 @@ struct View {
     T* ptr = nullptr;
 };
 
+// The switches of a context.  Two are public (tls_options: exact_prefix, slim); the others are developer / test switches
+// that select kernel variants and launch shapes for A/B runs, reached by name through tls_debug_set_switch (never part
+// of the stable ABI).  -1 (band_max, prune_min_live: negative) = the library decides.
+struct Switches {
+    int32_t exact_prefix, slim;
+    int32_t prune, screen32, no_screen, fast_slab, x_staged, split, split_batch, sort2, threads, blocks, plan_threads;
+    int32_t parts;           // two-role kernel: shares of a period's duration rows a (period, tile) item is cut into
+    int64_t prune_min_live;
+    double band_max;
+};
+struct SwitchName { const char* name; const char* env; size_t offset; int kind; };   // kind 0: int32, 1: int64, 2: double
+#define TLS_SW(field, env, kind) { #field, env, offsetof(Switches, field), kind }
+const SwitchName kSwitchNames[] = {
+    TLS_SW(exact_prefix, "TLS_EXACT_PREFIX", 0), TLS_SW(slim, "TLS_SLIM", 0), TLS_SW(prune, "TLS_PRUNE", 0),
+    TLS_SW(screen32, "TLS_SCREEN32", 0), TLS_SW(no_screen, "TLS_NO_SCREEN", 0), TLS_SW(fast_slab, "TLS_FAST_SLAB", 0),
+    TLS_SW(x_staged, "TLS_X_STAGED", 0), TLS_SW(split, "TLS_SPLIT", 0), TLS_SW(split_batch, "TLS_SPLIT_BATCH", 0),
+    TLS_SW(sort2, "TLS_SORT2", 0), TLS_SW(threads, "TLS_THREADS", 0), TLS_SW(blocks, "TLS_BLOCKS", 0),
+    TLS_SW(plan_threads, "TLS_PLAN_THREADS", 0), TLS_SW(parts, "TLS_PARTS", 0), TLS_SW(prune_min_live, "TLS_PRUNE_MIN_LIVE", 1),
+    TLS_SW(band_max, "TLS_BAND_MAX", 2),
+};
+#undef TLS_SW
+const SwitchName* find_switch(const char* name) {
+    for (const auto& sw : kSwitchNames) if (name && std::strcmp(sw.name, name) == 0) return &sw;
+    return nullptr;
+}
+void switch_store(Switches& o, const SwitchName& sw, double value) {
+    unsigned char* at = reinterpret_cast<unsigned char*>(&o) + sw.offset;
+    if (sw.kind == 0) { const int32_t v = value < 0 ? -1 : (int32_t)value; std::memcpy(at, &v, sizeof v); }
+    else if (sw.kind == 1) { const int64_t v = value < 0 ? -1 : (int64_t)value; std::memcpy(at, &v, sizeof v); }
+    else { const double v = value < 0 ? -1.0 : value; std::memcpy(at, &v, sizeof v); }
+}
+double switch_load(const Switches& o, const SwitchName& sw) {
+    const unsigned char* at = reinterpret_cast<const unsigned char*>(&o) + sw.offset;
+    if (sw.kind == 0) { int32_t v; std::memcpy(&v, at, sizeof v); return (double)v; }
+    if (sw.kind == 1) { int64_t v; std::memcpy(&v, at, sizeof v); return (double)v; }
+    double v; std::memcpy(&v, at, sizeof v); return v;
+}
+// every switch "the library decides" (all bytes defined: plans are keyed by memcmp over the struct)
+Switches default_switches() {
+    Switches o;
+    std::memset(&o, 0, sizeof o);
+    for (const auto& sw : kSwitchNames) switch_store(o, sw, -1.0);
+    return o;
+}
+// "name=value,name=value" (what tls_debug_get_switches writes) over a set of switches; false on an unknown name
+bool switches_parse(Switches& o, const char* spec) {
+    if (!spec) return true;
+    std::string text(spec);
+    size_t at = 0;
+    while (at < text.size()) {
+        size_t end = text.find(',', at);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(at, end - at);
+        at = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos) return false;
+        const SwitchName* sw = find_switch(item.substr(0, eq).c_str());
+        if (!sw) return false;
+        switch_store(o, *sw, std::atof(item.c_str() + eq + 1));
+    }
+    return true;
+}
+
+// The TLS_* environment variables (one per switch, kSwitchNames), read ONCE per process: what a new context starts with and
+// what the context-free planning call (tls_period_costs) uses when it is given no switches.  Nothing reads the environment
+// after this.
+const Switches& process_options() {
+    static const Switches cached = [] {
+        Switches o = default_switches();
+        for (const auto& sw : kSwitchNames)
+            if (const char* v = std::getenv(sw.env)) switch_store(o, sw, (*v == 0 && sw.kind == 0) ? 1.0 : std::atof(v));
+        return o;
+    }();
+    return cached;
+}
+
 // what a prepared plan was built from: a second tls_prepare with the same time stamps, period list, template table,
 // parameters and developer switches only replaces the flux (the search call of a survey, or of repeated power()
 // calls).  Compared byte for byte (memcmp runs at ~10 GB/s; a cfg2 key is 120 KB).
 struct PlanLayout {   // byte offsets of the plan arrays inside d_plan / h_stage (256-byte aligned)
-    size_t t = 0, y = 0, w = 0, periods = 0, order = 0, rows = 0, widths = 0, screens = 0, q = 0, q2 = 0, g = 0, tile_prefix = 0, total = 0;
+    size_t t = 0, y = 0, w = 0, periods = 0, order = 0, rows = 0, widths = 0, screens = 0, q = 0, q2 = 0, g = 0, tile_prefix = 0, row_cost = 0, total = 0;
 };
 
 struct PlanKey {
@@ -93,39 +170,8 @@ struct PlanKey {
     std::vector<double> t, periods, values, overshoot;
     std::vector<int64_t> offset, length, width;
     tls_params params = {0, 0, 0, 0, 0, 0};
-    tls_options opt;
+    Switches opt;
 };
-
-// every switch "the library decides"
-tls_options default_options() {
-    tls_options o;
-    std::memset(&o, 0, sizeof o);
-    o.exact_prefix = o.prune = o.screen32 = o.no_screen = o.fast_slab = o.x_staged = o.split = o.split_batch = -1;
-    o.sort2 = o.sort3 = o.stage_c = o.slab_wgs = o.threads = o.blocks = o.plan_threads = -1;
-    o.slim = -1;
-    o.prune_min_live = -1;
-    o.band_max = -1.0;
-    return o;
-}
-
-// The TLS_* environment variables (include/tls_amd.h, tls_options), read ONCE per process: what a new context starts
-// with and what the context-free planning calls (tls_period_costs) use.  Nothing reads the environment after this.
-const tls_options& process_options() {
-    static const tls_options cached = [] {
-        tls_options o = default_options();
-        auto geti = [](const char* name, int32_t& field) { if (const char* v = std::getenv(name)) field = (int32_t)std::atoi(v); };
-        geti("TLS_EXACT_PREFIX", o.exact_prefix); geti("TLS_PRUNE", o.prune); geti("TLS_SCREEN32", o.screen32);
-        if (std::getenv("TLS_NO_SCREEN")) o.no_screen = 1;
-        geti("TLS_FAST_SLAB", o.fast_slab); geti("TLS_X_STAGED", o.x_staged); geti("TLS_SPLIT", o.split);
-        geti("TLS_SPLIT_BATCH", o.split_batch); geti("TLS_SORT2", o.sort2); geti("TLS_SORT3", o.sort3);
-        geti("TLS_STAGE_C", o.stage_c); geti("TLS_SLAB_WGS", o.slab_wgs); geti("TLS_THREADS", o.threads);
-        geti("TLS_BLOCKS", o.blocks); geti("TLS_PLAN_THREADS", o.plan_threads); geti("TLS_SLIM", o.slim);
-        if (const char* v = std::getenv("TLS_PRUNE_MIN_LIVE")) o.prune_min_live = std::atoll(v);
-        if (const char* v = std::getenv("TLS_BAND_MAX")) o.band_max = std::atof(v);
-        return o;
-    }();
-    return cached;
-}
 
 }  // namespace
 
@@ -175,8 +221,6 @@ struct tls_ctx {
     const double* over_S0 = nullptr; const double* over_w0 = nullptr;
     double* over_chi2 = nullptr; long long* over_row = nullptr; double* over_depth = nullptr;
     bool sort2 = false;                      // tiled variant: two-level sort
-    bool sort3 = false;                      // tiled variant, one light curve: fused partition + per-bin sort + prefix sum
-    DevBuf<unsigned long long> d_sort3;      // its pass-1 output
     int batch_curves = 1;                    // light curves the next launch searches (tls_search_batch)
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
     DevBuf<double> d_spec;                                         // SDE spectra: SR | power_raw | power | sde[2] | chi2 copy
@@ -185,7 +229,10 @@ struct tls_ctx {
     bool split = false;                      // the plan supports it (enqueue uses it for single-curve launches)
     int split_blocks = 0;                    // workgroups of its launches (not capped by the number of periods: tiles are items too)
     int split_batch = 0;                     // periods per batch: as many slabs are held in HBM
-    int64_t split_max_items = 0;             // most (period, tile) items of any batch
+    int64_t split_max_items = 0;             // most (period, tile, row part) items of any batch
+    bool split_fast = false;                 // the two roles may run fast prefix-sum mode (uniform weights, X at staging, dot products on X)
+    int row_parts = 1;                       // shares of a period's duration rows a (period, tile) item is cut into
+    View<double> d_row_cost;                 // [n_widths + 1] expected work of the rows < k: places the shares
     View<unsigned int> d_tile_prefix;        // [n_periods + 1] tiles in front of work item w (queue order)
     std::vector<unsigned int> host_tile_prefix;
     DevBuf<double> d_partials;               // [split_max_items][3] a tile's winner
@@ -193,9 +240,8 @@ struct tls_ctx {
     int hdr_bytes = 0, tile_len = 0, tile_halo = 0, region_pad = 0, p2_shift = 4;
     bool prune_kernel = false;        // launch the pruning variant (pruning_pays)
     std::vector<tlsdev::WidthEntry> host_widths;  // kept for tls_update_flux's pruning decision
-    long long prune_min_live = 256;   // live units per period (tile) from which pruning pays; tls_options::prune_min_live overrides
-    tls_options opt;                  // the context's switches (tls_set_options; initially the process's TLS_* environment)
-    bool stage_c = false;
+    long long prune_min_live = 256;   // live units per period (tile) from which pruning pays; switch prune_min_live overrides
+    Switches opt;                     // the context's switches (tls_set_options / tls_debug_set_switch; initially the process's TLS_* environment)
 
     // host-side plan
     bool prepared = false, executed = false;
@@ -277,7 +323,7 @@ size_t template_values(const tls_template* tmpl) {
     return (size_t)std::max<int64_t>(total, 0);
 }
 
-bool key_matches(const PlanKey& k, const tls_options& opt, const double* t, int64_t n, const double* periods, int64_t n_periods,
+bool key_matches(const PlanKey& k, const Switches& opt, const double* t, int64_t n, const double* periods, int64_t n_periods,
                  const tls_template* tmpl, const tls_params* params) {
     if (!k.valid || k.n != n || k.n_periods != n_periods || k.n_rows != tmpl->n_rows) return false;
     if (std::memcmp(&k.params, params, sizeof(tls_params)) != 0) return false;
@@ -287,10 +333,10 @@ bool key_matches(const PlanKey& k, const tls_options& opt, const double* t, int6
         return false;
     if (k.values.size() != template_values(tmpl) || std::memcmp(k.values.data(), tmpl->values, k.values.size() * 8)) return false;
     if (std::memcmp(k.t.data(), t, (size_t)n * 8) || std::memcmp(k.periods.data(), periods, (size_t)n_periods * 8)) return false;
-    return std::memcmp(&k.opt, &opt, sizeof(tls_options)) == 0;
+    return std::memcmp(&k.opt, &opt, sizeof(Switches)) == 0;
 }
 
-void key_store(PlanKey& k, const tls_options& opt, const double* t, int64_t n, const double* periods, int64_t n_periods,
+void key_store(PlanKey& k, const Switches& opt, const double* t, int64_t n, const double* periods, int64_t n_periods,
                const tls_template* tmpl, const tls_params* params) {
     k.n = n; k.n_periods = n_periods; k.n_rows = tmpl->n_rows; k.params = *params;
     k.t.assign(t, t + n); k.periods.assign(periods, periods + n_periods);
@@ -496,7 +542,7 @@ void build_screens(const std::vector<tlsdev::WidthEntry>& widths, const std::vec
         // q~' within 1 ulp of levd -- absorbed by inflating the remainder; |dsum| * mean enters the same way)
         sc.sq = (double)sq;
         sc.r2 = (double)(r2 * (1.0L + 1e-9L)) + 1e-24 + 1e-12 * (double)fabsl(dsum);
-        sc.valid = one_segment_only ? 0 : 1;   // developer switch (tls_options::no_screen): the one-segment bound (cell_bound) for every row
+        sc.valid = one_segment_only ? 0 : 1;   // developer switch (switch no_screen): the one-segment bound (cell_bound) for every row
     }
 }
 
@@ -520,17 +566,18 @@ bool screen_admissible(bool resident, bool uniform, double e_abs_max) {
 // (0.32) 2.94 / 2.54 / 2.47; 300 ppm (0.38) 3.22 / 2.76 / 2.58; 500 ppm (0.42) 3.61 / 2.93 / 2.75.  The
 // screen halves the FMA instructions of the dot products but adds a split pass and a valuation pass per period (DESIGN
 // section 4): it pays where the dot products dominate and the pruning passes do not pay yet.
-// tls_options::prune = 0/1 and ::screen32 = 0/1 force either choice (tests run all three variants).
+// switch prune = 0/1 and ::screen32 = 0/1 force either choice (tests run all three variants).
 constexpr double kScreenFromFraction = 0.13, kPruneFromFraction = 0.24, kPruneFromFractionBesideScreen = 0.30;
-bool pruning_pays(const tls_options& opt, const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool resident,
+bool pruning_pays(const Switches& opt, const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool resident,
                   bool screen_ok = false) {
+    if (!resident) return false;   // (the bound's look-ups in X want the series in LDS: no slab instantiation)
     if (opt.prune >= 0) return opt.prune != 0;
-    if (!resident || !(sigma > 0) || widths.empty()) return false;
+    if (!(sigma > 0) || widths.empty()) return false;
     for (const auto& we : widths) if (!we.prunable) return false;
     if (opt.screen32 >= 0) screen_ok = screen_ok && opt.screen32 != 0;
     return passing_fraction(widths, sigma, depth_min) >= (screen_ok ? kPruneFromFractionBesideScreen : kPruneFromFraction);
 }
-bool screen_pays(const tls_options& opt, const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool admissible) {
+bool screen_pays(const Switches& opt, const std::vector<tlsdev::WidthEntry>& widths, double sigma, double depth_min, bool admissible) {
     if (!admissible) return false;
     if (opt.screen32 >= 0) return opt.screen32 != 0;
     return passing_fraction(widths, sigma, depth_min) >= kScreenFromFraction;
@@ -688,9 +735,9 @@ void order_by_cost(const std::vector<int64_t>& cost, std::vector<int>& order) {
 }
 
 // the two-role kernel of the slab path (fold role, then search role over (period, tile) items)
-template <bool UNI, bool STAGE_C, bool PRUNING = false, bool COUNTING = false>
+template <bool UNI, bool COUNTING = false>
 hipError_t launch_split(tls_ctx* ctx, const tlsdev::SearchArgs& args, int blocks) {
-    auto kernel = tlsdev::tls_fold_search_kernel<UNI, STAGE_C, PRUNING, COUNTING>;
+    auto kernel = tlsdev::tls_fold_search_kernel<UNI, COUNTING>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
@@ -699,9 +746,9 @@ hipError_t launch_split(tls_ctx* ctx, const tlsdev::SearchArgs& args, int blocks
     return hipGetLastError();
 }
 
-template <bool RES, bool UNI, bool STAGE_C, typename IdxT, bool PRUNING = false, bool COUNTING = false, bool SCREEN = false>
+template <bool RES, bool UNI, typename IdxT, bool PRUNING = false, bool COUNTING = false, bool SCREEN = false>
 hipError_t launch_variant(tls_ctx* ctx, const tlsdev::SearchArgs& args, int blocks) {
-    auto kernel = tlsdev::tls_search_kernel<RES, UNI, STAGE_C, IdxT, PRUNING, COUNTING, SCREEN>;
+    auto kernel = tlsdev::tls_search_kernel<RES, UNI, IdxT, PRUNING, COUNTING, SCREEN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
@@ -774,7 +821,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         a.eps_fast = fast_mode_eps(ctx->M, ctx->y_abs_max);
         a.slack_unit = 2.5e-16 * c_max;
         a.exact_prefix = ctx->opt.exact_prefix == 1 ? 1 : 0;
-        // Series in the HBM slab, one-workgroup-per-period kernel: fast mode too (tls_options::fast_slab = 0: exact mode).
+        // Series in the HBM slab, one-workgroup-per-period kernel: fast mode too (switch fast_slab = 0: exact mode).
         // The band grows with the series (eps ~ 2^-52 (n + W) max|flux|) while the noise of a window mean shrinks: 2.6 % of
         // the TESS-size and 10 % of the Kepler-size periods hit it and go through the prefix sum and phase 3 a second time
         // (the folded flux is kept).  Round 4, same box: Kepler full grid 275.8 -> 254.8 ms, TESS 2.97 -> 2.90 ms.
@@ -785,7 +832,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         a.fast_slab = ctx->opt.fast_slab == 0 ? 0 : 1;
     }
     a.x_at_staging = 0;
-    if (!ctx->resident && a.fast_slab && !ctx->stage_c) {
+    if (!ctx->resident && a.fast_slab) {
         bool any_oversize = false;   // (rows evaluated straight from the slab list their cells with the first tile: they need all of X)
         for (const auto& we : ctx->host_widths) any_oversize = any_oversize || we.oversize != 0;
         a.x_at_staging = any_oversize ? 0 : 1;
@@ -823,7 +870,6 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     }
     if (!ctx->resident && a.fast_slab && ctx->flux_sigma > 0) a.band_prefix = ctx->d_band_now;
     a.sort2 = ctx->sort2 ? 1 : 0;
-    a.sort3 = ctx->sort3 ? 1 : 0; a.sort3_scratch = ctx->d_sort3.ptr;
     a.n_curves = ctx->batch_curves;
     a.curve_S0 = ctx->over_S0 ? ctx->over_S0 : ctx->d_curve_S0.ptr;
     a.curve_w0 = ctx->over_w0 ? ctx->over_w0 : ctx->d_curve_w0.ptr;
@@ -833,6 +879,8 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.batch_lo = 0; a.batch_n = 0; a.tile_prefix = ctx->d_tile_prefix.ptr;
     a.partials = ctx->d_partials.ptr; a.tiles_done = ctx->d_tiles_done.ptr;
     a.fold_ready = ctx->d_tiles_done.ptr ? ctx->d_tiles_done.ptr + ctx->split_batch : nullptr;   // (only the two-role plan has them)
+    a.split_fast = ctx->split_fast && a.x_at_staging && a.g != nullptr ? 1 : 0;
+    a.row_parts = ctx->row_parts; a.row_cost = ctx->d_row_cost.ptr;
     hipError_t e;
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
     if ((e = timing_pair(ctx, &evp)) != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("timing events: ") + hipGetErrorString(e));
@@ -840,28 +888,31 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         --ctx->ev_used;
         return fail(ctx, TLS_E_HIP, std::string("timing events: ") + hipGetErrorString(e));
     }
-    // pruning variant: uniform weights, noisy enough that most trial cells pass the depth predicate,
+    // pruning variant: LDS-resident series, uniform weights, noisy enough that most trial cells pass the depth predicate,
     // and not while the evaluated cells are being counted (counting means evaluating all of them)
-    const bool prune = ctx->uniform_w && ctx->prune_kernel && !count_work;
+    const bool prune = ctx->resident && ctx->uniform_w && ctx->prune_kernel && !count_work;
     // (counting has an instantiation of its own: the plain kernels do not keep the counters)
-#define TLS_LAUNCH(RES, STAGE, IDX, BLOCKS)                                                                         \
-    (!ctx->uniform_w ? (count_work ? launch_variant<RES, false, STAGE, IDX, false, true>(ctx, a, BLOCKS)                    \
-                                   : launch_variant<RES, false, STAGE, IDX, false, false>(ctx, a, BLOCKS))                   \
-     : prune         ? launch_variant<RES, true, STAGE, IDX, true, false>(ctx, a, BLOCKS)                                    \
-     : count_work    ? launch_variant<RES, true, STAGE, IDX, false, true>(ctx, a, BLOCKS)                                    \
-                     : launch_variant<RES, true, STAGE, IDX, false, false>(ctx, a, BLOCKS))
-#define TLS_LAUNCH_SPLIT(STAGE, BLOCKS)                                                                             \
-    (!ctx->uniform_w ? (count_work ? launch_split<false, STAGE, false, true>(ctx, a, BLOCKS)                                \
-                                   : launch_split<false, STAGE, false, false>(ctx, a, BLOCKS))                               \
-     : prune         ? launch_split<true, STAGE, true, false>(ctx, a, BLOCKS)                                                \
-     : count_work    ? launch_split<true, STAGE, false, true>(ctx, a, BLOCKS)                                                \
-                     : launch_split<true, STAGE, false, false>(ctx, a, BLOCKS))
+#define TLS_LAUNCH_RESIDENT(BLOCKS)                                                                                          \
+    (!ctx->uniform_w ? (count_work ? launch_variant<true, false, unsigned short, false, true>(ctx, a, BLOCKS)                   \
+                                   : launch_variant<true, false, unsigned short, false, false>(ctx, a, BLOCKS))                  \
+     : prune         ? launch_variant<true, true, unsigned short, true, false>(ctx, a, BLOCKS)                                   \
+     : count_work    ? launch_variant<true, true, unsigned short, false, true>(ctx, a, BLOCKS)                                   \
+                     : launch_variant<true, true, unsigned short, false, false>(ctx, a, BLOCKS))
+#define TLS_LAUNCH_SLAB(BLOCKS)                                                                                              \
+    (!ctx->uniform_w ? (count_work ? launch_variant<false, false, unsigned int, false, true>(ctx, a, BLOCKS)                    \
+                                   : launch_variant<false, false, unsigned int, false, false>(ctx, a, BLOCKS))                   \
+     : count_work    ? launch_variant<false, true, unsigned int, false, true>(ctx, a, BLOCKS)                                    \
+                     : launch_variant<false, true, unsigned int, false, false>(ctx, a, BLOCKS))
+#define TLS_LAUNCH_SPLIT(BLOCKS)                                                                                             \
+    (!ctx->uniform_w ? (count_work ? launch_split<false, true>(ctx, a, BLOCKS) : launch_split<false, false>(ctx, a, BLOCKS))    \
+     : count_work    ? launch_split<true, true>(ctx, a, BLOCKS)                                                              \
+                     : launch_split<true, false>(ctx, a, BLOCKS))
     const bool split = !ctx->resident && ctx->split && ctx->batch_curves == 1;
     // fp32 screen of the dot products (tlsdev::screen_cells): where the host expects it to pay (screen_pays); counting the
     // work and the debug entries run the plain variant, whose bits it returns anyway
     const bool screen = ctx->screen_kernel && screen_admissible(ctx->resident, ctx->uniform_w, ctx->e_abs_max) && !prune &&
                         !count_work && !debug_folded && !debug_prefix;
-    const char* kernel_name = ctx->resident ? (prune ? "resident+prune" : "resident") : split ? "slab+split" : (prune ? "slab+prune" : "slab");
+    const char* kernel_name = ctx->resident ? (prune ? "resident+prune" : "resident") : split ? "slab+split" : "slab";
     if (screen) {
         kernel_name = "resident+screen32";
         const size_t region = (size_t)ctx->M + 1 + (size_t)ctx->region_pad;
@@ -871,7 +922,7 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         er = ctx->d_park.reserve((size_t)ctx->blocks * tlsdev::kParkCap * 2);   // (a ParkedCell is two doubles wide)
         if (er != hipSuccess) { --ctx->ev_used; return fail(ctx, TLS_E_HIP, std::string("fp32 screen scratch: ") + hipGetErrorString(er)); }
         a.park_cells = ctx->d_park.ptr;
-        e = launch_variant<true, true, false, unsigned short, false, false, true>(ctx, a, ctx->blocks);
+        e = launch_variant<true, true, unsigned short, false, false, true>(ctx, a, ctx->blocks);
     } else if (ctx->slim_blocks > 0 && ctx->uniform_w && !ctx->prune_kernel &&
                !(ctx->screen_kernel && screen_admissible(ctx->resident, ctx->uniform_w, ctx->e_abs_max)) && !debug_folded && !debug_prefix) {
         // (by the plan's choice, not this launch's: a search that counts its work runs the counting instantiation of the kernel
@@ -885,11 +936,9 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
             hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->slim_blocks), dim3((unsigned)tlsdev::kSlimThreads), ctx->slim_lds, ctx->stream, a);
             e = hipGetLastError();
         }
-    } else if (ctx->resident) e = TLS_LAUNCH(true, false, unsigned short, ctx->blocks);
-    else if (!split) {
-        if (ctx->stage_c) e = TLS_LAUNCH(false, true, unsigned int, ctx->blocks);
-        else e = TLS_LAUNCH(false, false, unsigned int, ctx->blocks);
-    } else {
+    } else if (ctx->resident) e = TLS_LAUNCH_RESIDENT(ctx->blocks);
+    else if (!split) e = TLS_LAUNCH_SLAB(ctx->blocks);
+    else {
         // series in the HBM slab, one light curve: per batch of periods ONE launch of the two-role kernel -- every
         // workgroup folds periods of the batch until none is left (one slab per period), then searches (period, tile) items
         e = hipSuccess;
@@ -898,12 +947,12 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
             a.queue = ctx->d_squeue.ptr;   // [0..1] the fold role's queue, [2..3] the search role's
             const int64_t items = (int64_t)ctx->host_tile_prefix[(size_t)(lo + a.batch_n)] - (int64_t)ctx->host_tile_prefix[(size_t)lo];
             const int blocks = (int)std::min<int64_t>(ctx->split_blocks, std::max<int64_t>(items, 1));
-            if (ctx->stage_c) e = TLS_LAUNCH_SPLIT(true, blocks);
-            else e = TLS_LAUNCH_SPLIT(false, blocks);
+            e = TLS_LAUNCH_SPLIT(blocks);
         }
     }
 #undef TLS_LAUNCH_SPLIT
-#undef TLS_LAUNCH
+#undef TLS_LAUNCH_SLAB
+#undef TLS_LAUNCH_RESIDENT
     // (a failure from here on gives the event pair back: tls_kernel_timing must not meet a pair whose second event was
     // never recorded)
     if (e != hipSuccess) { --ctx->ev_used; return fail(ctx, TLS_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
@@ -1020,18 +1069,49 @@ tls_ctx* tls_ctx_create(int device_id) {
 
 int tls_get_options(const tls_ctx* ctx, tls_options* out) {
     if (!ctx || !out) return TLS_E_ARG;
-    *out = ctx->opt;
+    out->exact_prefix = ctx->opt.exact_prefix; out->slim = ctx->opt.slim;
     return TLS_OK;
 }
 
-int tls_set_options(tls_ctx* ctx, const tls_options* opt) {
-    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
-    if (!opt) return fail(ctx, TLS_E_ARG, "null options");
-    tls_options o = *opt;
+namespace {
+int adopt_switches(tls_ctx* ctx, const Switches& o) {
     if (std::memcmp(&o, &ctx->opt, sizeof o) == 0) return TLS_OK;
     ctx->opt = o;
     // a prepared plan was built for the old switches: the next tls_prepare plans again (the key holds them too)
     ctx->prepared = false; ctx->executed = false;
+    return TLS_OK;
+}
+}  // namespace
+
+int tls_set_options(tls_ctx* ctx, const tls_options* opt) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!opt) return fail(ctx, TLS_E_ARG, "null options");
+    Switches o = ctx->opt;
+    o.exact_prefix = opt->exact_prefix < 0 ? -1 : opt->exact_prefix;
+    o.slim = opt->slim < 0 ? -1 : opt->slim;
+    return adopt_switches(ctx, o);
+}
+
+int tls_debug_set_switch(tls_ctx* ctx, const char* name, double value) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    const SwitchName* sw = find_switch(name);
+    if (!sw) return fail(ctx, TLS_E_ARG, std::string("unknown switch: ") + (name ? name : "(null)"));
+    Switches o = ctx->opt;
+    switch_store(o, *sw, value);
+    return adopt_switches(ctx, o);
+}
+
+int tls_debug_get_switches(const tls_ctx* ctx, char* out, int64_t capacity) {
+    if (!out || capacity < 1) return TLS_E_ARG;
+    const Switches& o = ctx ? ctx->opt : process_options();
+    std::string text;
+    for (const auto& sw : kSwitchNames) {
+        char item[96];
+        std::snprintf(item, sizeof item, "%s%s=%.17g", text.empty() ? "" : ",", sw.name, switch_load(o, sw));
+        text += item;
+    }
+    if ((int64_t)text.size() + 1 > capacity) return TLS_E_ARG;
+    std::memcpy(out, text.c_str(), text.size() + 1);
     return TLS_OK;
 }
 
@@ -1046,7 +1126,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     if (ctx->ev_stage) (void)hipEventDestroy(ctx->ev_stage);
     ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release();
-    ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_sort3.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_pqueues.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
+    ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_pqueues.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
     ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
     ctx->d_split.release(); ctx->d_park.release(); ctx->d_band.release();
     if (ctx->h_band) (void)hipHostFree(ctx->h_band);
@@ -1182,7 +1262,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
     ctx->slim_blocks = 0; ctx->slim_lds = 0;
     if (ctx->resident) {
         ctx->nb = (int)n;
-        ctx->tile_len = 0; ctx->tile_halo = 0; ctx->sort2 = false; ctx->sort3 = false;
+        ctx->tile_len = 0; ctx->tile_halo = 0; ctx->sort2 = false;
         ctx->lds_bytes = resident_bytes;
         const size_t per_cu = kLdsPerCU / resident_bytes;
         ctx->threads = per_cu >= 2 ? 512 : 1024;
@@ -1191,8 +1271,8 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)wg_per_cu * ctx->n_cu);
         if (ctx->opt.blocks > 0) ctx->blocks = std::max(1, std::min(ctx->blocks, ctx->opt.blocks));   // developer switch
         // Four (at least three) 256-thread workgroups per CU, phase 3 on X alone (tls_slim_kernel.hip.h): uniform weights, and
-        // the period's one region + header within a quarter (a third) of the LDS.  (tls_options::slim = 0: never.)
-        // (auto: only while the library also decides between the classic kernel's variants -- an explicit tls_options::prune
+        // the period's one region + header within a quarter (a third) of the LDS.  (switch slim = 0: never.)
+        // (auto: only while the library also decides between the classic kernel's variants -- an explicit switch prune
         // or ::screen32 selects among THOSE; slim = 1 forces this kernel wherever neither pruning nor the screen is taken)
         // (exact prefix-sum mode throughout is the classic kernel's: this one values its cells on the plain scan, and keeps
         // the exact prefix sum for the windows the plain scan cannot decide)
@@ -1213,11 +1293,9 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // (as fine as the LDS allows: a NEARLY commensurate period spreads its piles over neighbouring buckets, and fine
         // buckets keep them below the size from which the counting rank is left; what LDS remains behind the counters
         // stages piled-up buckets for the workgroup sort, fold_and_sort)
-        // Workgroups per CU of the slab variant: one 1024-thread workgroup with all of the LDS, or (TLS_SLAB_WGS=2, measured
-        // below) two 512-thread ones with half each, so that one period's latency-bound phases overlap another's arithmetic.
-        int slab_wgs = 1;
-        if (ctx->opt.slab_wgs == 2) slab_wgs = 2;
-        const size_t lds_budget = kLdsPerCU / (size_t)slab_wgs;
+        // One 1024-thread workgroup per CU with all of its LDS (two 512-thread ones with half each were measured in rounds 3
+        // and 4 and lost: more tiles, more halo staged; the switch is gone).
+        const size_t lds_budget = kLdsPerCU;
         ctx->nb = (int)std::min<int64_t>(n, (int64_t)((lds_budget - hdr) / 4));
         size_t halo = (size_t)W + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
         const size_t unit = (size_t)tlsdev::kR * tlsdev::kWave;  // tile bounds: multiples of 320
@@ -1242,22 +1320,12 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
                 halo = widest_fit + (widest_fit & 1) + (size_t)(tlsdev::kR - 1) * (size_t)std::max(widest_stride, tlsdev::kMaxTiledStride) + 2 * tlsdev::kU + 4;
             }
         }
-        // staged per tile: e (or e*w), w for per-point weights, and the prefix sum C beside them only
-        // if that costs no extra tiles.  Otherwise C takes the samples' place for the predicate pass
-        // and the samples follow for the dot products: two stagings per tile, but fewer and larger
-        // tiles (TESS: 2 instead of 3, -8 %; Kepler-size: 7 instead of 82, most of a tile is halo)
-        const size_t buffers_c = (uniform ? 1 : 2) + 1, buffers_noc = buffers_c - 1;
-        auto tiles_for = [&](size_t buffers) -> size_t {
-            const size_t cap = (lds_budget - hdr) / 8 / buffers;
-            if (cap < halo + unit) return 0;  // does not fit
-            const size_t cap_tile = (cap - halo) / unit * unit;
-            return ((size_t)M + cap_tile - 1) / cap_tile;
-        };
-        const size_t tiles_c = tiles_for(buffers_c), tiles_noc = tiles_for(buffers_noc);
-        if (tiles_noc == 0) return fail(ctx, TLS_E_ARG, "widest transit window does not fit the LDS tile");
-        ctx->stage_c = tiles_c != 0 && tiles_c <= tiles_noc;
-        if (ctx->opt.stage_c >= 0) ctx->stage_c = tiles_c != 0 && ctx->opt.stage_c != 0;   // A/B switch
-        const size_t buffers = ctx->stage_c ? buffers_c : buffers_noc;
+        // staged per tile: e (or e*w), and w for per-point weights.  The prefix sum takes the samples' place for the
+        // predicate pass (or is formed in place from the staged flux: fast mode), the samples follow for the dot products --
+        // two stagings per tile, but fewer and larger tiles than with X staged beside the samples (TESS: 2 instead of 3,
+        // -8 %; Kepler-size: 7 instead of 82, most of a tile is halo; that variant was dropped in round 6).
+        const size_t buffers = uniform ? 1 : 2;
+        if ((lds_budget - hdr) / 8 / buffers < halo + unit) return fail(ctx, TLS_E_ARG, "widest transit window does not fit the LDS tile");
         const size_t cap_doubles = (lds_budget - hdr) / 8 / buffers;
         const size_t cap_tile = (cap_doubles - halo) / unit * unit;
         const size_t n_tiles = ((size_t)M + cap_tile - 1) / cap_tile;
@@ -1297,27 +1365,19 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
                 pr.pad = pr.k_hi > pr.k_lo ? tile_for_khi[(size_t)pr.k_hi] : 0;
             }
         }
-        ctx->cumsum_round = 2 * tlsdev::kCumsumChunk / slab_wgs;
+        ctx->cumsum_round = 2 * tlsdev::kCumsumChunk;
         const size_t cumsum_bytes = 8 * ((size_t)ctx->cumsum_round + 4);
         ctx->lds_bytes = hdr + std::max<size_t>(std::max<size_t>(4 * (size_t)ctx->nb, cumsum_bytes),
                                                 buffers * 8 * (tile + halo));
-        ctx->threads = slab_wgs == 2 ? 512 : 1024;
+        ctx->threads = 1024;
         if (ctx->opt.threads > 0) ctx->threads = std::max(64, std::min(1024, ctx->opt.threads / 64 * 64));   // developer switch
-        ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)ctx->n_cu * slab_wgs);
+        ctx->blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)ctx->n_cu);
         if (ctx->opt.blocks > 0)   // developer switch: workgroups in flight (memory-system experiments)
             ctx->blocks = std::max(1, std::min(ctx->blocks, ctx->opt.blocks));
         // two-level sort with sequential HBM accesses (fold_and_sort_tiled) when its LDS windows fit
         const size_t sort2_bytes = hdr + (size_t)tlsdev::sort2_lds_bytes((int)n, ctx->threads);
         ctx->sort2 = sort2_bytes <= lds_budget && ctx->opt.sort2 != 0;
         if (ctx->sort2) ctx->lds_bytes = std::max(ctx->lds_bytes, sort2_bytes);
-        // one light curve per launch: partition into large phase bins, per-bin LDS sort fused with the prefix sum
-        const size_t sort3_bytes = hdr + (size_t)tlsdev::sort3_lds_bytes();
-        // (measured on the Kepler-size series: 8 % fewer HBM bytes than the two-level sort -- 5.2 vs 5.7 MB per
-        // period -- but 32 % more kernel time, its 23 bin rounds of eleven barriers each cost more than the
-        // gather they avoid; on the TESS-size series 15 % slower.  The two-level sort stays the default,
-        // TLS_SORT3=1 selects this path; both are tested.)
-        ctx->sort3 = sort3_bytes <= lds_budget && tlsdev::sort3_bins((int)n) <= tlsdev::kSort3MaxBins && (int64_t)W <= n &&
-                     ctx->opt.sort3 == 1;
         // Two-role slab kernel: every workgroup folds periods into per-period slabs, then searches
         // (period, tile) items; the periods go through it in batches that hold one slab per period in HBM (as many periods as
         // fit `kSplitSlabBytes`, at least four rounds of workgroups; all of them when the grid is small).
@@ -1327,18 +1387,32 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         // CU in a different phase and needs no hand-off (TESS 2.99 vs 3.50 ms, Kepler sample 5.37 vs 5.43 ms; 713 periods of
         // N = 70 128, 2.8 rounds: 1.37 vs 1.63 ms; 308 periods of the TESS-size series: 0.53 ms both ways).  Hence: up to one
         // and a half rounds of periods -> two-role kernel.  TLS_SPLIT=0/1 forces the choice (A/B, tests).
-        ctx->split_blocks = ctx->n_cu * slab_wgs;
+        ctx->split_blocks = ctx->n_cu;
         if (ctx->opt.blocks > 0) ctx->split_blocks = std::max(1, std::min(ctx->split_blocks, ctx->opt.blocks));
         {
-            // The two-role kernel has no fast prefix-sum mode (its fold role cannot know what its search role will find), and
-            // the mode of a period must not depend on the launch shape (enqueue): the plan takes it by itself only where every
-            // period runs exact mode anyway; tls_options::split = 0 / 1 forces the choice (A/B, tests).
-            const bool all_exact = ctx->opt.exact_prefix == 1 || ctx->opt.fast_slab == 0 || ctx->opt.sort3 == 1;
-            ctx->split = n_periods > 0 && (ctx->opt.split >= 0 ? ctx->opt.split != 0
-                                                               : all_exact && 2 * n_periods <= 3 * (int64_t)ctx->split_blocks);
-            // (Cutting the positions finer than the LDS requires -- more items per workgroup when the periods are few -- was
-            // measured and is not done: every tile stages its halo, waits for its slab and walks every row; 307 periods of the
-            // TESS-size series 0.53 ms with two tiles per period, 0.62 / 0.75 / 1.00 ms with 4 / 8 / 16 items per workgroup.)
+            // WHICH launches take it.  The mode of a period never depends on the launch shape (enqueue), so the two roles must
+            // be able to run a period in the mode the one-workgroup kernel gives it: fast mode with X formed at tile-staging
+            // time and the dot products on X (`split_fast`: uniform weights, no row wider than an LDS tile, an even number of
+            // points), or a plan that is exact throughout.  Where that holds, a SHORT launch whose last round of periods would
+            // be partly filled -- the share of a rank of a multi-GPU search, a few hundred periods of a long series -- goes
+            // through the two roles: 3.6 items per workgroup instead of 1.2 periods, and the launch ends within a tile's work
+            // instead of a whole period's.  Measured (round 6, TESS-size series, same box, one-workgroup kernel / two roles):
+            // 307 periods 0.583 / 0.479 ms, 411 periods 0.522 / 0.489; but 256 periods (one full round) 0.567 / 0.623 and 512
+            // 0.484 / 0.509 -- a launch of whole rounds has no partly filled round to repair and pays the hand-off (slabs read
+            // across XCDs, the ready flags) for nothing; a full grid stays with the one-workgroup kernel (every CU in a
+            // different phase).  Hence: up to four rounds, and the last one filled to between 1 and 70 %.
+            // switch split = 0 / 1 forces the choice (A/B, tests).
+            bool any_oversize = false;
+            for (const auto& we : widths) any_oversize = any_oversize || we.oversize != 0;
+            const bool all_exact = ctx->opt.exact_prefix == 1 || ctx->opt.fast_slab == 0;
+            ctx->split_fast = uniform && !any_oversize && (n & 1) == 0 && !all_exact && ctx->opt.x_staged != 0;
+            const int64_t last_round = n_periods % (int64_t)ctx->split_blocks;
+            const bool short_launch = n_periods <= 4 * (int64_t)ctx->split_blocks && last_round > 0 && 10 * last_round <= 7 * (int64_t)ctx->split_blocks;
+            ctx->split = n_periods > 0 && (ctx->opt.split >= 0 ? ctx->opt.split != 0 : (all_exact || ctx->split_fast) && short_launch);
+            // Row parts (switch parts = N): a (period, tile) item cut further into N shares of the period's duration rows.
+            // Measured and NOT taken by default: every share stages the tile, forms its X and walks the lists again, its
+            // waves share fewer batches (TESS-size, 307 periods: 0.479 ms with one share, 0.578 with two, 0.646 with three).
+            ctx->row_parts = 1;
             const size_t slab_bytes = regions * ((region_doubles + 1) & ~(size_t)1) * 8;
             constexpr size_t kSplitSlabBytes = (size_t)12 << 30;
             int64_t batch = std::max<int64_t>((int64_t)(kSplitSlabBytes / slab_bytes), (int64_t)4 * ctx->split_blocks);
@@ -1347,10 +1421,11 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             ctx->host_tile_prefix.assign((size_t)n_periods + 1, 0u);
             ctx->split_max_items = 0;
             if (ctx->split) {
+                if (ctx->opt.parts >= 1) ctx->row_parts = std::min(8, (int)ctx->opt.parts);
                 for (int64_t wk = 0; wk < n_periods; ++wk) {
                     const tlsdev::PeriodRows& pr = prow[(size_t)order[(size_t)wk]];
                     const size_t tl = pr.pad > 0 ? (size_t)pr.pad : tile;      // the kernel's tile length of this period
-                    ctx->host_tile_prefix[(size_t)wk + 1] = ctx->host_tile_prefix[(size_t)wk] + (unsigned int)(((size_t)M + tl - 1) / tl);
+                    ctx->host_tile_prefix[(size_t)wk + 1] = ctx->host_tile_prefix[(size_t)wk] + (unsigned int)(((size_t)M + tl - 1) / tl) * (unsigned int)ctx->row_parts;
                 }
                 for (int64_t lo = 0; lo < n_periods; lo += ctx->split_batch) {
                     const int64_t hi = std::min<int64_t>(n_periods, lo + ctx->split_batch);
@@ -1365,11 +1440,6 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             }
         }
         const size_t scratch_blocks = std::max<size_t>((size_t)ctx->blocks, ctx->split ? (size_t)ctx->split_batch : 0);
-        const size_t wg_blocks = std::max<size_t>((size_t)ctx->blocks, ctx->split ? (size_t)ctx->split_blocks : 0);
-        if (ctx->sort3) {
-            ctx->lds_bytes = std::max(ctx->lds_bytes, sort3_bytes);
-            TLS_HIP(ctx, ctx->d_sort3.reserve(wg_blocks * (size_t)tlsdev::sort3_scratch_doubles((int)n)));
-        }
         TLS_HIP(ctx, ctx->d_scratch.reserve(scratch_blocks * regions * (region_doubles + 1) + 16));
     }
     // per-width work units of phase 3 (M is fixed for the plan, so these are period independent)
@@ -1423,6 +1493,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         L.g = place(with_g ? nq * 8 : 0);
         const bool with_tiles = !ctx->resident && ctx->split;
         L.tile_prefix = place(with_tiles ? (np + 1) * sizeof(unsigned int) : 0);
+        L.row_cost = place(with_tiles ? (nw + 1) * sizeof(double) : 0);
         L.total = off;
         int rcs = stage_reserve(ctx, L.total);
         if (rcs) return rcs;
@@ -1462,7 +1533,21 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
                 gr[we.q_len] = qr[we.q_len - 1];
             }
         }
-        if (with_tiles) std::memcpy(h + L.tile_prefix, ctx->host_tile_prefix.data(), (np + 1) * sizeof(unsigned int));
+        if (with_tiles) {
+            std::memcpy(h + L.tile_prefix, ctx->host_tile_prefix.data(), (np + 1) * sizeof(unsigned int));
+            // expected work of every duration row (prefix over the width table): its trial positions through the depth
+            // predicate + the template taps of the fraction of its windows that white noise of the flux's scatter sends past
+            // transit_depth_min (as tls_period_costs): only the balance of a period's row parts depends on it
+            double* rc = reinterpret_cast<double*>(h + L.row_cost);
+            rc[0] = 0.0;
+            for (size_t k = 0; k < nw; ++k) {
+                const auto& we = widths[k];
+                double frac = 1.0;
+                if (flux_sigma > 0) frac = 0.5 * std::erfc(params->transit_depth_min * std::sqrt((double)we.width) / flux_sigma / std::sqrt(2.0));
+                rc[k + 1] = rc[k] + (double)we.n_pos * (0.3 + 0.06 * (double)we.q_len * frac);
+            }
+        }
+        ctx->d_row_cost.ptr = reinterpret_cast<double*>(ctx->d_plan.ptr + L.row_cost);
         unsigned char* d = ctx->d_plan.ptr;
         ctx->d_tile_prefix.ptr = reinterpret_cast<unsigned int*>(d + L.tile_prefix);
         ctx->d_t.ptr = reinterpret_cast<double*>(d + L.t); ctx->d_y.ptr = reinterpret_cast<double*>(d + L.y);
@@ -1734,7 +1819,6 @@ int tls_debug_poison_lds(tls_ctx* ctx, uint32_t word) {
     TLS_HIP(ctx, smear(ctx->d_perm.ptr, ctx->d_perm.cap * sizeof(unsigned int)));
     TLS_HIP(ctx, smear(ctx->d_split.ptr, ctx->d_split.cap * sizeof(float)));
     TLS_HIP(ctx, smear(ctx->d_park.ptr, ctx->d_park.cap * sizeof(double)));
-    TLS_HIP(ctx, smear(ctx->d_sort3.ptr, ctx->d_sort3.cap * sizeof(unsigned long long)));
     TLS_HIP(ctx, smear(ctx->d_fscratch.ptr, ctx->d_fscratch.cap * sizeof(double)));
     return TLS_OK;
 }
@@ -2252,8 +2336,12 @@ int tls_grid_cells(const double* t, int64_t n, const double* periods, int64_t n_
 
 int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t n_periods, const tls_template* tmpl,
                      const tls_params* params, double sigma, int64_t* cells_per_period, double* taps_per_period,
-                     double* time_per_period, int64_t* workgroups_in_flight, const tls_options* options) {
-    const tls_options po = options ? *options : process_options();
+                     double* time_per_period, int64_t* workgroups_in_flight, const char* switches) {
+    Switches po = process_options();
+    if (!switches_parse(po, switches)) {
+        g_create_error = "tls_period_costs: malformed switches (expected name=value,... of tls_debug_get_switches)";
+        return TLS_E_ARG;
+    }
     if (!t || !periods || !cells_per_period || !taps_per_period || n < 3 || n_periods < 0) {
         g_create_error = "tls_period_costs: invalid argument";
         return TLS_E_ARG;

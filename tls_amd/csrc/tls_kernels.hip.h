@@ -46,9 +46,8 @@
 // larger strides a runtime-stride form with one scalar tap stream per window; rows left with a
 // handful of live chunks are re-listed and evaluated one window per lane.
 //
-// Variants (template parameters): RESIDENT / tiled series, UNIFORM_W / per-point weights, STAGE_C
-// (tiled: prefix sum staged beside the samples, or in their place for the predicate pass), WITH_PRUNING (noisy light curves: an
-// exact branch-and-bound step drops the cells that cannot win before phase 3b, see cell_bound).
+// Variants (template parameters): RESIDENT / tiled series, UNIFORM_W / per-point weights, WITH_PRUNING (LDS-resident series,
+// noisy light curves: an exact branch-and-bound step drops the cells that cannot win before phase 3b, see cell_bound).
 // Survey batches (SearchArgs::n_curves > 1): the fold + sort of a period is shared by all light
 // curves of the launch; phases 2-4 run per curve.
 //
@@ -504,8 +503,6 @@ struct SearchArgs {
     long long list_stride;      // entries per workgroup
     // survey mode: n_curves light curves on the same time stamps share the fold + sort of a period
     int sort2;                  // tiled variant: use fold_and_sort_tiled (its LDS fits)
-    int sort3;                  // tiled variant, one light curve: fold_sort_cumsum_tiled
-    unsigned long long* sort3_scratch;   // [blocks][sort3_scratch_doubles(n)] pass-1 output of that path
     double* debug_folded;                // test entry (tls_debug_folded): [n_periods][n] folded flux of every period, or nullptr
     double* debug_prefix;                // test entry (tls_debug_prefix): [n_periods][M + 1] prefix sum C of every period, or nullptr
     unsigned long long* period_cycles;   // developer entry (tls_debug_period_cycles): [n_periods] shader cycles per period, or nullptr
@@ -540,14 +537,17 @@ struct SearchArgs {
     int region_pad;         // spare entries behind every folded-series region (region_pad_for)
     // two-kernel slab path (kRoleFold / kRoleSearch): the periods order[batch_lo .. batch_lo + batch_n) of one batch; the
     // folded series of work item w lives in slab w - batch_lo.  The search kernel's items are (period, position tile)
-    // pairs: tile_prefix[w] = tiles of all work items in front of w (in queue order), item g of the batch is tile
-    // tile_prefix[batch_lo] + g.  A tile's winner goes to partials[g]; the workgroup that finishes a period's last tile
+    // pairs (x row parts, SearchArgs::row_parts): tile_prefix[w] = items of all periods in front of w (in queue order), item g
+    // of the batch is tile_prefix[batch_lo] + g.  A tile's winner goes to partials[g]; the workgroup that finishes a period's last tile
     // (tiles_done[slot]) compares them and writes the period's result.
     int batch_lo, batch_n;
     const unsigned int* tile_prefix;   // [n_periods + 1]
     double* partials;                  // [items of the largest batch][3]: stat | td | (k, i)
     unsigned int* tiles_done;          // [periods of the largest batch], zero between launches
     unsigned int* fold_ready;          // [periods of the largest batch] 1: the slab is complete; zero between launches
+    int split_fast;                    // two roles: != 0 the plan supports fast prefix-sum mode there (uniform weights, X at staging, taps g)
+    int row_parts;                     // search role: a period's tiles are walked by this many work items, a share of its duration rows each
+    const double* row_cost;            // [n_widths + 1] expected work of the rows < k (prefix over the width table): places the shares
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period, double epoch) {
@@ -2961,79 +2961,6 @@ __device__ __noinline__ bool fold_and_sort_tiled_call(global_ptr<const double> t
                                       from_global_arg(f_out), from_global_arg(w_out_g), from_global_arg(dbg_check));
 }
 
-// ---------------------------------------------------------------------------------------
-// Series in HBM, one light curve per launch: fold, stable sort and exact prefix sum in ONE sweep whose
-// HBM accesses are all sequential and issued in large batches (the first version of this path was
-// bound by exposed HBM latency: per-wave bins of ~160 points, 10 chunks of prefix sum, each with its
-// own round trip).
-//   pass 1  the points are partitioned into B = n/6144 coarse phase bins through an LDS staging
-//           buffer (8 K points per round): a 32-bit fixed-point phase key, the index AND the flux (and
-//           weight) of the point, every bin's points of a round leaving as one contiguous segment;
-//   pass 2  bin by bin (<= 8192 points, the whole workgroup): the points into registers (requested one
-//           bin ahead), an LDS bucket sort on the key (ties on the 32-bit key are decided by
-//           the exact fp64 phase, then the index: the order of numpy's stable sort, core.py:120),
-//           the sorted flux of the bin assembled in LDS, written out, and -- while it is there -- run
-//           through the exact prefix sum (exact_cumsum, carry from the previous bin), whose values are
-//           written out as well.  The folded flux is never read back for the prefix sum.
-//   patch   the prefix sum continues over the first W samples again (core.py:126-132).
-// The slab afterwards holds f[0..n) (and w) and C[0..M]; e = 1 - f is formed when a tile is staged.
-// Returns false (all threads alike) when a coarse bin overflows (phases piled up): the caller falls
-// back to the general path.
-constexpr int kSort3BinCap = 4096;      // points one coarse phase bin may hold
-constexpr int kSort3BinMean = 3072;     // target points per coarse bin
-constexpr int kSort3Fine = 2048;        // fine buckets of the per-bin LDS sort
-constexpr int kSort3Chunk = 16384;      // points partitioned per pass-1 round
-constexpr int kSort3MaxBins = 128;
-__host__ __device__ constexpr int sort3_bins(int n) {
-    return (n + kSort3BinMean - 1) / kSort3BinMean < 1 ? 1 : (n + kSort3BinMean - 1) / kSort3BinMean;
-}
-__host__ __device__ constexpr long long sort3_lds_bytes() {
-    // bin counters + the larger of the pass-1 staging (8 B per point) and the pass-2 arrays
-    // (flux / prefix-sum buffer, sorted entries, fine-bucket counters); the patch round reuses the front
-    const long long counters = 4LL * 4 * kSort3MaxBins;
-    const long long pass1 = 8LL * kSort3Chunk;
-    const long long pass2 = 16LL * kSort3BinCap /* landing zone of the next bin's records */ + 8LL * (kSort3BinCap + 2) +
-                            8LL * kSort3BinCap + 4LL * (kSort3Fine + 4);
-    const long long patch = 8LL * (kSort3Chunk + 1) + 8;
-    long long m = pass1 > pass2 ? pass1 : pass2;
-    m = m > patch ? m : patch;
-    return counters + m;
-}
-__host__ __device__ constexpr long long sort3_scratch_doubles(int n) {   // pass-1 output: entry, flux, weight per slot
-    return 3LL * sort3_bins(n) * kSort3BinCap;
-}
-
-// 32-bit fixed-point phase: monotone in the phase, uniform resolution 2^-32
-
-// exclusive prefix sum of cnt[0..nb) (LDS) in place, nb <= 8 * blockDim.x; two LDS barriers
-__device__ __forceinline__ void block_exclusive_scan8(unsigned int* cnt, int nb, unsigned int* wsum, int tid) {
-    const int nt = blockDim.x;
-    const int lane = tid & (kWave - 1), nw = nt / kWave;
-    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    const int chunk = (nb + nt - 1) / nt;   // <= 8
-    const int lo = tid * chunk;
-    unsigned int c[8], local = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { c[e] = (e < chunk && lo + e < nb) ? cnt[lo + e] : 0u; local += c[e]; }
-    unsigned int incl = local;
-    incl += (unsigned int)dpp_i32<kDppRowShr1, 0xF>((int)incl);
-    incl += (unsigned int)dpp_i32<kDppRowShr2, 0xF>((int)incl);
-    incl += (unsigned int)dpp_i32<kDppRowShr4, 0xF>((int)incl);
-    incl += (unsigned int)dpp_i32<kDppRowShr8, 0xF>((int)incl);
-    incl += (unsigned int)dpp_i32<kDppBcast15, 0xA>((int)incl);
-    incl += (unsigned int)dpp_i32<kDppBcast31, 0xC>((int)incl);
-    if (lane == kWave - 1) wsum[wave] = incl;
-    lds_barrier();
-    unsigned int run = incl - local;
-    for (int v = 0; v < wave; ++v) run += wsum[v];
-    (void)nw;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < chunk && lo + e < nb) { cnt[lo + e] = run; run += c[e]; }
-    lds_barrier();
-}
-
-typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));   // one partitioned point: {key << 32 | index, flux bits}
-
 // dst[0..count) (slab, HBM) = src[0..count) (LDS): 16-byte stores wherever the destination allows
 // the same for a piece of the prefix sum C on its way into the slab, stored as X[k] = k - C[k] (an exact subtraction:
 // see depth_pass); src[j] is C[k0 + j]
@@ -3066,295 +2993,39 @@ __device__ __forceinline__ void copy_out_stream(double* dst, const double* src, 
     if (tid == 0 && head + 2 * pairs < count) stream_store(dst + count - 1, src[count - 1]);
 }
 
-template <bool UNIFORM_W>
-__device__ __forceinline__ bool fold_sort_cumsum_tiled(const double* t, const double* y, const double* w, int n, int W,
-                                                    double period, double* f_out, double* c_out, double* w_out,
-                                                    unsigned long long* g_scratch, unsigned char* lds_generic,
-                                                    unsigned int* wsum_generic, Cumsum2Scratch* cs_generic,
-                                                    unsigned long long* dbg) {
-    unsigned char* lds = as_lds(lds_generic);
-    unsigned int* wsum = as_lds(wsum_generic);
-    Cumsum2Scratch* cs = as_lds(cs_generic);
-    PhaseClock pc; pc.start(dbg);   // its own clock: the caller restarts its clock behind the call
+// The exact prefix pass over a period's slab, out of line (registers of its own), for a work item of the two-role kernel's
+// search role whose fast attempt noted band windows (2-7 % of the periods): the fold role leaves no X for a fast period, so
+// the item forms X = k - numpy.cumsum itself -- f (regA) through LDS in rounds of `round` elements, the patch (core.py:126) an
+// index mapping of the copy-in, X to regB, the sentinels behind it.  Needs the full 1024-thread workgroup (one block a round).
+__device__ __noinline__ void slab_exact_prefix_call(global_ptr<const double> f_, global_ptr<double> x_, int n_, int M_, int region_pad_,
+                                                    int round_, unsigned int buf_addr_, unsigned int cs_addr_,
+                                                    global_ptr<unsigned long long> dbg) {
+    typedef __attribute__((address_space(3))) double* lds_d;
+    const double* regA = from_global_arg(f_);
+    double* regB = from_global_arg(x_);
+    const int n = uniform_i32(n_), M = uniform_i32(M_), region_pad = uniform_i32(region_pad_), kRound = uniform_i32(round_);
+    const unsigned int buf_addr = (unsigned int)__builtin_amdgcn_readfirstlane((int)buf_addr_);
+    const unsigned int cs_addr = (unsigned int)__builtin_amdgcn_readfirstlane((int)cs_addr_);
+    double* buf = (double*)(lds_d)(uintptr_t)buf_addr;   // C[0..len], f = buf + 1 (16-byte aligned)
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int B = sort3_bins(n);
-    unsigned int* l_cnt = reinterpret_cast<unsigned int*>(lds);      // [B] points of the bin in this round
-    unsigned int* l_start = l_cnt + kSort3MaxBins;                   // [B]
-    unsigned int* g_cnt = l_start + kSort3MaxBins;                   // [B] points of the bin so far
-    unsigned int* flags = g_cnt + kSort3MaxBins;                     // [0]: overflow
-    unsigned char* area = lds + 4 * 4 * kSort3MaxBins;
-    constexpr int kE = kSort3BinCap / 1024;   // points per thread in pass 2 (1024-thread workgroups)
-    if (kE * nt < kSort3BinCap) return false; // needs 1024 threads (uniform)
-    // pass-1 output, bin-major: a 16-byte record per point -- the sort key, the index and the FLUX travel
-    // together (a gather y[index] in pass 2 would be 70 000 random 64-byte requests per period and CU);
-    // weights, when there are any, in a parallel array
-    const long long slots = (long long)B * kSort3BinCap;
-    u64x2* g_rec = reinterpret_cast<u64x2*>(g_scratch);
-    double* g_w = reinterpret_cast<double*>(g_scratch + 2 * slots);
-
-    // Barriers inside the two passes are lds_barrier(): they order the LDS steps and leave the global
-    // loads and the slab stores in flight.
-    // ---- pass 1: partition into coarse phase bins -----------------------------------------------------
-    {
-        constexpr int kChunk = UNIFORM_W ? kSort3Chunk / 2 : kSort3Chunk / 4;   // 16 / 24 bytes per staged point
-        constexpr int kPer = kChunk / 1024;        // points per thread and round
-        u64x2* st_rec = reinterpret_cast<u64x2*>(area);                     // [chunk]
-        double* st_w = reinterpret_cast<double*>(st_rec + kChunk);
-        if (tid < kSort3MaxBins) { l_cnt[tid] = 0u; g_cnt[tid] = 0u; }
-        if (tid == 0) flags[0] = 0u;
-        double tv[kPer], yv[kPer], wv[kPer];
-#pragma unroll
-        for (int e = 0; e < kPer; ++e) {   // all in flight
-            const bool ok = tid + e * nt < n;
-            tv[e] = ok ? t[tid + e * nt] : 0.0;
-            yv[e] = ok ? y[tid + e * nt] : 0.0;
-            if constexpr (!UNIFORM_W) wv[e] = ok ? w[tid + e * nt] : 0.0;
-        }
-        lds_barrier();
-        for (int c0 = 0; c0 < n; c0 += kChunk) {
-            const int cn = n - c0 < kChunk ? n - c0 : kChunk;
-            unsigned int key[kPer], rank[kPer];
-#pragma unroll
-            for (int e = 0; e < kPer; ++e) {
-                key[e] = phase_key(fold_phase(tv[e], period, 0.0));
-                const int bin = (int)(((unsigned long long)key[e] * (unsigned long long)B) >> 32);
-                rank[e] = tid + e * nt < cn ? atomicAdd(&l_cnt[bin], 1u) : 0u;
-            }
-            lds_barrier();
-            if (tid < kWave) {   // exclusive scan over the bins (B <= 128: two per lane) and the capacity test
-                const unsigned int c0b = 2 * tid < B ? l_cnt[2 * tid] : 0u, c1b = 2 * tid + 1 < B ? l_cnt[2 * tid + 1] : 0u;
-                const unsigned int c = c0b + c1b;
-                unsigned int incl = c;
-                incl += (unsigned int)dpp_i32<kDppRowShr1, 0xF>((int)incl);
-                incl += (unsigned int)dpp_i32<kDppRowShr2, 0xF>((int)incl);
-                incl += (unsigned int)dpp_i32<kDppRowShr4, 0xF>((int)incl);
-                incl += (unsigned int)dpp_i32<kDppRowShr8, 0xF>((int)incl);
-                incl += (unsigned int)dpp_i32<kDppBcast15, 0xA>((int)incl);
-                incl += (unsigned int)dpp_i32<kDppBcast31, 0xC>((int)incl);
-                if (2 * tid < B) {
-                    l_start[2 * tid] = incl - c;
-                    if (g_cnt[2 * tid] + c0b > (unsigned int)kSort3BinCap) flags[0] = 1u;
-                }
-                if (2 * tid + 1 < B) {
-                    l_start[2 * tid + 1] = incl - c + c0b;
-                    if (g_cnt[2 * tid + 1] + c1b > (unsigned int)kSort3BinCap) flags[0] = 1u;
-                }
-            }
-            lds_barrier();
-            if (flags[0]) { __syncthreads(); return false; }
-            unsigned int base[kPer];
-#pragma unroll
-            for (int e = 0; e < kPer; ++e) {   // the reads of all points in flight together
-                const int bin = (int)(((unsigned long long)key[e] * (unsigned long long)B) >> 32);
-                base[e] = l_start[bin];
-            }
-#pragma unroll
-            for (int e = 0; e < kPer; ++e) {
-                if (tid + e * nt < cn) {
-                    u64x2 rec;
-                    rec.x = ((unsigned long long)key[e] << 32) | (unsigned int)(c0 + tid + e * nt);
-                    rec.y = (unsigned long long)__double_as_longlong(yv[e]);
-                    st_rec[base[e] + rank[e]] = rec;
-                    if constexpr (!UNIFORM_W) st_w[base[e] + rank[e]] = wv[e];
-                }
-            }
-            // the next round's points are requested now (nothing else of this wave is pending), consumed
-            // behind this round's copy-out
-            {
-                const int c1 = c0 + kChunk;
-#pragma unroll
-                for (int e = 0; e < kPer; ++e) {
-                    const bool ok = c1 + tid + e * nt < n;
-                    tv[e] = ok ? t[c1 + tid + e * nt] : 0.0;
-                    yv[e] = ok ? y[c1 + tid + e * nt] : 0.0;
-                    if constexpr (!UNIFORM_W) wv[e] = ok ? w[c1 + tid + e * nt] : 0.0;
-                }
-            }
-            lds_barrier();
-            // every bin's points of this round leave as one contiguous segment, one 16-byte store per point
-#pragma unroll
-            for (int e = 0; e < kPer; ++e) {
-                const int sidx = tid + e * nt;
-                if (sidx < cn) {
-                    const u64x2 rec = st_rec[sidx];
-                    const int bin = (int)(((rec.x >> 32) * (unsigned long long)B) >> 32);
-                    const long long dst = (long long)bin * kSort3BinCap + g_cnt[bin] + ((unsigned int)sidx - l_start[bin]);
-                    stream_store(&g_rec[dst], rec);
-                    if constexpr (!UNIFORM_W) stream_store(&g_w[dst], st_w[sidx]);
-                }
-            }
-            lds_barrier();
-            if (tid < B) { g_cnt[tid] += l_cnt[tid]; l_cnt[tid] = 0u; }
-            lds_barrier();
-        }
-    }
-    __syncthreads();   // the partitioned points are in memory: other threads read them below
-    pc.mark(2);
-
-    // ---- pass 2: bin by bin -- LDS sort on the key, prefix sum of the sorted flux ---------------------------
-    // Software pipeline over the bins: the records of bin b+1 stream into an LDS landing zone
-    // (global_load_lds: no registers, 1 KiB per wave-instruction) while bin b is sorted; every lane later
-    // reads exactly the slots its own wave's loads filled, so no barrier guards the zone.  The prefix sum
-    // of bin b leaves for the slab at the top of round b+1, when its stores no longer sit between a load
-    // and its use.
-    u64x2* landing = reinterpret_cast<u64x2*>(area);                                 // [cap]
-    double* buf = reinterpret_cast<double*>(landing + kSort3BinCap);                 // C[0..m], f = buf + 1
-    unsigned long long* ent_s = reinterpret_cast<unsigned long long*>(buf + kSort3BinCap + 2);   // [cap] bucket order
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(ent_s + kSort3BinCap);       // [fine + 1]
-    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    // (inline assembly, not __builtin_amdgcn_global_load_lds: the compiler cannot tell the landing zone from
-    // the other LDS arrays and would wait for the transfer -- vmcnt(0) -- before EVERY later LDS access, i.e.
-    // right after it is issued.  The zone is read only behind the explicit vmem_wait_all() of the next round.)
-    const unsigned int landing_addr = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) u64x2*)landing;
-    auto request_bin = [&](int bin, int tid) {
-        const int mb = (int)g_cnt[bin];
-        const u64x2* src = g_rec + (long long)bin * kSort3BinCap;
-#pragma unroll
-        for (int e = 0; e < kE; ++e) {
-            const int i = tid + e * nt;
-            const unsigned int dst = (unsigned int)__builtin_amdgcn_readfirstlane((int)(landing_addr + 16u * (unsigned int)(wave * kWave + e * nt)));
-            unsigned int m0_saved;
-            if (i < mb)   // M0 carries the LDS base of the transfer; it is put back (the compiler may own it)
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-#if TLS_NT_LOAD
-                             " nt"
-#endif
-                             "\n\ts_mov_b32 m0, %0"
-                             : "=&s"(m0_saved) : "v"(src + i), "s"(dst) : "memory");
-        }
-    };
     double carry = 0.0;
-    int off = 0, prev_off = 0, prev_m = -1;
-    request_bin(0, tid);
-    const int tid_outer = tid;
-    for (int b = 0; b < B; ++b) {
-        // Every address of this round is recomputed from an opaque copy of the thread index: hoisted out of
-        // the loop they would all be live across it, and at 128 registers per thread the compiler spills
-        // them -- each reload then waits (vmcnt) for the transfer that was issued just before it.
-        int tid = tid_outer;
-        asm volatile("" : "+v"(tid));
-        const int m = (int)g_cnt[b];
-        // smallest key of the bin and of the next one: (key * B) >> 32 == b  <=>  lo_key <= key < hi_key
-        const unsigned long long lo_key = (((unsigned long long)b << 32) + (unsigned long long)B - 1ull) / (unsigned long long)B;
-        const unsigned long long hi_key = ((((unsigned long long)b + 1ull) << 32) + (unsigned long long)B - 1ull) / (unsigned long long)B;
-        const double scale = (double)kSort3Fine / (double)(hi_key - lo_key) * (1.0 - 1e-9);
-        u64x2 rec[kE];
-        double wv[kE];
-        vmem_wait_all();                                   // this wave's records of bin b have landed
-        pc.mark(22);
-#pragma unroll
-        for (int e = 0; e < kE; ++e) {
-            u64x2 none; none.x = ~0ull; none.y = 0ull;
-            rec[e] = tid + e * nt < m ? landing[tid + e * nt] : none;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): the zone is read before it is refilled
-        if (b + 1 < B) request_bin(b + 1, tid);
-        pc.mark(23);
-        if constexpr (!UNIFORM_W) {
-            const long long base = (long long)b * kSort3BinCap;
-#pragma unroll
-            for (int e = 0; e < kE; ++e) wv[e] = tid + e * nt < m ? stream_load(g_w + base + tid + e * nt) : 0.0;
-        }
-        if (prev_m >= 0) copy_out_stream(c_out + prev_off, buf, prev_m + 1, tid);   // prefix sum of the previous bin
-        pc.mark(24);
-        for (int k = tid; k <= kSort3Fine; k += nt) cnt[k] = 0u;
-        lds_barrier();
-        pc.mark(0);
-        int fb[kE];
-        unsigned int r[kE];
-#pragma unroll
-        for (int e = 0; e < kE; ++e) {
-            const double rel = (double)((rec[e].x >> 32) - lo_key);
-            const int fbe = (int)(rel * scale);
-            fb[e] = fbe < kSort3Fine - 1 ? fbe : kSort3Fine - 1;
-            r[e] = tid + e * nt < m ? atomicAdd(&cnt[fb[e]], 1u) : 0u;
+    const bool dma = TLS_SLAB_DMA && (n & 1) == 0;   // pairs of samples never straddle the patch boundary
+    for (int c0 = 0; c0 < M; c0 += kRound) {
+        const int len = M - c0 < kRound ? M - c0 : kRound;
+        if (dma) { slab_to_lds_async(buf + 1, regA, c0, len, n, tid); vmem_wait_all(); }
+        else {
+            for (int k = tid; k < len; k += nt) { const int pp = c0 + k; buf[1 + k] = regA[pp < n ? pp : pp - n]; }
         }
         lds_barrier();
-        block_exclusive_scan8(cnt, kSort3Fine, wsum, tid);
-        if (tid == 0) cnt[kSort3Fine] = (unsigned int)m;   // the end of the last bucket
-        pc.mark(1);
-        int lo[kE];
-#pragma unroll
-        for (int e = 0; e < kE; ++e) lo[e] = (int)cnt[fb[e]];           // reads of all points in flight together
-#pragma unroll
-        for (int e = 0; e < kE; ++e) if (tid + e * nt < m) ent_s[lo[e] + (int)r[e]] = rec[e].x;
-        lds_barrier();
-        int len[kE], rank[kE], longest = 0;
-#pragma unroll
-        for (int e = 0; e < kE; ++e) {
-            len[e] = tid + e * nt < m ? (int)cnt[fb[e] + 1] - lo[e] : 0;
-            rank[e] = 0;
-            longest = len[e] > longest ? len[e] : longest;
+        for (int b0 = 0; b0 < len; b0 += 16 * nt) {   // (16 elements a thread and block: one block when the workgroup has 1024 threads)
+            const int blen = len - b0 < 16 * nt ? len - b0 : 16 * nt;
+            carry = exact_cumsum_round_call(buf_addr + 8u * (unsigned int)b0, blen, carry, cs_addr, dbg);
         }
-        // rank inside the fine bucket (1.5 points on average): the s-th member of every point's bucket is
-        // read in one batch, so the LDS latency is paid per step, not per point and step
-#pragma unroll
-        for (int delta = kWave / 2; delta > 0; delta >>= 1) {
-            const int o = __shfl_xor(longest, delta, kWave);
-            longest = o > longest ? o : longest;
-        }
-        for (int s2 = 0; s2 < longest; ++s2) {
-            unsigned long long o[kE];
-#pragma unroll
-            for (int e = 0; e < kE; ++e) o[e] = s2 < len[e] ? ent_s[lo[e] + s2] : ~0ull;
-#pragma unroll
-            for (int e = 0; e < kE; ++e) {
-                if (s2 < len[e]) {
-                    const unsigned int okey = (unsigned int)(o[e] >> 32), oid = (unsigned int)(o[e] & 0xffffffffull);
-                    const unsigned int key = (unsigned int)(rec[e].x >> 32), id = (unsigned int)(rec[e].x & 0xffffffffull);
-                    bool less = okey < key;
-                    if (okey == key && oid != id) {   // same 32-bit key (about once per period): the exact phases decide
-                        const double pa = fold_phase(t[oid], period, 0.0), pm = fold_phase(t[id], period, 0.0);
-                        less = pa < pm || (pa == pm && oid < id);
-                    }
-                    rank[e] += less ? 1 : 0;
-                }
-            }
-        }
-        pc.mark(4);
-#pragma unroll
-        for (int e = 0; e < kE; ++e)
-            if (tid + e * nt < m) buf[1 + lo[e] + rank[e]] = __longlong_as_double((long long)rec[e].y);
-        lds_barrier();
-        pc.mark(3);
-        // the sorted flux of the bin: out to the slab, then through the prefix sum where it lies
-        copy_out_stream(f_out + off, buf + 1, m, tid);
-        pc.mark(12);
-        // (inlined: a call would drain the vector-memory counter -- the flux stores just issued, the next
-        // bin's records in flight -- at its entry)
-        static_assert(kSort3BinCap <= 5 * 1024, "one block of 5 elements per thread covers a bin");
-        if (m > 0) carry = exact_cumsum_block_inline<5, true>(buf + 1, buf, 0, m, carry, cs, dbg);
-        else if (tid == 0) buf[0] = carry;
-        if constexpr (!UNIFORM_W) {
-            // (rare path, not pipelined: the prefix sum leaves now, the weights take its place)
-            copy_out_stream(c_out + off, buf, m + 1, tid);
-            lds_barrier();
-#pragma unroll
-            for (int e = 0; e < kE; ++e) if (tid + e * nt < m) buf[1 + lo[e] + rank[e]] = wv[e];
-            lds_barrier();
-            copy_out_stream(w_out + off, buf + 1, m, tid);
-            lds_barrier();
-            prev_m = -1;
-        } else {
-            prev_off = off; prev_m = m;
-        }
-        off += m;
-        pc.mark(5);
-    }
-    if (prev_m >= 0) copy_out_stream(c_out + prev_off, buf, prev_m + 1, tid);
-    __syncthreads();   // the folded flux is in memory: the patch below reads its head back
-    buf = reinterpret_cast<double*>(area);   // the patch round is longer than a bin: it takes the whole area
-    // ---- patch: the prefix sum runs on over the first W samples (core.py:126-132) -------------------------
-    for (int k0 = 0; k0 < W; k0 += kSort3Chunk) {
-        const int len = W - k0 < kSort3Chunk ? W - k0 : kSort3Chunk;
-        copy_in_flight4(buf + 1, f_out + k0, len);
-        lds_barrier();
-        carry = exact_cumsum<true>(buf + 1, buf, len, cs, dbg, carry);
-        copy_out_stream(c_out + n + k0, buf, len + 1, tid);
+        copy_out_stream_x(regB + c0, buf, len + 1, tid, c0);   // the slab keeps X[k] = k - C[k]
         lds_barrier();
     }
-    pc.mark(5);
-    return true;
+    for (int k = tid; k < region_pad; k += nt) regB[M + 1 + k] = -(double)(k + 1) * 1.0e300;
+    __syncthreads();
 }
 
 typedef const __attribute__((address_space(4))) SearchArgs* args_ptr;
@@ -3372,7 +3043,7 @@ enum { kRoleAll = 0, kRoleFold = 1, kRoleSearch = 2 };
 // One kernel, one workgroup per period from the fold to the argmin (LDS-resident series; survey batches on long series).
 // SCREEN: the fp32 screen of the dot products (screen_cells; LDS-resident series, uniform weights, plain variant; the
 // host admits it when every sample splits exactly into two fp32 halves).
-template <bool RESIDENT, bool UNIFORM_W, bool STAGE_C, typename IdxT, bool WITH_PRUNING = false, bool COUNTING = true, bool SCREEN = false>
+template <bool RESIDENT, bool UNIFORM_W, typename IdxT, bool WITH_PRUNING = false, bool COUNTING = true, bool SCREEN = false>
 __global__ void __launch_bounds__(TLS_LAUNCH_THREADS, TLS_WAVES_PER_EU)
 tls_search_kernel(const SearchArgs) {
     constexpr int ROLE = kRoleAll;
@@ -3387,18 +3058,18 @@ tls_search_kernel(const SearchArgs) {
 // empty, so the fold it may wait for is running on a workgroup that holds a CU and waits for nothing.
 // (The roles as called `__noinline__` functions were measured too: no different in time -- and a called function cannot
 // reach the kernel-argument segment through the builtin, which is null there.  PERF_LOG.md, round 4.)
-template <bool UNI_, bool STAGE_, bool PRUNE_ = false, bool COUNT_ = true>
+template <bool UNI_, bool COUNT_ = true>
 __global__ void __launch_bounds__(TLS_LAUNCH_THREADS, TLS_WAVES_PER_EU)
 tls_fold_search_kernel(const SearchArgs) {
     {
-        constexpr bool RESIDENT = false, UNIFORM_W = UNI_, STAGE_C = false, WITH_PRUNING = false, COUNTING = false, SCREEN = false;
+        constexpr bool RESIDENT = false, UNIFORM_W = UNI_, WITH_PRUNING = false, COUNTING = false, SCREEN = false;
         typedef unsigned int IdxT;
         constexpr int ROLE = kRoleFold;
 #include "tls_search_body.inc.h"
     }
     __syncthreads();
     {
-        constexpr bool RESIDENT = false, UNIFORM_W = UNI_, STAGE_C = STAGE_, WITH_PRUNING = PRUNE_, COUNTING = COUNT_, SCREEN = false;
+        constexpr bool RESIDENT = false, UNIFORM_W = UNI_, WITH_PRUNING = false, COUNTING = COUNT_, SCREEN = false;
         typedef unsigned int IdxT;
         constexpr int ROLE = kRoleSearch;
 #include "tls_search_body.inc.h"

@@ -1,5 +1,5 @@
 // tls_search_body.inc.h -- the body of the search kernels, included textually INSIDE the __global__ functions of
-// tls_kernels.hip.h (never on its own).  The including scope defines RESIDENT, UNIFORM_W, STAGE_C, IdxT, WITH_PRUNING,
+// tls_kernels.hip.h (never on its own).  The including scope defines RESIDENT, UNIFORM_W, IdxT, WITH_PRUNING,
 // COUNTING and ROLE (kRoleAll / kRoleFold / kRoleSearch).  Textual inclusion, not a function: as an always-inlined
 // device function the same code lost the kernel's work-group-size facts (thread-index ranges) at the point where clang
 // emits them, and the slab instantiation -- which sits at the 128-register cliff -- came out with five times the
@@ -26,7 +26,9 @@
     CumsumScratch* cumsum_scratch = reinterpret_cast<CumsumScratch*>(smem + 560);
     // the pruning variant is a separate instantiation: its extra state costs the plain variant 3-8 %
     // when both live in one kernel, and the host knows from the noise level which one pays
-    constexpr bool PRUNE = UNIFORM_W && WITH_PRUNING && (TLS_PRUNE != 0);
+    // (LDS-resident series only: on a series in the HBM slab the bound's look-ups in X are global loads -- forced, it never
+    // paid, and round 6 dropped the slab instantiations)
+    constexpr bool PRUNE = RESIDENT && UNIFORM_W && WITH_PRUNING && (TLS_PRUNE != 0);
     // the fp32 screen of the dot products (screen_cells): its own instantiation, chosen by the host
     constexpr bool SCR = SCREEN && RESIDENT && UNIFORM_W && !WITH_PRUNING && !COUNTING && ROLE == kRoleAll;
     // coarse prefix sum of e^2 for the pruning bound; the cumsum scratch is dead by the time it is built
@@ -62,7 +64,7 @@
 
     if (tid == 0) {
         [[maybe_unused]] const long long need = RESIDENT ? (long long)ap->hdr_bytes + (UNIFORM_W ? 2 : 3) * 8LL * RS
-                                        : (long long)ap->hdr_bytes + (UNIFORM_W ? (STAGE_C ? 2 : 1) : (STAGE_C ? 3 : 2)) * 8LL * (ap->tile_len + ap->tile_halo);
+                                        : (long long)ap->hdr_bytes + (UNIFORM_W ? 1 : 2) * 8LL * (ap->tile_len + ap->tile_halo);
         TLS_CHECK(*ap, need <= ap->lds_bytes, kChkLdsCarve);
         TLS_CHECK(*ap, (long long)kFixedHeader + 4LL * (3 * ap->n_widths + 2) <= ap->hdr_bytes, kChkLdsCarve);
     }
@@ -85,48 +87,44 @@
     // Series in the HBM slab, one light curve, plain variant: windows inside the undecided band are noted (band_window) and
     // decided after the attempt on the period's exact prefix sum -- the period loop is entered a second time for the prefix
     // pass only (`resolve_band`), the lanes' leads and counts of the attempt are kept
-    constexpr bool BAND = !RESIDENT && ROLE == kRoleAll && !WITH_PRUNING;
+    // (the search role of the two-role kernel likewise: its work item re-enters the loop, forms the period's exact prefix sum
+    // itself -- the fold role left none in fast mode -- and decides the windows ITS tile noted)
+    constexpr bool BAND = !RESIDENT && ROLE != kRoleFold && !WITH_PRUNING;
     [[maybe_unused]] bool resolve_band = false;
     [[maybe_unused]] Lead kept_lead = no_lead();
     [[maybe_unused]] unsigned int kept_eval = 0;
     [[maybe_unused]] unsigned long long kept_steps = 0, kept_issued = 0;
     [[maybe_unused]] BandEntry* const band_list = reinterpret_cast<BandEntry*>(chunk_list + ap->list_cap);   // (the pruning variant's second list: idle here)
-    int work = 0;
+    int work = 0, work_raw = 0;
     for (;;) {
         // ---- fetch the next period from the queue ----------------------------------
         if (!retry_exact) {
             if (tid == 0) { s_work[0] = (int)atomicAdd(ap->queue + (ROLE == kRoleSearch ? 2 : 0), 1u); s_work[1] = 0; s_work[2] = 0; s_work[4] = 0; }
             __syncthreads();
-            work = __builtin_amdgcn_readfirstlane(s_work[0]);
+            work_raw = __builtin_amdgcn_readfirstlane(s_work[0]);
             __syncthreads();
         } else if (tid == 0) {
             s_work[1] = 0; s_work[2] = 0;   // (published by the barriers of the sort, long before any thread may raise them again)
         }
+        work = work_raw;   // (the roles turn the ticket into a period below: a second attempt starts from the ticket again)
+        [[maybe_unused]] const bool again = retry_exact;   // this entry is a second attempt / a band resolution of the same work item
         int flag_slot = 1;   // the "undecided" flag of the attempt in flight: s_work[1] and s_work[2] take turns
         // exact mode: X = k - numpy.cumsum, bit for bit; fast mode: X = plain prefix sum of 1 - f (depth_pass)
         // (the two-kernel slab path has no second attempt: its fold kernel always leaves X = k - numpy.cumsum)
         // (the mode of a period depends on the series and the period alone, never on its place in the launch: sending the
         // launch's last round straight to exact mode would spare TESS-size grids a late second attempt -- measured 2.90
         // -> 2.81 ms -- but a period's bits would then depend on which other periods the call holds)
-        bool period_exact = (!RESIDENT && (ROLE != kRoleAll || ap->fast_slab == 0 || ap->sort3 != 0)) || retry_exact ||
-                            ap->exact_prefix != 0 || ap->debug_prefix != nullptr;
-        if constexpr (!RESIDENT && ROLE == kRoleAll) {
-            // a period whose windows are EXPECTED to hit the undecided band (long periods of a long series: many wide
-            // windows, little noise on their means) starts in exact mode: the fast attempt would mostly be wasted.  The
-            // expectation depends on the period's duration window and the light curve alone (host: band_prefix).
-            if (!period_exact && ap->band_prefix != nullptr && work < ap->n_periods) {   // (the queue's end is tested below)
-                const int pp = ap->order[work];
-                period_exact = ap->band_prefix[rows_c[pp].k_hi] - ap->band_prefix[rows_c[pp].k_lo] > ap->band_max;
-            }
-        }
+        // (decided below, once the roles of the two-role kernel have turned their ticket into a period)
         // (slab variant, one light curve: the folded flux of the fast attempt is still in the slab -- only X was written
         // behind it --, so the second attempt keeps it and starts at the prefix sum)
         [[maybe_unused]] const bool refold = !(retry_exact && !RESIDENT && ROLE == kRoleAll && ap->n_curves == 1 && ap->debug_folded == nullptr);
-        retry_exact = false;
         bool curve_exact = false;   // batches: this light curve again in exact mode (the permutation is kept: no new sort)
         // split roles: `work` counts the items of this launch -- the periods of the batch (fold), their tiles (search)
         int n_work = ap->n_periods;
-        [[maybe_unused]] int item = 0, item_tile = 0;
+        [[maybe_unused]] int item = 0, item_tile = 0, item_part = 0, item_first = 0;
+        // (search role: a period's items are its tiles x row parts; part j of a tile walks a contiguous share of the period's
+        // duration rows -- by expected work, SearchArgs::row_cost -- through phases 3a and 3b)
+        [[maybe_unused]] const int row_parts = ROLE == kRoleSearch ? (ap->row_parts > 1 ? ap->row_parts : 1) : 1;
         if constexpr (ROLE == kRoleFold) n_work = ap->batch_n;
         if constexpr (ROLE == kRoleSearch) n_work = (int)(ap->tile_prefix[ap->batch_lo + ap->batch_n] - ap->tile_prefix[ap->batch_lo]);
         if (work >= n_work) {
@@ -156,7 +154,9 @@
                 if (ap->tile_prefix[mid] <= G) lo_w = mid; else hi_w = mid;
             }
             work = __builtin_amdgcn_readfirstlane(lo_w);
-            item_tile = (int)(G - ap->tile_prefix[work]);
+            item_first = item - (int)(G - ap->tile_prefix[work]);          // the period's first item
+            item_tile = (int)(G - ap->tile_prefix[work]) / row_parts;
+            item_part = (int)(G - ap->tile_prefix[work]) % row_parts;
             regA = ap->scratch + (long long)(work - ap->batch_lo) * ap->scratch_stride;
             regB = regA + RS;
             if constexpr (!UNIFORM_W) regW = regB + RS;
@@ -173,6 +173,22 @@
         const int p = ap->order[work];
         TLS_CHECK(*ap, p >= 0 && p < ap->n_periods, kChkWorkItem);
         const double period = ap->periods[p];
+        // exact mode: X = k - numpy.cumsum, bit for bit; fast mode: X = plain prefix sum of 1 - f (depth_pass).
+        // The mode of a period depends on the series and the period alone, never on its place in the launch, the launch's
+        // shape or the kernel (one workgroup per period / two roles): sending a launch's last round straight to exact mode
+        // would spare TESS-size grids a late second attempt -- measured 2.90 -> 2.81 ms -- but a period's bits would then
+        // depend on which other periods the call holds.  (The two roles run fast mode where the plan supports it --
+        // SearchArgs::split_fast: uniform weights, X formed at tile-staging time, dot products on X --, exact mode otherwise.)
+        bool period_exact = (!RESIDENT && (ap->fast_slab == 0 || (ROLE != kRoleAll && ap->split_fast == 0))) || retry_exact ||
+                            ap->exact_prefix != 0 || ap->debug_prefix != nullptr;
+        if constexpr (!RESIDENT) {
+            // a period whose windows are EXPECTED to hit the undecided band (long periods of a long series: many wide
+            // windows, little noise on their means) starts in exact mode: the fast attempt would mostly be wasted.  The
+            // expectation depends on the period's duration window and the light curve alone (host: band_prefix).
+            if (!period_exact && ap->band_prefix != nullptr)
+                period_exact = ap->band_prefix[rows_c[p].k_hi] - ap->band_prefix[rows_c[p].k_lo] > ap->band_max;
+        }
+        retry_exact = false;
 #ifndef TLS_BODY_PRIO
 #define TLS_BODY_PRIO 1
 #endif
@@ -187,19 +203,12 @@
 
         // ---- phase 1: fold + stable sort by phase ----------------------------------
         bool sorted = false;
-        bool fused = false;   // fold, sort, gather AND prefix sum done by fold_sort_cumsum_tiled
         if constexpr (!RESIDENT && ROLE == kRoleAll) {
             if (!refold) sorted = true;
         }
         if constexpr (!RESIDENT && ROLE != kRoleSearch) {
-            if (!sorted && ap->sort3 && ap->n_curves == 1)
-                fused = fold_sort_cumsum_tiled<UNIFORM_W>(ap->t, ap->y, ap->w, n, W, period, regA, regB, regW,
-                                                          ap->sort3_scratch + (long long)blockIdx.x * sort3_scratch_doubles(n),
-                                                          smem + ap->hdr_bytes, wsum,
-                                                          reinterpret_cast<Cumsum2Scratch*>(cumsum_scratch), ap->phase_cycles);
-            if (ap->sort3 && ap->n_curves == 1) pc.start(ap->phase_cycles);   // the call kept its own clock
             // series in HBM: the two-level sort with sequential HBM accesses, unless a phase bin overflows
-            if (!sorted && !fused && ap->sort2) {
+            if (!sorted && ap->sort2) {
                 typedef global_ptr<const double> gcd;
                 typedef global_ptr<double> gd;
                 typedef global_ptr<unsigned int> gu;
@@ -214,7 +223,7 @@
                 pc.start(ap->phase_cycles);   // (the call kept its own clock)
             }
         }
-        if (ROLE != kRoleSearch && !sorted && !fused) {
+        if (ROLE != kRoleSearch && !sorted) {
             // (piled-up buckets are sorted by the workgroup: their list lives in the idle prefix-sum scratch; the slab
             // variant stages them in the LDS behind its bucket counters, the resident one sorts through the index)
             unsigned int* big_list = reinterpret_cast<unsigned int*>(cumsum_scratch);
@@ -257,16 +266,16 @@
         bool undecided = false;
         // series in the HBM slab, fast mode: X of a tile is formed from the tile's staged flux (scan_tile_x) instead of by a
         // prefix-sum pass over the whole series -- one pass of slab reads and the pass's barriers less per period
-        [[maybe_unused]] const bool x_staging = !RESIDENT && !STAGE_C && ROLE == kRoleAll && TLS_SLAB_DMA && !exact_mode &&
-                                                ap->x_at_staging != 0 && (n & 1) == 0;
-        [[maybe_unused]] double x_carry = 0.0;   // X at the first position of the next tile
+        // (every tile's scan starts at zero: only differences of X are ever read, and a tile's X is then the same function of
+        // the tile's samples in the one-workgroup kernel and in a (period, tile) item of the two-role kernel, whatever the flux)
+        [[maybe_unused]] const bool x_staging = !RESIDENT && TLS_SLAB_DMA && !exact_mode && ap->x_at_staging != 0 && (n & 1) == 0;
         [[maybe_unused]] int x_got = 0;          // X entries of the tile in flight (scan_tile_x)
         const double* y_c = ap->y + (long long)curve * n;
         if constexpr (ROLE != kRoleSearch) {
         // gather flux (and weights) in folded order; ph_orig (regA) is dead from here on.  kG
         // elements per step: their global reads (L2 latency) are in flight together -- the compiler
         // cannot overlap them itself, the LDS store of one may alias the index read of the next
-        const bool gathered = !RESIDENT && (fused || (sorted && ap->n_curves == 1));   // the sort did it on the way
+        const bool gathered = !RESIDENT && sorted && ap->n_curves == 1;   // the sort did it on the way
         constexpr int kG = TLS_GATHER_DEPTH;
         for (int k0 = tid; k0 < (gathered ? 0 : n); k0 += kG * nt) {
             int idx[kG];
@@ -318,9 +327,44 @@
         const int k_x = __builtin_amdgcn_readfirstlane(rows_c[p].k_x);
         const int n_rows = k_hi - k_lo;
         TLS_CHECK(*ap, 0 <= k_lo && k_lo <= k_x && k_x <= k_hi && k_hi <= ap->n_widths, kChkWorkItem);
+        // the duration rows THIS work item walks: all of the period's, or (search role with row parts) its contiguous share
+        // [ka, kb) by expected work -- row_cost is a prefix over the width table (host: expected taps + cells of a row), part
+        // j takes the rows whose prefix lies in the j-th of `row_parts` equal slices of the period's total.  Every row belongs
+        // to exactly one part; the parts' winners meet under the reference's total order like the tiles' (phase 4).
+        int ka = k_lo, kb = k_hi;
+        if constexpr (ROLE == kRoleSearch) {
+            if (row_parts > 1 && n_rows > 0) {
+                const double c0 = ap->row_cost[k_lo], c1 = ap->row_cost[k_hi];
+                const double lo_t = c0 + (c1 - c0) * ((double)item_part / (double)row_parts);
+                const double hi_t = c0 + (c1 - c0) * ((double)(item_part + 1) / (double)row_parts);
+                // row k belongs to the part whose slice holds the MIDDLE of its cost interval
+                ka = k_hi; kb = k_lo;
+#pragma unroll 1
+                for (int k = k_lo; k < k_hi; ++k) {
+                    const double mid = 0.5 * (ap->row_cost[k] + ap->row_cost[k + 1]);
+                    const bool mine = (mid >= lo_t || item_part == 0) && (mid < hi_t || item_part == row_parts - 1);
+                    if (mine) { ka = k < ka ? k : ka; kb = k + 1 > kb ? k + 1 : kb; }
+                }
+                if (ka >= kb) { ka = k_lo; kb = k_lo; }   // (an empty share: nothing to walk)
+                ka = __builtin_amdgcn_readfirstlane(ka); kb = __builtin_amdgcn_readfirstlane(kb);
+            }
+        }
+        const int kx_a = k_x < ka ? ka : (k_x > kb ? kb : k_x);   // dense rows of the share: [ka, kx_a), strided: [kx_a, kb)
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
         if (tid == 0) s_work[3] = 0;   // ticket counter of the strided rows (phase 3a), published the same way
         if constexpr (BAND) { if (tid == 0 && !resolve_band) s_work[4] = 0; }   // the noted band windows of this light curve's attempt
+        // (search role: the fold role has done it -- except for the second entry of a work item whose fast attempt noted band
+        // windows or overflowed: the fold left no X for a fast period, the item forms the period's exact prefix sum itself.
+        // Two items of one period may do so at the same time: they store the same values.)
+        if constexpr (ROLE == kRoleSearch) {
+            if (again) {   // (out of line, with registers of its own: rare, and the search role's allocation stays what phase 3 needs)
+                typedef global_ptr<const double> gcd;
+                typedef global_ptr<double> gd;
+                slab_exact_prefix_call((gcd)regA, (gd)regB, n, M, region_pad, ap->cumsum_round,
+                                       lds_address(reinterpret_cast<double*>(smem + ap->hdr_bytes) + 1), lds_address(cumsum_scratch),
+                                       (global_ptr<unsigned long long>)ap->phase_cycles);
+            }
+        }
         if constexpr (ROLE != kRoleSearch) {
         // numpy.cumsum order (helpers.py:72), bit for bit, evaluated by the whole workgroup -- or, in fast mode,
         // e = 1 - f and its plain prefix sum X in one pass (depth_pass explains why that decides the same cells)
@@ -334,9 +378,9 @@
             exact_sequential_cumsum(regA, regB, M, cumsum_scratch, ap->phase_cycles);
 #endif
             }
-        } else if (!fused && x_staging) {
+        } else if (x_staging) {
             // (fast mode with X formed at tile-staging time: no prefix-sum pass, the slab's X region is written tile by tile)
-        } else if (!fused) {
+        } else {
             // the series is in the HBM slab: the scan runs through LDS, 16 K elements a round, in place
             // (C[k+1] over f[k]); the patch (core.py:126: the first W samples again) is an index mapping
             // of the copy-in; LDS-only barriers, so the prefix-sum stores of a round stay in flight
@@ -396,10 +440,6 @@
                 lds_barrier();
                 pc.mark(27);
             }
-        } else {
-            // (the fused sort path has left C in the slab)
-            __syncthreads();
-            for (int k = tid; k <= M; k += nt) regB[k] = (double)k - regB[k];
         }
         // sentinels behind X: a window that would start past the end of the T0 grid sees an
         // absurdly negative "depth" and fails the depth predicate without any bounds test.  The
@@ -514,7 +554,7 @@
                 lead = kept_lead; n_eval = kept_eval; n_steps = kept_steps; n_issued = kept_issued;
             }
         }
-        const int p_end = ROLE == kRoleSearch ? p_first + 1 : (resolving ? 0 : M);
+        const int p_end = resolving ? p_first : (ROLE == kRoleSearch ? p_first + 1 : M);
         for (int p_lo = p_first; p_lo < p_end; p_lo += tile_len) {
         const int p_hi = p_lo + tile_len;
         const double* e_base = regA;   // e_base[b] = sample b of e (or e*w)
@@ -523,30 +563,9 @@
         if constexpr (!RESIDENT) {
             double* tile_e = reinterpret_cast<double*>(smem + ap->hdr_bytes);
             const int staged = ap->tile_len + ap->tile_halo;
-            double* tile_w = tile_e + staged;
-            double* tile_c = UNIFORM_W ? tile_w : tile_w + staged;
             __syncthreads();  // the previous tile (or the sort histogram) is no longer read
             pc.mark(20);
-            if constexpr (STAGE_C) {
-                {
-                    const int avail = M + 1 + region_pad - p_lo;            // entries the slab still holds
-                    const int valid = avail < staged ? (avail > 0 ? avail : 0) : staged;
-                    if (TLS_SLAB_DMA && (n & 1) == 0) {
-                        stage_samples_async<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M, tid);
-                        slab_to_lds_async(tile_c, regB, p_lo, valid, 0x7fffffff, tid);
-                        vmem_wait_all();
-                        lds_barrier();
-                        finish_samples<UNIFORM_W>(tile_e, tile_w, p_lo, staged, M, tid);
-                    } else {
-                        stage_samples<UNIFORM_W>(tile_e, tile_w, regA, regW, p_lo, staged, n, M);
-                        copy_in_flight4(tile_c, regB + p_lo, valid);
-                    }
-                    for (int k = valid + tid; k < staged; k += nt) tile_c[k] = -(double)(p_lo + k - M) * 1.0e300;
-                }
-                e_base = tile_e - p_lo;
-                w_base = tile_w - p_lo;
-                c_base = tile_c - p_lo;
-            } else {
+            {
                 // no room for C beside the samples: the predicate pass gets C in the samples' place
                 // (sequential HBM reads instead of the predicate's scattered ones), the samples follow
                 // once the live units are listed
@@ -556,9 +575,8 @@
                     slab_to_lds_async(tile_e, regA, p_lo, have, n, tid);
                     vmem_wait_all();
                     lds_barrier();
-                    scan_tile_x(tile_e, have, staged, x_carry, reinterpret_cast<double*>(cumsum_scratch), tid);
+                    scan_tile_x(tile_e, have, staged, 0.0, reinterpret_cast<double*>(cumsum_scratch), tid);
                     const int got = have < staged ? have + 1 : staged;          // X entries formed
-                    if (tile_len < got) x_carry = tile_e[tile_len];
                     x_got = got;   // (X goes to the slab only if the tile turns out to have live cells: below)
                     for (int k = got + tid; k < staged; k += nt) tile_e[k] = -(double)(p_lo + k - M) * 1.0e300;
                 } else {
@@ -586,8 +604,8 @@
         // (the mean is monotone in the window sum, so min() decides exactly).
         const bool exact_u = __builtin_amdgcn_readfirstlane((int)exact_mode) != 0;
         const double thr_hi = rule.dmin + rule.eps, thr_lo = rule.dmin - rule.eps;
-        if (k_x > k_lo) {
-            const int units0 = widths_c[k_lo].n_chunks;  // the shortest width has the most positions
+        if (kx_a > ka) {
+            const int units0 = widths_c[ka].n_chunks;  // the shortest width has the most positions
             const int unit_lo = p_lo / kR;               // tile bounds are multiples of kR * 64
             const int unit_hi = p_hi / kR < units0 ? p_hi / kR : units0;
             const int n_dense = k_x - k_lo;
@@ -610,13 +628,13 @@
 #define TLS_ROW_BATCH 2
 #endif
                 constexpr int kRowBatch = TLS_ROW_BATCH;
-                for (int k = k_lo; k < k_x; k += kRowBatch) {
+                for (int k = ka; k < kx_a; k += kRowBatch) {
                     int dv[kRowBatch];
                     double inv[kRowBatch], dC[kRowBatch];
                     double c_hi[kRowBatch][kR];
 #pragma unroll
                     for (int j = 0; j < kRowBatch; ++j) {
-                        const int kk = k + j < k_x ? k + j : k_x - 1;  // the tail repeats the last row
+                        const int kk = k + j < kx_a ? k + j : kx_a - 1;  // the tail repeats the last row
                         dv[j] = widths_c[kk].width;
                         inv[j] = widths_c[kk].inv_d;
                         const int hi0 = min(u0 + dv[j], M + 1);  // past the grid: sentinels
@@ -633,7 +651,7 @@
                     }
 #pragma unroll
                     for (int j = 0; j < kRowBatch; ++j) {
-                        if (k + j < k_x) {
+                        if (k + j < kx_a) {
                             // (a lane past the row's units reads sentinels or foreign cells: it is masked below and
                             // must not raise `undecided`)
                             // the row's live lanes as a wave-uniform mask, straight from the compare
@@ -707,10 +725,10 @@
         for (;;) {
             int ticket = 0;
             if (lane == 0) ticket = atomicAdd(&s_work[3], 1);
-            const int k = (k_x > k_lo ? k_x : k_lo) + __builtin_amdgcn_readfirstlane(ticket);
-            if (k >= k_hi) break;
+            const int k = kx_a + __builtin_amdgcn_readfirstlane(ticket);
+            if (k >= kb) break;
 #else
-        for (int k = (k_x > k_lo ? k_x : k_lo) + wave; k < k_hi; k += nw) {
+        for (int k = kx_a + wave; k < kb; k += nw) {
 #endif
             const int d = widths_c[k].width, xth = widths_c[k].xth, n_pos = widths_c[k].n_pos;
             const int n_units = widths_c[k].n_chunks;
@@ -798,9 +816,9 @@
         // parts, sum_j q_j e_{i+j} = sum_{j<=L} g_j X_{i+j} with the difference taps g (host: L.g) --, so the tile keeps its X
         // for phase 3b: no second staging of the samples, no X written to the slab and read back (Kepler size: 4.0 -> 2.8 MB
         // of slab traffic per period).  X is exact here (a sum of multiples of 2^-53 below 1), the taps carry one rounding.
-        [[maybe_unused]] const bool x_dot = !RESIDENT && !STAGE_C && UNIFORM_W && !PRUNE && x_staging && ap->g != nullptr;
+        [[maybe_unused]] const bool x_dot = !RESIDENT && UNIFORM_W && x_staging && ap->g != nullptr;
         [[maybe_unused]] const double* x_tile = nullptr;
-        if constexpr (!RESIDENT && !STAGE_C) {
+        if constexpr (!RESIDENT) {
           if (x_dot) {
             // (the tile's X, biased by -p_lo like every tile pointer.  x_tile is read through the LDS address space only --
             // x_load<true>, load_taps --: c_base is a global pointer on the other path, and one pointer that is either is FLAT)
@@ -967,7 +985,7 @@
                     const const_screen_ptr scr = screens_c + k;
                     // (the screen reads kSeg + 1 values of X per window through c_base: LDS when the series is resident or
                     // the tile holds X beside the samples; not worth it from the HBM slab)
-                    const bool screened = (RESIDENT || STAGE_C) && prunable && scr->valid != 0;
+                    const bool screened = RESIDENT && prunable && scr->valid != 0;
                     const double slack = slack_unit * (double)(d + 64);
                     const int reach = tiled ? (kR - 1) * xth + d : d;   // samples covered by the windows of a unit
                     const int step = tiled ? kR * xth : xth;            // samples between two units
@@ -1164,7 +1182,7 @@
                         pass = depth_pass(dX, inv_d, dd, dmin, rule.eps, exact_mode, und_w);
                         if (und_w) band_window(rule, k, i, dX, undecided);
                         if (bound_row && pass) {
-                            if ((RESIDENT || STAGE_C) && screened_row)
+                            if (RESIDENT && screened_row)
                                 pass = (double)window_bound(c_base, i, d, dd, inv_d, ov, widths_c[k].sum_q2, screens_c + k, P2,
                                                             ap->p2_shift, p2_blocks, dmin, rule.eps, exact_mode, undecided,
                                                             slack_unit * (double)(d + 64)) >= T;
@@ -1548,7 +1566,7 @@
                 // of them (the comparison is the reference's total order on (value, width, T0): any order of arrival
                 // gives the same cell).  Agent-scope atomics: the tiles of a period run on different XCDs.
                 typedef unsigned long long u64;
-                const unsigned int tiles_p = ap->tile_prefix[work + 1] - ap->tile_prefix[work];
+                const unsigned int tiles_p = ap->tile_prefix[work + 1] - ap->tile_prefix[work];   // (tiles x row parts)
                 if (tiles_p > 1u) {
                     u64* mine = reinterpret_cast<u64*>(ap->partials) + 3LL * item;
                     __hip_atomic_store(mine + 0, (u64)__double_as_longlong(g.stat), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1560,7 +1578,7 @@
                     reset_ready = write_out;
                     if (write_out) {
                         __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next batch
-                        const u64* first = reinterpret_cast<const u64*>(ap->partials) + 3LL * ((long long)item - item_tile);
+                        const u64* first = reinterpret_cast<const u64*>(ap->partials) + 3LL * (long long)item_first;
                         for (unsigned int j = 0; j < tiles_p; ++j) {
                             Best o;
                             o.stat = __longlong_as_double((long long)__hip_atomic_load(first + 3 * j + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));

@@ -12,6 +12,61 @@ from . import _lib
 
 _default_context = {}
 _device_groups = {}
+_groups_lock = threading.Lock()
+
+# devices="auto" (the default of power(), validate.py:81's use_threads = cpu_count()): the grid goes over every visible
+# GPU when the one-GPU search is modelled to take longer than sharding costs -- a launch and a share of one all-gather per
+# extra rank (~50 us each, measured launch + small-message RCCL latency) -- and stays on one GPU otherwise
+AUTO_OVERHEAD_S_PER_RANK = 50e-6
+SHADER_CLOCK_HZ = 2.4e9   # tls_period_costs returns shader cycles of an MI355X
+
+
+def resolve_devices(devices=None, device=None, context=None):
+    """One place that reads the three ways a caller names GPUs (api.power, search_periods, survey.*_batch).
+
+    Returns ("group", DeviceGroup) | ("list", [ids...]) (two or more) | ("one", device id or None) | ("auto", None).
+    Raises ValueError for an empty list, non-integer ids, or devices= combined with device= / context=."""
+    if devices is None:
+        return "one", device
+    if isinstance(devices, DeviceGroup):
+        if device is not None or context is not None:
+            raise ValueError("pass either devices= or device=/context=, not both")
+        return "group", devices
+    if isinstance(devices, str):
+        if devices != "auto":
+            raise ValueError('devices must be a list of GPU ids, a DeviceGroup or "auto"')
+        if device is not None or context is not None:   # an explicit single device wins over the default "auto"
+            return "one", device
+        return "auto", None
+    try:
+        ids = [int(d) for d in devices]
+        same = all(int(d) == d for d in devices)
+    except (TypeError, ValueError):
+        raise ValueError("devices must be a non-empty list of integer GPU ids")
+    if not ids or not same or any(d < 0 for d in ids):
+        raise ValueError("devices must be a non-empty list of non-negative integer GPU ids")
+    if device is not None or context is not None:
+        raise ValueError("pass either devices= or device=/context=, not both")
+    if len(ids) == 1:
+        return "one", ids[0]
+    return "list", ids
+
+
+def auto_devices(t, y, periods, table, params, n_visible=None, options=None):
+    """devices="auto": the ids to shard over (a list of two or more) or None for one GPU.  The modelled one-GPU search
+    time T1 (tls_period_costs: shader cycles per period, `slots` periods side by side) against the overhead of sharding:
+    n GPUs are modelled to take T1 / n + AUTO_OVERHEAD_S_PER_RANK * (n - 1); the n with the smallest value is taken (every
+    visible GPU once T1 is a few milliseconds; one GPU when the search is shorter than the overhead)."""
+    from . import shard
+    n_visible = _lib.device_count() if n_visible is None else int(n_visible)
+    if n_visible <= 1 or len(periods) < 2 * n_visible:
+        return None
+    sigma = float(numpy.std(numpy.asarray(y, dtype=numpy.float64)))
+    _, _, times, slots = _lib.period_costs(t, periods, table, params, sigma, with_slots=True, options=options)
+    one_gpu_s = shard.block_makespan(times, slots) / SHADER_CLOCK_HZ
+    modelled = [one_gpu_s / n + AUTO_OVERHEAD_S_PER_RANK * (n - 1) for n in range(1, n_visible + 1)]
+    n_best = 1 + int(numpy.argmin(modelled))
+    return list(range(n_best)) if n_best > 1 else None
 
 
 def default_context(device=None):
@@ -24,8 +79,8 @@ def default_context(device=None):
 
 class DeviceGroup(object):
     """The period grid of ONE search over several GPUs of this process: one tls_ctx and one host thread per listed
-    device ("internally one host thread per GPU"), contiguous period blocks placed by modelled time
-    (tls_amd.shard), and the per-period (chi2, row, depth) triples brought together by ONE collective: an RCCL
+    device ("internally one host thread per GPU"), the periods dealt out cyclically (rank r takes
+    periods[r::n], tls_amd.shard), and the per-period (chi2, row, depth) triples brought together by ONE collective: an RCCL
     all-gather over the devices (tls_comm_*, ncclAllGather on every context's stream) when they are distinct GPUs,
     a device-to-host copy per block and a concatenation when the list names a GPU more than once (RCCL takes one
     rank per device).  The counterpart of the reference's Pool(processes=use_threads) over periods
@@ -44,7 +99,8 @@ class DeviceGroup(object):
         self.distinct = len(set(self.devices)) == len(self.devices)
         self.uses_rccl = self.distinct and len(self.devices) > 1
         self._comm_ready = False
-        self.last_blocks = None          # period-block boundaries of the last search
+        self._lock = threading.RLock()   # one search (or batch) at a time: the contexts and the communicator are not re-entrant
+        self.last_blocks = None          # periods per rank of the last search (cyclic shares: rank r took periods[r::n])
         self.last_collective = None      # "rccl_allgather" | "host_concatenate" | "none"
 
     def _threads(self, fn):
@@ -72,41 +128,82 @@ class DeviceGroup(object):
             return
         uid = self.contexts[0].comm_unique_id()
         n = len(self.contexts)
-        self._threads(lambda r: self.contexts[r].comm_init(n, r, uid))   # ncclCommInitRank: every rank from its own thread
+        try:
+            self._threads(lambda r: self.contexts[r].comm_init(n, r, uid))   # ncclCommInitRank: every rank from its own thread
+        except BaseException:
+            self._drop()   # (a rank that never joined leaves the others' communicators half-built)
+            raise
         self._comm_ready = True
 
+    def _drop(self):
+        """After a failure inside a collective the communicator is unusable: the group leaves the per-process cache and
+        is closed (close() does both); the next call builds a fresh one."""
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def search(self, t, y, dy, periods, table, params):
+        with self._lock:
+            return self._search(t, y, dy, periods, table, params)
+
+    def _search(self, t, y, dy, periods, table, params):
         from . import shard
+        if not self.contexts:
+            raise RuntimeError("tls_amd: this DeviceGroup is closed")
         n = len(self.contexts)
         periods = numpy.ascontiguousarray(periods, dtype=numpy.float64)
         if n == 1:
             self.last_blocks, self.last_collective = numpy.asarray([0, len(periods)]), "none"
             return self.contexts[0].search(t, y, dy, periods, table, params)[:3]
         job = shard.ShardedSearch(0, n)
-        job.plan(t, periods, table, params, y=y, options=self.contexts[0].get_options())
-        bounds, count = job.bounds, job.count_per_rank
-        self.last_blocks = bounds
+        job.plan(t, periods, table, params, with_costs=False)      # cyclic shares: rank r searches periods[r::n]
+        count = job.count_per_rank
+        shares = [job.indices(r) for r in range(n)]
+        self.last_blocks = numpy.asarray([len(ix) for ix in shares])
         self._ensure_comm()
         parts = [None] * n
 
-        def work(r):
+        # Two phases with a join between them: a rank that fails to prepare or execute (bad device, out of memory) must
+        # not leave the others waiting in the all-gather for ever.  Phase 1 -- every rank searches its block and waits
+        # for its own stream; only if ALL of them succeeded does phase 2 enter the collective.
+        def search_block(r):
             ctx = self.contexts[r]
-            lo, hi = int(bounds[r]), int(bounds[r + 1])
-            ctx.prepare(t, y, dy, periods[lo:hi], table, params)
+            ctx.prepare(t, y, dy, numpy.ascontiguousarray(periods[shares[r]]), table, params)
             ctx.execute()
+            ctx.synchronize()
+
+        self._threads(search_block)   # (raises before anybody has touched the communicator: it stays usable)
+
+        def gather(r):
+            ctx = self.contexts[r]
             # RCCL: every rank contributes its (zero-padded) block and receives all of them; otherwise its own block
             parts[r] = ctx.comm_allgather_results(count, n) if self.uses_rccl else ctx.fetch()
 
-        self._threads(work)
+        try:
+            self._threads(gather)
+        except BaseException:
+            if self.uses_rccl:
+                self._drop()
+            raise
         if self.uses_rccl:
             self.last_collective = "rccl_allgather"
             chi2, row, depth = parts[0]
-            return (shard.assemble(chi2, bounds, count), shard.assemble(row, bounds, count),
-                    shard.assemble(depth, bounds, count))
+            return job.assemble(chi2), job.assemble(row), job.assemble(depth)
         self.last_collective = "host_concatenate"
-        return tuple(numpy.concatenate([parts[r][k] for r in range(n)]) for k in range(3))
+        out = []
+        for k in range(3):
+            full = numpy.empty(len(periods), dtype=parts[0][k].dtype)
+            for r in range(n):
+                full[shares[r]] = parts[r][k]
+            out.append(full)
+        return tuple(out)
 
     def close(self):
+        with _groups_lock:   # (a closed group is never handed out again)
+            for key, grp in list(_device_groups.items()):
+                if grp is self:
+                    del _device_groups[key]
         for ctx in self.contexts:
             if self._comm_ready:
                 try:
@@ -115,42 +212,53 @@ class DeviceGroup(object):
                     pass
             ctx.close()
         self.contexts = []
+        self._comm_ready = False
 
 
 def device_group(devices):
     """Per-process cache of DeviceGroups keyed by the device list (contexts and the RCCL communicator are kept)."""
     key = tuple(int(d) for d in devices)
-    if key not in _device_groups:
-        _device_groups[key] = DeviceGroup(key)
-    return _device_groups[key]
+    if not key:
+        raise ValueError("devices must name at least one GPU")
+    with _groups_lock:
+        if key not in _device_groups:
+            _device_groups[key] = DeviceGroup(key)
+        return _device_groups[key]
 
 
 def search_periods(t, y, dy, periods, table, transit_depth_min, R_star_min, R_star_max,
                    M_star_min, M_star_max, T0_fit_margin, context=None, device=None,
-                   verbose=False, count_work=False, return_counters=False, devices=None):
+                   verbose=False, count_work=False, return_counters=False, devices=None, used=None):
     """chi2, row, depth for every trial period (same order as `periods`).
 
     table: tls_amd.template.TemplateTable.  Raises RuntimeError if the HIP
     library or a GPU is unavailable -- there is no CPU path.
-    devices: a list of GPU ids shards the period grid over them (DeviceGroup); None / one id: one GPU.
+    devices: a list of GPU ids shards the period grid over them (DeviceGroup); None / one id: one GPU; "auto": every
+    visible GPU when the modelled one-GPU time exceeds the overhead of sharding (auto_devices).
+    used: a dict that receives "context" (the context of the single device, or the group's first) and "devices".
     """
     params = dict(transit_depth_min=transit_depth_min, R_star_min=R_star_min,
                   R_star_max=R_star_max, M_star_min=M_star_min, M_star_max=M_star_max,
                   T0_fit_margin=T0_fit_margin)
-    if devices is not None and (isinstance(devices, DeviceGroup) or len(devices) > 1):
-        if context is not None:
-            raise ValueError("pass either context= or devices=, not both")
-        group = devices if isinstance(devices, DeviceGroup) else device_group(devices)
+    kind, what = resolve_devices(devices, device, context)
+    if kind == "auto":
+        ids = auto_devices(t, y, periods, table, params)
+        kind, what = ("list", ids) if ids else ("one", None)
+    if kind in ("group", "list"):
+        group = what if kind == "group" else device_group(what)
         chi2, row, depth = group.search(t, y, dy, periods, table, params)
+        if used is not None:
+            used["context"], used["devices"] = group.contexts[0], list(group.devices)
         if verbose:
-            print("GPU search on %d devices %s: period blocks %s, %s" % (len(group.devices), group.devices,
-                                                                        list(numpy.diff(group.last_blocks)), group.last_collective))
+            print("GPU search on %d devices %s: periods per device %s, %s" % (len(group.devices), group.devices,
+                                                                          list(group.last_blocks), group.last_collective))
         if return_counters:
             return chi2, row, depth, None
         return chi2, row, depth
-    if devices is not None and len(devices) == 1 and device is None and context is None:
-        device = list(devices)[0]
+    device = what
     ctx = context if context is not None else default_context(device)
+    if used is not None:
+        used["context"], used["devices"] = ctx, [getattr(ctx, "device", device)]
     chi2, row, depth, counters = ctx.search(t, y, dy, periods, table, params,
                                             count_work=count_work)
     if verbose:

@@ -1,15 +1,21 @@
-"""Multi-GPU mode: the period grid block-partitioned over ranks (one process per
-GPU), each rank searching its contiguous block, ONE all-gather of the per-period
-(chi2, row, depth) triples at the end.
+"""Multi-GPU mode: the period grid partitioned over ranks (one process per GPU, or one context per GPU of one
+process: tls_amd.search.DeviceGroup), each rank searching its share, ONE all-gather of the per-period (chi2, row,
+depth) triples at the end.
 
-The reference's only parallelism is exactly this data parallelism over periods
-(a multiprocessing pool, main.py:140-163); periods are independent, so there is
-no exchange inside the search.  Block boundaries are placed by cumulative trial-
-cell cost, not by count: cells per period vary 4x across the grid.
+The reference's only parallelism is exactly this data parallelism over periods (a multiprocessing pool handing out
+ONE period at a time, main.py:140-163); periods are independent, so there is no exchange inside the search.
 
-The collective is pluggable so the host logic can be exercised without GPUs:
-`RcclGather` (product: ncclAllGather through the C ABI) or any callable with the
-same signature (tests use torch.distributed/gloo).
+Layout (round 6): **cyclic** -- rank r takes periods r, r + R, r + 2R, ... of the ascending grid (a block-cyclic
+partition with blocks of one period).  Cells per period vary 4x across the grid and a period's cost with its kernel,
+its noise level and its neighbours on the CU; rounds 2-5 placed CONTIGUOUS blocks by a fitted time model
+(`partition_by_makespan`, kept below: bench.py still reports it) and were as good as the model: 4.2 (90 d), 5.2
+(TESS) and 7.3 (Kepler) of 8 on the one-GPU projection.  Dealing the periods out in turn gives every rank the same mix of
+short and long periods whatever the model says -- what the reference's pool does by handing out single periods --, and
+each rank's own queue then packs its share longest-first (Kepler 7.8 projected; TESS 6.0 with the two-role kernel
+that short launches of a slab series take).  A period's result does not depend on which rank searches it.
+
+The collective is pluggable so the host logic can be exercised without GPUs: `RcclGather` (product: ncclAllGather
+through the C ABI) or any callable with the same signature (tests use torch.distributed/gloo).
 """
 import numpy
 
@@ -106,13 +112,29 @@ def bounds_digest(bounds):
 
 
 def assemble(gathered, bounds, count_per_rank):
-    """Undo the padding of an all-gather: `gathered` has n_ranks blocks of
+    """Undo the padding of an all-gather of CONTIGUOUS blocks: `gathered` has n_ranks blocks of
     count_per_rank entries; block r carries bounds[r+1]-bounds[r] valid ones."""
     parts = []
     for r in range(len(bounds) - 1):
         size = int(bounds[r + 1] - bounds[r])
         parts.append(gathered[r * count_per_rank: r * count_per_rank + size])
     return numpy.concatenate(parts) if parts else gathered[:0]
+
+
+def cyclic_indices(n_periods, n_ranks, rank):
+    """Periods of rank `rank` under the cyclic layout: rank, rank + n_ranks, ..."""
+    return numpy.arange(int(rank), int(n_periods), int(n_ranks), dtype=numpy.int64)
+
+
+def assemble_cyclic(gathered, n_periods, n_ranks, count_per_rank):
+    """Undo the padding AND the interleaving of an all-gather of cyclic shares: entry j of rank r's block is period
+    r + j * n_ranks."""
+    gathered = numpy.asarray(gathered)
+    out = numpy.empty(int(n_periods), dtype=gathered.dtype)
+    for r in range(int(n_ranks)):
+        idx = cyclic_indices(n_periods, n_ranks, r)
+        out[idx] = gathered[r * count_per_rank: r * count_per_rank + len(idx)]
+    return out
 
 
 class RcclGather(object):
@@ -128,51 +150,69 @@ class RcclGather(object):
 class ShardedSearch(object):
     """One rank's view of a period-sharded search.
 
-    plan(...)     decide the blocks (same on every rank), prepare this rank's block
-    run()         execute on this rank's GPU (asynchronous)
+    plan(...)     decide the shares (same on every rank); returns this rank's period indices
     gather(fn)    all-gather + assemble -> full chi2/row/depth on every rank
-    """
 
-    def __init__(self, rank, n_ranks):
-        self.rank, self.n_ranks = int(rank), int(n_ranks)
-        self.bounds = None
+    layout "cyclic" (default): rank r searches periods[r::n_ranks].  layout "blocks": contiguous blocks placed by the
+    modelled time of tls_period_costs (rounds 2-5; `bounds`)."""
+
+    def __init__(self, rank, n_ranks, layout="cyclic"):
+        if layout not in ("cyclic", "blocks"):
+            raise ValueError("layout must be 'cyclic' or 'blocks'")
+        self.rank, self.n_ranks, self.layout = int(rank), int(n_ranks), layout
+        self.n_periods = 0
+        self.bounds = None   # layout "blocks": boundaries of the contiguous blocks
         self.count_per_rank = 0
         self.costs = None    # trial cells per period
         self.taps = None     # expected template taps per period
-        self.times = None    # modelled search time per period: what the boundaries balance
+        self.times = None    # modelled search time per period
+        self.slots = 0
 
-    def plan(self, t, periods, table, params, y=None, options=None, allgather_digests=None):
-        """Block boundaries by cumulative MODELLED TIME (tls_period_costs): per period a fixed part (fold, sort,
-        prefix sum), a part per trial cell and a part per expected template tap.  Balancing trial cells alone
-        leaves the blocks of short periods -- many cheap periods, each with the full fixed cost -- 1.2x (90 d),
-        2.1x (TESS) and 4x (Kepler 4 yr) slower than the mean at 8 ranks (profiles/r03_cost_model_fit.json).
-        y (the flux) only sets the noise level the tap estimate assumes; every rank must pass the same.
-        options: the switches of the searching context (Context.get_options()): the model prices the kernel variant
-        and prefix-sum mode the search will run.  allgather_digests: a callable (32-byte digest) -> list of every
-        rank's digest; when given, the ranks compare the boundaries they derived before anything is searched (every
-        rank derives them itself from floating-point model times: ranks that disagreed -- different devices visible,
-        different switches -- would assemble mismatched blocks without any error)."""
-        sigma = 0.0 if y is None else float(numpy.std(numpy.asarray(y, dtype=numpy.float64)))
-        self.costs, self.taps, self.times, self.slots = _lib.period_costs(t, periods, table, params, sigma, with_slots=True,
-                                                                          options=options)
-        # (a rank's GPU searches `slots` periods side by side: what is balanced is the time of its LAST round's end)
-        self.bounds = partition_by_makespan(self.times, self.n_ranks, self.slots)
-        self.count_per_rank = max(1, int(numpy.max(numpy.diff(self.bounds))))
-        if allgather_digests is not None:
+    def indices(self, rank=None):
+        """Period indices (into the ascending grid) of a rank's share."""
+        r = self.rank if rank is None else int(rank)
+        if self.layout == "cyclic":
+            return cyclic_indices(self.n_periods, self.n_ranks, r)
+        return numpy.arange(int(self.bounds[r]), int(self.bounds[r + 1]), dtype=numpy.int64)
+
+    def plan(self, t, periods, table, params, y=None, options=None, allgather_digests=None, with_costs=True):
+        """The shares of every rank.  Cyclic layout: nothing to compute (the cost model is evaluated all the same when
+        `with_costs`: bench.py and the tests report modelled against measured balance).  Block layout: boundaries by
+        cumulative MODELLED TIME (tls_period_costs): per period a fixed part (fold, sort, prefix sum), a part per trial
+        cell and a part per expected template tap.  y (the flux) only sets the noise level the tap estimate assumes;
+        every rank must pass the same.  options: the switches of the searching context (Context.get_options()).
+        allgather_digests: a callable (32-byte digest) -> list of every rank's digest; when given, the ranks compare the
+        shares they derived before anything is searched (ranks that disagreed -- different grids, different switches --
+        would assemble mismatched results without any error).  Returns this rank's period indices."""
+        self.n_periods = len(periods)
+        if with_costs or self.layout == "blocks":
+            sigma = 0.0 if y is None else float(numpy.std(numpy.asarray(y, dtype=numpy.float64)))
+            self.costs, self.taps, self.times, self.slots = _lib.period_costs(t, periods, table, params, sigma, with_slots=True,
+                                                                              options=options)
+        if self.layout == "blocks":
+            # (a rank's GPU searches `slots` periods side by side: what is balanced is the time of its LAST round's end)
+            self.bounds = partition_by_makespan(self.times, self.n_ranks, self.slots)
+            self.count_per_rank = max(1, int(numpy.max(numpy.diff(self.bounds))))
             mine = bounds_digest(self.bounds)
+        else:
+            self.count_per_rank = max(1, -(-self.n_periods // self.n_ranks))
+            mine = bounds_digest(numpy.asarray([self.n_periods, self.n_ranks, self.count_per_rank]))
+        if allgather_digests is not None:
             theirs = [bytes(d) for d in allgather_digests(mine)]
             if len(theirs) != self.n_ranks or any(d != mine for d in theirs):
-                raise RuntimeError("tls_amd: the ranks derived different period blocks (rank %d of %d): same inputs, "
+                raise RuntimeError("tls_amd: the ranks derived different period shares (rank %d of %d): same inputs, "
                                    "switches and device type on every rank?" % (self.rank, self.n_ranks))
-        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
-        return int(lo), int(hi)
+        return self.indices()
 
     def my_cells(self):
-        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
-        return int(numpy.sum(self.costs[lo:hi]))
+        return int(numpy.sum(self.costs[self.indices()]))
 
     def gather(self, allgather):
         chi2, row, depth = allgather(self.count_per_rank)
-        c = self.count_per_rank
-        return (assemble(chi2, self.bounds, c), assemble(row, self.bounds, c),
-                assemble(depth, self.bounds, c))
+        return self.assemble(chi2), self.assemble(row), self.assemble(depth)
+
+    def assemble(self, gathered):
+        """One gathered array (n_ranks blocks of count_per_rank entries) back in grid order."""
+        if self.layout == "cyclic":
+            return assemble_cyclic(gathered, self.n_periods, self.n_ranks, self.count_per_rank)
+        return assemble(gathered, self.bounds, self.count_per_rank)

@@ -3,8 +3,8 @@ template searched back to back on one GPU by ONE C-ABI call (`tls_search_batch`)
 list, duration windows, template rows, work queue order) is prepared once; per light curve only
 the flux (and weights) are re-uploaded before the search kernel runs again.
 
-Across GPUs the light curves are simply dealt out: one process per GPU (bench.py), or `devices=[0, 1, ...]` on the
-calls below -- contiguous slices of the batch to the contexts of a `tls_amd.search.DeviceGroup`, one host thread each, no
+Across GPUs the light curves are simply dealt out: one process per GPU (bench.py), or `devices=[0, 1, ...]` / `devices="auto"`
+(every visible GPU) on the calls below -- contiguous slices of the batch to the contexts of a `tls_amd.search.DeviceGroup`, one host thread each, no
 collective (every light curve's results come back over its own GPU's copy engine).
 """
 import numpy
@@ -45,17 +45,30 @@ def _slices(n_curves, n_parts):
     return bounds
 
 
-def _on_devices(devices, call, n_curves):
+def _resolve(devices, device, context, n_curves):
+    """("group", DeviceGroup) or ("one", device id / None): search.resolve_devices, with "auto" = every visible GPU when
+    the batch has at least two light curves for each."""
+    kind, what = _search.resolve_devices(devices, device, context)
+    if kind == "auto":
+        from . import _lib
+        n = _lib.device_count()
+        kind, what = ("list", list(range(n))) if n > 1 and n_curves >= 2 * n else ("one", None)
+    if kind == "list":
+        kind, what = "group", _search.device_group(what)
+    return kind, what
+
+
+def _on_devices(group, call, n_curves):
     """call(context, lo, hi) for every device's slice of the batch, on the group's host threads; the slices' results."""
-    group = devices if isinstance(devices, _search.DeviceGroup) else _search.device_group(devices)
-    bounds = _slices(n_curves, len(group.contexts))
-    parts = [None] * len(group.contexts)
+    with group._lock:   # (the group's contexts are not re-entrant: one batch or search at a time)
+        bounds = _slices(n_curves, len(group.contexts))
+        parts = [None] * len(group.contexts)
 
-    def work(r):
-        if bounds[r + 1] > bounds[r]:
-            parts[r] = call(group.contexts[r], bounds[r], bounds[r + 1])
+        def work(r):
+            if bounds[r + 1] > bounds[r]:
+                parts[r] = call(group.contexts[r], bounds[r], bounds[r + 1])
 
-    group._threads(work)
+        group._threads(work)
     return [p for p in parts if p is not None]
 
 
@@ -79,14 +92,13 @@ def power_batch(t, flux_batch, dy_batch=None, context=None, device=None, with_ar
         return ctx.power_batch(inp["t"], y_rows[lo:hi], dy_rows[lo:hi], inp["periods"], inp["table"], inp["params"],
                                int(kernel), with_arrays=with_arrays, with_power=with_arrays)
 
-    if devices is not None and (isinstance(devices, _search.DeviceGroup) or len(devices) > 1):
-        parts = _on_devices(devices, call, len(y_rows))
+    kind, what = _resolve(devices, device, context, len(y_rows))
+    if kind == "group":
+        parts = _on_devices(what, call, len(y_rows))
         raw = numpy.concatenate([p[0] for p in parts])
         chi2, row, depth, power = (numpy.concatenate([p[k] for p in parts]) if with_arrays else None for k in (1, 2, 3, 4))
     else:
-        if devices is not None and device is None and context is None:
-            device = list(devices)[0]
-        ctx = context if context is not None else _search.default_context(device)
+        ctx = context if context is not None else _search.default_context(what)
         raw, chi2, row, depth, power = call(ctx, 0, len(y_rows))
     names = list(raw.dtype.names) + ["duration"]
     summary = numpy.zeros(len(raw), dtype=[(k, raw.dtype[k]) for k in raw.dtype.names] + [("duration", "f8")])
@@ -112,12 +124,11 @@ def search_batch(t, flux_batch, dy_batch=None, context=None, device=None, device
     def call(ctx, lo, hi):
         return ctx.search_batch(inp["t"], y_rows[lo:hi], dy_rows[lo:hi], inp["periods"], inp["table"], inp["params"])
 
-    if devices is not None and (isinstance(devices, _search.DeviceGroup) or len(devices) > 1):
-        parts = _on_devices(devices, call, len(y_rows))
+    kind, what = _resolve(devices, device, context, len(y_rows))
+    if kind == "group":
+        parts = _on_devices(what, call, len(y_rows))
         chi2, row, depth = (numpy.concatenate([p[k] for p in parts]) for k in range(3))
     else:
-        if devices is not None and device is None and context is None:
-            device = list(devices)[0]
-        ctx = context if context is not None else _search.default_context(device)
+        ctx = context if context is not None else _search.default_context(what)
         chi2, row, depth = call(ctx, 0, len(y_rows))
     return inp["periods"], chi2, row, depth
