@@ -759,8 +759,7 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
     and per-point weights; and both against the oracle.  Round 6: in the DEFAULT prefix-sum mode too (uniform weights) -- a
     period takes fast or exact mode by (light curve, period) alone in both kernels, a tile's X is formed from the tile's
     staged flux in both, a work item whose tile noted band windows forms the period's exact prefix sum itself and decides
-    them (2 % of the TESS-size and 7 % of the Kepler-size periods) -- and with the items cut further into shares of the
-    duration rows (`parts`).  Per-point weights: the two roles run exact mode only, so that comparison pins the
+    them (2 % of the TESS-size and 7 % of the Kepler-size periods).  Per-point weights: the two roles run exact mode only, so that comparison pins the
     one-kernel path to exact mode (`fast_slab = 0`) and checks its default against it to 1e-10."""
     t, f, kw = synthetic.config(name)
     dy = None
@@ -772,8 +771,8 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
     if batch:
         gpu.set_options(split_batch=batch)
     results = {}
-    for mode, parts in (("0", None), ("1", None), ("1", 2)):
-        gpu.set_options(split=mode, parts=parts)
+    for mode, parts in (("0", None), ("1", None)):
+        gpu.set_options(split=mode)
         counted = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
         assert not gpu.plan_info()["resident"]
         assert gpu.last_kernel() == ("slab+split" if mode == "1" else "slab")
@@ -784,7 +783,7 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
         for a, b in zip(plain[:3], counted[:3]):
             numpy.testing.assert_array_equal(a, b)
         results[(mode, parts)] = counted
-    for key in (("1", None), ("1", 2)):
+    for key in (("1", None),):
         for a, b in zip(results[("0", None)][:3], results[key][:3]):
             numpy.testing.assert_array_equal(a, b)
         assert results[("0", None)][3]["evaluated_cells"] == results[key][3]["evaluated_cells"]
@@ -794,7 +793,7 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
     assert results[("1", None)][3]["evaluated_cells"] == int(want[3][1])
     if per_point:
         # the one-kernel path as it runs by default (fast prefix-sum mode)
-        gpu.set_options(fast_slab=None, split="0", parts=None)
+        gpu.set_options(fast_slab=None, split="0")
         fast = gpu.search(inp["t"], inp["y"], inp["dy"], sel, inp["table"], inp["params"], count_work=True)
         numpy.testing.assert_array_equal(fast[1], results[("1", None)][1])
         numpy.testing.assert_allclose(fast[0], results[("1", None)][0], rtol=1e-10, atol=0)
@@ -802,7 +801,7 @@ def test_two_role_slab_kernel_equals_the_one_kernel_path_bit_for_bit(gpu, oracle
         assert fast[3]["inner_steps"] == results[("1", None)][3]["inner_steps"]
     else:
         # ... and the all-exact plan through both kernels (what the two roles ran before round 6)
-        gpu.set_options(fast_slab="0", parts=None)
+        gpu.set_options(fast_slab="0")
         exact = {}
         for mode in ("0", "1"):
             gpu.set_options(split=mode)

@@ -86,7 +86,6 @@ struct View {
 struct Switches {
     int32_t exact_prefix, slim;
     int32_t prune, screen32, no_screen, fast_slab, x_staged, split, split_batch, sort2, threads, blocks, plan_threads;
-    int32_t parts;           // two-role kernel: shares of a period's duration rows a (period, tile) item is cut into
     int64_t prune_min_live;
     double band_max;
 };
@@ -97,7 +96,7 @@ const SwitchName kSwitchNames[] = {
     TLS_SW(screen32, "TLS_SCREEN32", 0), TLS_SW(no_screen, "TLS_NO_SCREEN", 0), TLS_SW(fast_slab, "TLS_FAST_SLAB", 0),
     TLS_SW(x_staged, "TLS_X_STAGED", 0), TLS_SW(split, "TLS_SPLIT", 0), TLS_SW(split_batch, "TLS_SPLIT_BATCH", 0),
     TLS_SW(sort2, "TLS_SORT2", 0), TLS_SW(threads, "TLS_THREADS", 0), TLS_SW(blocks, "TLS_BLOCKS", 0),
-    TLS_SW(plan_threads, "TLS_PLAN_THREADS", 0), TLS_SW(parts, "TLS_PARTS", 0), TLS_SW(prune_min_live, "TLS_PRUNE_MIN_LIVE", 1),
+    TLS_SW(plan_threads, "TLS_PLAN_THREADS", 0), TLS_SW(prune_min_live, "TLS_PRUNE_MIN_LIVE", 1),
     TLS_SW(band_max, "TLS_BAND_MAX", 2),
 };
 #undef TLS_SW
@@ -161,7 +160,7 @@ const Switches& process_options() {
 // parameters and developer switches only replaces the flux (the search call of a survey, or of repeated power()
 // calls).  Compared byte for byte (memcmp runs at ~10 GB/s; a cfg2 key is 120 KB).
 struct PlanLayout {   // byte offsets of the plan arrays inside d_plan / h_stage (256-byte aligned)
-    size_t t = 0, y = 0, w = 0, periods = 0, order = 0, rows = 0, widths = 0, screens = 0, q = 0, q2 = 0, g = 0, tile_prefix = 0, row_cost = 0, total = 0;
+    size_t t = 0, y = 0, w = 0, periods = 0, order = 0, rows = 0, widths = 0, screens = 0, q = 0, q2 = 0, g = 0, tile_prefix = 0, total = 0;
 };
 
 struct PlanKey {
@@ -231,8 +230,6 @@ struct tls_ctx {
     int split_batch = 0;                     // periods per batch: as many slabs are held in HBM
     int64_t split_max_items = 0;             // most (period, tile, row part) items of any batch
     bool split_fast = false;                 // the two roles may run fast prefix-sum mode (uniform weights, X at staging, dot products on X)
-    int row_parts = 1;                       // shares of a period's duration rows a (period, tile) item is cut into
-    View<double> d_row_cost;                 // [n_widths + 1] expected work of the rows < k: places the shares
     View<unsigned int> d_tile_prefix;        // [n_periods + 1] tiles in front of work item w (queue order)
     std::vector<unsigned int> host_tile_prefix;
     DevBuf<double> d_partials;               // [split_max_items][3] a tile's winner
@@ -880,7 +877,6 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     a.partials = ctx->d_partials.ptr; a.tiles_done = ctx->d_tiles_done.ptr;
     a.fold_ready = ctx->d_tiles_done.ptr ? ctx->d_tiles_done.ptr + ctx->split_batch : nullptr;   // (only the two-role plan has them)
     a.split_fast = ctx->split_fast && a.x_at_staging && a.g != nullptr ? 1 : 0;
-    a.row_parts = ctx->row_parts; a.row_cost = ctx->d_row_cost.ptr;
     hipError_t e;
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
     if ((e = timing_pair(ctx, &evp)) != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("timing events: ") + hipGetErrorString(e));
@@ -1409,10 +1405,6 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             const int64_t last_round = n_periods % (int64_t)ctx->split_blocks;
             const bool short_launch = n_periods <= 4 * (int64_t)ctx->split_blocks && last_round > 0 && 10 * last_round <= 7 * (int64_t)ctx->split_blocks;
             ctx->split = n_periods > 0 && (ctx->opt.split >= 0 ? ctx->opt.split != 0 : (all_exact || ctx->split_fast) && short_launch);
-            // Row parts (switch parts = N): a (period, tile) item cut further into N shares of the period's duration rows.
-            // Measured and NOT taken by default: every share stages the tile, forms its X and walks the lists again, its
-            // waves share fewer batches (TESS-size, 307 periods: 0.479 ms with one share, 0.578 with two, 0.646 with three).
-            ctx->row_parts = 1;
             const size_t slab_bytes = regions * ((region_doubles + 1) & ~(size_t)1) * 8;
             constexpr size_t kSplitSlabBytes = (size_t)12 << 30;
             int64_t batch = std::max<int64_t>((int64_t)(kSplitSlabBytes / slab_bytes), (int64_t)4 * ctx->split_blocks);
@@ -1421,11 +1413,10 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
             ctx->host_tile_prefix.assign((size_t)n_periods + 1, 0u);
             ctx->split_max_items = 0;
             if (ctx->split) {
-                if (ctx->opt.parts >= 1) ctx->row_parts = std::min(8, (int)ctx->opt.parts);
                 for (int64_t wk = 0; wk < n_periods; ++wk) {
                     const tlsdev::PeriodRows& pr = prow[(size_t)order[(size_t)wk]];
                     const size_t tl = pr.pad > 0 ? (size_t)pr.pad : tile;      // the kernel's tile length of this period
-                    ctx->host_tile_prefix[(size_t)wk + 1] = ctx->host_tile_prefix[(size_t)wk] + (unsigned int)(((size_t)M + tl - 1) / tl) * (unsigned int)ctx->row_parts;
+                    ctx->host_tile_prefix[(size_t)wk + 1] = ctx->host_tile_prefix[(size_t)wk] + (unsigned int)(((size_t)M + tl - 1) / tl);
                 }
                 for (int64_t lo = 0; lo < n_periods; lo += ctx->split_batch) {
                     const int64_t hi = std::min<int64_t>(n_periods, lo + ctx->split_batch);
@@ -1493,7 +1484,6 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         L.g = place(with_g ? nq * 8 : 0);
         const bool with_tiles = !ctx->resident && ctx->split;
         L.tile_prefix = place(with_tiles ? (np + 1) * sizeof(unsigned int) : 0);
-        L.row_cost = place(with_tiles ? (nw + 1) * sizeof(double) : 0);
         L.total = off;
         int rcs = stage_reserve(ctx, L.total);
         if (rcs) return rcs;
@@ -1535,19 +1525,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         }
         if (with_tiles) {
             std::memcpy(h + L.tile_prefix, ctx->host_tile_prefix.data(), (np + 1) * sizeof(unsigned int));
-            // expected work of every duration row (prefix over the width table): its trial positions through the depth
-            // predicate + the template taps of the fraction of its windows that white noise of the flux's scatter sends past
-            // transit_depth_min (as tls_period_costs): only the balance of a period's row parts depends on it
-            double* rc = reinterpret_cast<double*>(h + L.row_cost);
-            rc[0] = 0.0;
-            for (size_t k = 0; k < nw; ++k) {
-                const auto& we = widths[k];
-                double frac = 1.0;
-                if (flux_sigma > 0) frac = 0.5 * std::erfc(params->transit_depth_min * std::sqrt((double)we.width) / flux_sigma / std::sqrt(2.0));
-                rc[k + 1] = rc[k] + (double)we.n_pos * (0.3 + 0.06 * (double)we.q_len * frac);
-            }
         }
-        ctx->d_row_cost.ptr = reinterpret_cast<double*>(ctx->d_plan.ptr + L.row_cost);
         unsigned char* d = ctx->d_plan.ptr;
         ctx->d_tile_prefix.ptr = reinterpret_cast<unsigned int*>(d + L.tile_prefix);
         ctx->d_t.ptr = reinterpret_cast<double*>(d + L.t); ctx->d_y.ptr = reinterpret_cast<double*>(d + L.y);

@@ -537,8 +537,8 @@ struct SearchArgs {
     int region_pad;         // spare entries behind every folded-series region (region_pad_for)
     // two-kernel slab path (kRoleFold / kRoleSearch): the periods order[batch_lo .. batch_lo + batch_n) of one batch; the
     // folded series of work item w lives in slab w - batch_lo.  The search kernel's items are (period, position tile)
-    // pairs (x row parts, SearchArgs::row_parts): tile_prefix[w] = items of all periods in front of w (in queue order), item g
-    // of the batch is tile_prefix[batch_lo] + g.  A tile's winner goes to partials[g]; the workgroup that finishes a period's last tile
+    // pairs: tile_prefix[w] = tiles of all work items in front of w (in queue order), item g of the batch is tile
+    // tile_prefix[batch_lo] + g.  A tile's winner goes to partials[g]; the workgroup that finishes a period's last tile
     // (tiles_done[slot]) compares them and writes the period's result.
     int batch_lo, batch_n;
     const unsigned int* tile_prefix;   // [n_periods + 1]
@@ -546,8 +546,6 @@ struct SearchArgs {
     unsigned int* tiles_done;          // [periods of the largest batch], zero between launches
     unsigned int* fold_ready;          // [periods of the largest batch] 1: the slab is complete; zero between launches
     int split_fast;                    // two roles: != 0 the plan supports fast prefix-sum mode there (uniform weights, X at staging, taps g)
-    int row_parts;                     // search role: a period's tiles are walked by this many work items, a share of its duration rows each
-    const double* row_cost;            // [n_widths + 1] expected work of the rows < k (prefix over the width table): places the shares
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period, double epoch) {

@@ -121,10 +121,7 @@
         bool curve_exact = false;   // batches: this light curve again in exact mode (the permutation is kept: no new sort)
         // split roles: `work` counts the items of this launch -- the periods of the batch (fold), their tiles (search)
         int n_work = ap->n_periods;
-        [[maybe_unused]] int item = 0, item_tile = 0, item_part = 0, item_first = 0;
-        // (search role: a period's items are its tiles x row parts; part j of a tile walks a contiguous share of the period's
-        // duration rows -- by expected work, SearchArgs::row_cost -- through phases 3a and 3b)
-        [[maybe_unused]] const int row_parts = ROLE == kRoleSearch ? (ap->row_parts > 1 ? ap->row_parts : 1) : 1;
+        [[maybe_unused]] int item = 0, item_tile = 0;
         if constexpr (ROLE == kRoleFold) n_work = ap->batch_n;
         if constexpr (ROLE == kRoleSearch) n_work = (int)(ap->tile_prefix[ap->batch_lo + ap->batch_n] - ap->tile_prefix[ap->batch_lo]);
         if (work >= n_work) {
@@ -154,9 +151,7 @@
                 if (ap->tile_prefix[mid] <= G) lo_w = mid; else hi_w = mid;
             }
             work = __builtin_amdgcn_readfirstlane(lo_w);
-            item_first = item - (int)(G - ap->tile_prefix[work]);          // the period's first item
-            item_tile = (int)(G - ap->tile_prefix[work]) / row_parts;
-            item_part = (int)(G - ap->tile_prefix[work]) % row_parts;
+            item_tile = (int)(G - ap->tile_prefix[work]);
             regA = ap->scratch + (long long)(work - ap->batch_lo) * ap->scratch_stride;
             regB = regA + RS;
             if constexpr (!UNIFORM_W) regW = regB + RS;
@@ -327,29 +322,6 @@
         const int k_x = __builtin_amdgcn_readfirstlane(rows_c[p].k_x);
         const int n_rows = k_hi - k_lo;
         TLS_CHECK(*ap, 0 <= k_lo && k_lo <= k_x && k_x <= k_hi && k_hi <= ap->n_widths, kChkWorkItem);
-        // the duration rows THIS work item walks: all of the period's, or (search role with row parts) its contiguous share
-        // [ka, kb) by expected work -- row_cost is a prefix over the width table (host: expected taps + cells of a row), part
-        // j takes the rows whose prefix lies in the j-th of `row_parts` equal slices of the period's total.  Every row belongs
-        // to exactly one part; the parts' winners meet under the reference's total order like the tiles' (phase 4).
-        int ka = k_lo, kb = k_hi;
-        if constexpr (ROLE == kRoleSearch) {
-            if (row_parts > 1 && n_rows > 0) {
-                const double c0 = ap->row_cost[k_lo], c1 = ap->row_cost[k_hi];
-                const double lo_t = c0 + (c1 - c0) * ((double)item_part / (double)row_parts);
-                const double hi_t = c0 + (c1 - c0) * ((double)(item_part + 1) / (double)row_parts);
-                // row k belongs to the part whose slice holds the MIDDLE of its cost interval
-                ka = k_hi; kb = k_lo;
-#pragma unroll 1
-                for (int k = k_lo; k < k_hi; ++k) {
-                    const double mid = 0.5 * (ap->row_cost[k] + ap->row_cost[k + 1]);
-                    const bool mine = (mid >= lo_t || item_part == 0) && (mid < hi_t || item_part == row_parts - 1);
-                    if (mine) { ka = k < ka ? k : ka; kb = k + 1 > kb ? k + 1 : kb; }
-                }
-                if (ka >= kb) { ka = k_lo; kb = k_lo; }   // (an empty share: nothing to walk)
-                ka = __builtin_amdgcn_readfirstlane(ka); kb = __builtin_amdgcn_readfirstlane(kb);
-            }
-        }
-        const int kx_a = k_x < ka ? ka : (k_x > kb ? kb : k_x);   // dense rows of the share: [ka, kx_a), strided: [kx_a, kb)
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;  // published by the cumsum's barriers
         if (tid == 0) s_work[3] = 0;   // ticket counter of the strided rows (phase 3a), published the same way
         if constexpr (BAND) { if (tid == 0 && !resolve_band) s_work[4] = 0; }   // the noted band windows of this light curve's attempt
@@ -604,8 +576,8 @@
         // (the mean is monotone in the window sum, so min() decides exactly).
         const bool exact_u = __builtin_amdgcn_readfirstlane((int)exact_mode) != 0;
         const double thr_hi = rule.dmin + rule.eps, thr_lo = rule.dmin - rule.eps;
-        if (kx_a > ka) {
-            const int units0 = widths_c[ka].n_chunks;  // the shortest width has the most positions
+        if (k_x > k_lo) {
+            const int units0 = widths_c[k_lo].n_chunks;  // the shortest width has the most positions
             const int unit_lo = p_lo / kR;               // tile bounds are multiples of kR * 64
             const int unit_hi = p_hi / kR < units0 ? p_hi / kR : units0;
             const int n_dense = k_x - k_lo;
@@ -628,13 +600,13 @@
 #define TLS_ROW_BATCH 2
 #endif
                 constexpr int kRowBatch = TLS_ROW_BATCH;
-                for (int k = ka; k < kx_a; k += kRowBatch) {
+                for (int k = k_lo; k < k_x; k += kRowBatch) {
                     int dv[kRowBatch];
                     double inv[kRowBatch], dC[kRowBatch];
                     double c_hi[kRowBatch][kR];
 #pragma unroll
                     for (int j = 0; j < kRowBatch; ++j) {
-                        const int kk = k + j < kx_a ? k + j : kx_a - 1;  // the tail repeats the last row
+                        const int kk = k + j < k_x ? k + j : k_x - 1;  // the tail repeats the last row
                         dv[j] = widths_c[kk].width;
                         inv[j] = widths_c[kk].inv_d;
                         const int hi0 = min(u0 + dv[j], M + 1);  // past the grid: sentinels
@@ -651,7 +623,7 @@
                     }
 #pragma unroll
                     for (int j = 0; j < kRowBatch; ++j) {
-                        if (k + j < kx_a) {
+                        if (k + j < k_x) {
                             // (a lane past the row's units reads sentinels or foreign cells: it is masked below and
                             // must not raise `undecided`)
                             // the row's live lanes as a wave-uniform mask, straight from the compare
@@ -725,10 +697,10 @@
         for (;;) {
             int ticket = 0;
             if (lane == 0) ticket = atomicAdd(&s_work[3], 1);
-            const int k = kx_a + __builtin_amdgcn_readfirstlane(ticket);
-            if (k >= kb) break;
+            const int k = (k_x > k_lo ? k_x : k_lo) + __builtin_amdgcn_readfirstlane(ticket);
+            if (k >= k_hi) break;
 #else
-        for (int k = kx_a + wave; k < kb; k += nw) {
+        for (int k = (k_x > k_lo ? k_x : k_lo) + wave; k < k_hi; k += nw) {
 #endif
             const int d = widths_c[k].width, xth = widths_c[k].xth, n_pos = widths_c[k].n_pos;
             const int n_units = widths_c[k].n_chunks;
@@ -1566,7 +1538,7 @@
                 // of them (the comparison is the reference's total order on (value, width, T0): any order of arrival
                 // gives the same cell).  Agent-scope atomics: the tiles of a period run on different XCDs.
                 typedef unsigned long long u64;
-                const unsigned int tiles_p = ap->tile_prefix[work + 1] - ap->tile_prefix[work];   // (tiles x row parts)
+                const unsigned int tiles_p = ap->tile_prefix[work + 1] - ap->tile_prefix[work];
                 if (tiles_p > 1u) {
                     u64* mine = reinterpret_cast<u64*>(ap->partials) + 3LL * item;
                     __hip_atomic_store(mine + 0, (u64)__double_as_longlong(g.stat), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1578,7 +1550,7 @@
                     reset_ready = write_out;
                     if (write_out) {
                         __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next batch
-                        const u64* first = reinterpret_cast<const u64*>(ap->partials) + 3LL * (long long)item_first;
+                        const u64* first = reinterpret_cast<const u64*>(ap->partials) + 3LL * ((long long)item - item_tile);
                         for (unsigned int j = 0; j < tiles_p; ++j) {
                             Best o;
                             o.stat = __longlong_as_double((long long)__hip_atomic_load(first + 3 * j + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));

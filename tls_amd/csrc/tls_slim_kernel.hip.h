@@ -829,7 +829,7 @@ tls_slim_kernel(const SearchArgs) {
                 if (lane == 0) {
                     bool und_none = false;
                     // (valued like every other cell of the period: on the plain scan's window sum)
-                    consider<UNIFORM_W, false, true>(lead, 0.0, dX_noted, i, inv_d, dd, rule, overshoot, sum_q2, Bs, k, n_eval, und_none, widths_c, X);
+                    consider<UNIFORM_W, true, true>(lead, 0.0, dX_noted, i, inv_d, dd, rule, overshoot, sum_q2, Bs, k, n_eval, und_none, widths_c, X);
                     if constexpr (COUNTING) n_steps += (unsigned long long)L;
                 }
             }
@@ -849,6 +849,10 @@ tls_slim_kernel(const SearchArgs) {
                 if (n_band <= kBandCap) {
                     resolve_band = true;
                     kept_lead = lead; kept_eval = n_eval; kept_steps = n_steps; kept_issued = n_issued;
+                    // (the lead's window sum as the PLAIN scan has it, taken now: the resolution pass overwrites X with the exact
+                    // prefix sum, and every cell of a period is valued on the same X -- ADVICE r05: read again there, the
+                    // incumbent and the winner of a resolved period were valued on the other prefix sum, 1e-13 off)
+                    kept_lead.dX = lead.stat < INFINITY ? X[lead.i + widths_c[lead.k].width] - X[lead.i] : 0.0;
                 }
                 if (ap->phase_cycles && tid == 0) atomicAdd(&ap->phase_cycles[37], 1ull);
                 if (ap->n_curves > 1) { curve_exact = true; --curve; continue; }
@@ -865,7 +869,8 @@ tls_slim_kernel(const SearchArgs) {
         pc.mark(21);
 
         // ---- phase 4: argmin over the workgroup (core.py:70-74, 183-188) ------------------------------
-        Best best = settle_best<UNIFORM_W, false>(lead, widths_c, X);
+        // (a resolved period: X now holds the exact prefix sum; its leads carry the plain scan's window sums)
+        Best best = resolving ? settle_best<UNIFORM_W, true>(lead, widths_c, X) : settle_best<UNIFORM_W, false>(lead, widths_c, X);
 #pragma unroll
         for (int delta = kWave / 2; delta > 0; delta >>= 1) {
             Best o = shfl_down_best(best, delta);

@@ -12,7 +12,7 @@ ctx = _lib.Context(0)
 t, f, kw = synthetic.config(name)
 inp = synthetic.search_inputs(t, f, **kw)
 periods = inp["periods"][lo:hi]
-for label, sw in (("one-wg", dict(split=0)), ("split p1", dict(split=1, parts=1)), ("split p2", dict(split=1, parts=2)), ("split p3", dict(split=1, parts=3))):
+for label, sw in (("one-wg", dict(split=0)), ("split", dict(split=1))):
     ctx.set_options(**sw)
     ctx.prepare(inp["t"], inp["y"], inp["dy"], periods, inp["table"], inp["params"])
     ctx.execute()

@@ -31,8 +31,7 @@ if os.environ.get("PARTITION") == "sum":
     bounds = shard.partition_by_cost(job.times, n_blocks)
 cyclic = os.environ.get("PARTITION") == "cyclic"
 print("blocks", "cyclic" if cyclic else list(numpy.diff(bounds)))
-for label, sw in (("one-wg", dict(split=0)), ("split p1", dict(split=1, parts=1)), ("split p2", dict(split=1, parts=2)),
-                  ("auto", dict(split=None, parts=None))):
+for label, sw in (("one-wg", dict(split=0)), ("split", dict(split=1)), ("auto", dict(split=None))):
     ctx.set_options(**sw)
     ms, bad = [], 0
     for r in range(n_blocks):
