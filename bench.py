@@ -17,18 +17,24 @@ resident in HBM: the full period x duration x T0 grid search of BASELINE.json's 
     RCCL all-gather at the end of the timed region, so that every rank holds the whole batch ->
     per-GPU work is fixed, "scaling": "weak".
   * N > 1 additionally times the PERIOD-SHARD layout north_star describes (BASELINE config 4): ONE
-    light curve per step, its period grid block-partitioned over the GPUs by cumulative cell cost,
-    one RCCL all-gather per light curve -> strong scaling; reported under "shard" for config 2 and
-    for the TESS 2-min configuration, with max/mean trial cells per rank.
+    light curve per step, its period grid dealt out over the GPUs (cyclic shares: rank r searches
+    periods[r::N], tls_amd/shard.py), one RCCL all-gather per light curve -> strong scaling; reported
+    under "shard" for config 2 and for the TESS 2-min configuration, with every rank's kernel time.
 value = trial cells of the whole job / wall time of the K timed steps (barrier + device sync on
-both sides, max over ranks).  `roofline` prices the search kernel against HBM with the
-algorithmic bytes of SURVEY.md 8(d) (24*N + 24 B per period) and its HIP-event duration, and
-also reports the fp64 vector rate three ways (reference flops, issued FMAs, useful FMAs) -- the
-LDS-resident path is compute/LDS bound, not HBM bound.  At N = 1 the line also carries,
-measured outside the timed region: the one-shot call with host buffers (planning + H2D + kernel +
-D2H), the Kepler 4-yr and TESS 27-d configurations (kernel time + their own HBM
-roofline: these two ARE HBM-staged), the 1024-curve survey throughput including transfers, the
-500 ppm variant and the wall clock of the whole power() call.
+both sides, max over ranks), inputs resident in HBM when the timed region starts -- the bench contract
+of this build ("if the boundary hands over host buffers, note the PCIe-inclusive rate ... it is never
+`value`").  The search call FROM HOST BUFFERS (H2D + kernel + D2H through tls_search,
+plan reused / planned from scratch) is printed beside it as `value_one_shot` / `value_one_shot_cold`.
+`roofline` prices the dominant kernel of the headline configuration against the ceiling that binds it:
+the LDS-resident kernel against the fp64 VECTOR rate (`bound: "fp64"`: one FMA per template tap of an
+evaluated cell over its HIP-event duration; 78.6 TF peak) -- its light curve is L2-resident and the
+algorithmic bytes of SURVEY.md 8(d) (24*N + 24 B per period) are nominal for it: they are reported
+under `roofline.hbm` with the counter traffic --; the HBM-staged configurations (TESS 27 d, Kepler
+4 yr: `tess_27d.roofline`, `kepler_4yr.roofline`) against HBM with those algorithmic bytes, the
+counter traffic and the fp64 issue rate beside it.  At N = 1 the line also carries, measured outside
+the timed region: those two configurations, the 1024-curve survey throughput including transfers (with
+the slowest and the median group of 32), the noisier variants, the one-GPU projection of the 8-way
+shard (`shard_balance`) and the wall clock of the whole power() call.
 `cpu_baseline` is the C oracle (a port of core.py, OpenMP over periods) timed on this box's
 host cores on a bounded sample of the same workload.
 """
@@ -463,16 +469,23 @@ def survey_1024(ctx, n_curves):
     t0 = time.perf_counter()
     periods, chi2, row, depth = survey.search_batch(t, fluxes, context=ctx, **kw)
     wall = time.perf_counter() - t0
+    groups_search = ctx.batch_group_ms()
     best = numpy.argmin(chi2, axis=1)
     # survey-mode power(): search + SDE spectra + final T0 fit on the device, 80 bytes back per light curve
     survey.power_batch(t, fluxes[:64], context=ctx, **kw)
     t0 = time.perf_counter()
     summary, _ = survey.power_batch(t, fluxes, context=ctx, **kw)
     wall_power = time.perf_counter() - t0
+    groups_power = ctx.batch_group_ms()
+
+    def spread(g):   # (one stalled group of 32 -- r05's profile run held one call of 25.8 s among calls of 0.9 s -- shows as max >> median)
+        return {"groups": int(len(g)), "median_ms": float(numpy.median(g)) if len(g) else None, "max_ms": float(numpy.max(g)) if len(g) else None,
+                "argmax": int(numpy.argmax(g)) if len(g) else None}
     return {"curves": n_curves, "wall_s": wall, "curves_per_s": n_curves / wall,
             "ms_per_curve": 1e3 * wall / n_curves, "periods": len(periods),
             "argmin_seed0": int(best[0]), "note": "tls_search_batch, host buffers in and out",
             "curves_per_s_power": n_curves / wall_power, "power_wall_s": wall_power,
+            "group_ms_search": spread(groups_search), "group_ms_power": spread(groups_power),
             "power_note": "tls_power_batch: per light curve SDE, SDE_raw, period, T0, depth, duration row, chi2_min "
                           "(search + spectra + final T0 fit on the device)",
             "seed0": {k: float(summary[0][k]) for k in ("SDE", "period", "T0", "depth", "duration")},

@@ -175,6 +175,10 @@ int tls_debug_check_counts(tls_ctx *ctx, uint64_t *counts, int n);
  * the GPU may have left there.  A search after it must return the bits of a search before it
  * (tests/test_gpu_parity.py: no kernel reads memory it has not written). */
 int tls_debug_poison_lds(tls_ctx *ctx, uint32_t word);
+/* developer instrumentation: host wall time (ms) of every group of 32 light curves of the context's last tls_power_batch /
+ * tls_search_batch call (a stall in one group -- a transfer, a wait, a T0-fit launch -- shows here; bench.py prints the
+ * largest and the median).  Returns the number of groups; out may be NULL. */
+int tls_debug_batch_group_ms(const tls_ctx *ctx, double *out, int64_t capacity);
 /* block until the stream is idle */
 int tls_synchronize(tls_ctx *ctx);
 /* fetch: copy results (and counters, may be NULL) back; synchronises. */

@@ -31,7 +31,7 @@
  * The T0 fit is pinned by tests/golden/t0fit_*.npz: the per-epoch residuals the unmodified
  * reference's final_T0_fit computes, captured by tools/gen_golden_t0fit.py.
  *
- * Build: see oracle/Makefile  (gcc -O2 -fopenmp -shared -fPIC).
+ * Build: see oracle/Makefile  (gcc -O3 -ffp-contract=off -fopenmp -shared -fPIC; `make fast`: -O3 -ffast-math, timing only).
  */
 #include <math.h>
 #include <stdint.h>

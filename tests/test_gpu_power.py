@@ -256,6 +256,26 @@ def test_power_with_a_devices_list_returns_the_one_device_results():
             numpy.testing.assert_array_equal(numpy.asarray(other[k], dtype=float), numpy.asarray(plain[k], dtype=float), err_msg=k)
 
 
+def test_survey_of_1024_light_curves_has_no_stalled_group():
+    """one profile run of round 5 held a tls_power_batch call of 25.8 s for 1024 light curves among calls
+    of 0.9 s.  The library now times every group of 32 (tls_debug_batch_group_ms): the whole call within 3 s and no group
+    beyond 0.5 s (a group takes ~28 ms) -- a stall of that kind fails here with the group it happened in."""
+    import time
+    from tls_amd import survey, search as tsearch
+    t, f0, kw = synthetic.config("k2_90d", seed=0)
+    fluxes = numpy.stack([synthetic.config("k2_90d", seed=s)[1] for s in range(1024)])
+    ctx = tsearch.default_context(None)
+    survey.power_batch(t, fluxes[:64], context=ctx, **kw)      # plan, pinned staging, device buffers
+    t0 = time.perf_counter()
+    summary, _ = survey.power_batch(t, fluxes, context=ctx, **kw)
+    wall = time.perf_counter() - t0
+    groups = ctx.batch_group_ms()
+    assert len(groups) == 32 and len(summary) == 1024
+    assert wall < 3.0, (wall, groups.max(), int(groups.argmax()))
+    assert groups.max() < 500.0, (groups.max(), int(groups.argmax()), float(numpy.median(groups)))
+    assert int(numpy.sum(numpy.abs(summary["period"] - 10.123) < 0.05)) == 1024
+
+
 def test_auto_devices_on_a_one_gpu_box_is_the_one_device_search():
     """power()'s default devices="auto" (reference: use_threads = cpu_count(), validate.py:81): with one visible GPU it is the
     plain one-device call -- same context, same bits -- and an explicit device= or devices=[0] changes nothing."""

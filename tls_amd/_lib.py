@@ -23,7 +23,7 @@ ABI_VERSION = 5   # include/tls_amd.h TLS_AMD_ABI_VERSION: checked against the l
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version", "tls_abi_version",
     "tls_device_name", "tls_get_options", "tls_set_options", "tls_debug_set_switch", "tls_debug_get_switches", "tls_search", "tls_search_batch", "tls_power_batch", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_last_kernel", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_poison_lds", "tls_debug_period_cycles",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_last_kernel", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_poison_lds", "tls_debug_period_cycles", "tls_debug_batch_group_ms",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_info", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
     "tls_comm_barrier", "tls_comm_max",
@@ -169,6 +169,8 @@ def load():
     lib.tls_debug_prefix.argtypes = [vp, _c_double_p, i64, ctypes.POINTER(ctypes.c_int64)]
     lib.tls_debug_period_cycles.restype = ci
     lib.tls_debug_period_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), i64]
+    lib.tls_debug_batch_group_ms.restype = ci
+    lib.tls_debug_batch_group_ms.argtypes = [vp, _c_double_p, i64]
     lib.tls_debug_cumsum.restype = ci
     lib.tls_debug_cumsum.argtypes = [vp, _c_double_p, i64, _c_double_p, ci]
     lib.tls_grid_cells.restype = ci
@@ -469,6 +471,14 @@ class Context(object):
         out = numpy.zeros(self._n_periods, dtype=numpy.uint64)
         self._check(self._lib.tls_debug_period_cycles(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                                                       len(out)))
+        return out
+
+    def batch_group_ms(self):
+        """Host wall time (ms) of every group of 32 light curves of the last power_batch / search_batch call."""
+        n = self._lib.tls_debug_batch_group_ms(self._h, None, 0)
+        out = numpy.zeros(max(n, 0), dtype=numpy.float64)
+        if n > 0:
+            self._lib.tls_debug_batch_group_ms(self._h, _dp(out), n)
         return out
 
     def check_counts(self):

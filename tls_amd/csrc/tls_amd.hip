@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -202,6 +203,7 @@ struct tls_ctx {
     PlanKey key;
     PlanLayout layout;
     int64_t plan_reuses = 0;   // tls_prepare calls answered from the held plan
+    std::vector<double> batch_group_ms;   // wall time of every group of 32 light curves of the last tls_power_batch / tls_search_batch (tls_debug_batch_group_ms)
     DevBuf<double> d_scratch, d_pack, d_gather, d_scalar, d_stage;
     DevBuf<unsigned long long> d_phase, d_check;
     DevBuf<unsigned int> d_queue, d_squeue, d_lists, d_perm, d_pqueues;   // d_pqueues: tls_power_batch's T0-fit queues   // d_squeue: the search kernel's self-rewinding queue
@@ -1801,6 +1803,13 @@ int tls_debug_poison_lds(tls_ctx* ctx, uint32_t word) {
     return TLS_OK;
 }
 
+int tls_debug_batch_group_ms(const tls_ctx* ctx, double* out, int64_t capacity) {
+    if (!ctx) return TLS_E_ARG;
+    const int64_t n = (int64_t)ctx->batch_group_ms.size();
+    if (out) for (int64_t i = 0; i < std::min(n, capacity); ++i) out[i] = ctx->batch_group_ms[(size_t)i];
+    return (int)std::min<int64_t>(n, 0x7fffffff);
+}
+
 int tls_debug_check_counts(tls_ctx* ctx, uint64_t* counts, int n) {
     if (!ctx || !counts || n < 1) return fail(ctx, TLS_E_ARG, "bad argument");
     for (int i = 0; i < n; ++i) counts[i] = 0;
@@ -1983,11 +1992,13 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
     // (every HIP failure inside the pipeline leaves through `run`'s return value: the cleanup below then waits for
     // both streams -- asynchronous copies may still target the pinned slots and the caller's arrays -- and clears
     // the launch overrides)
+    ctx->batch_group_ms.assign((size_t)n_groups, 0.0);
     auto run = [&]() -> int {
     int rc = TLS_OK;
     for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
         auto& sl = ctx->slot[g & 1];
         const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
+        const auto group_t0 = std::chrono::steady_clock::now();   // (pipelined: a group's time is its host loop pass, waits for older groups included)
         if (g >= 2 && (rc = drain(g - 2))) break;           // the slot's buffers are free again
         // host side of the group: flux into the pinned staging area, weights, S0 (core.py:127)
         double* h_y = sl.h_in;
@@ -2033,6 +2044,7 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
         TLS_HIP(ctx, hipMemcpyAsync(sl.h_out + (size_t)group * np, sl.d_row.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
         TLS_HIP(ctx, hipMemcpyAsync(sl.h_out + 2 * (size_t)group * np, sl.d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
         TLS_HIP(ctx, hipEventRecord(sl.ev_out, ctx->copy_stream));
+        ctx->batch_group_ms[(size_t)g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - group_t0).count();
     }
     if (rc == TLS_OK)
         for (int64_t g = std::max<int64_t>(0, n_groups - 2); g < n_groups && rc == TLS_OK; ++g) rc = drain(g);
@@ -2141,8 +2153,10 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
     std::vector<int> n_epochs_h((size_t)group);
     rc = TLS_OK;
     const int64_t n_groups = (n_curves + group - 1) / group;
+    ctx->batch_group_ms.assign((size_t)n_groups, 0.0);
     for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
         const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
+        const auto group_t0 = std::chrono::steady_clock::now();
         // ---- flux of the group into the device, search (tls_search_batch's launch: fold + sort shared by the group)
         double* h_y = sl.h_in;
         double* h_w = sl.h_in + (size_t)group * nn;
@@ -2286,6 +2300,7 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
             std::memcpy(out_depth + c0 * n_periods, h_arrays + 2 * (size_t)group * np, (size_t)gc * np * 8);
         }
         if (out_power) std::memcpy(out_power + c0 * n_periods, h_power, (size_t)gc * np * 8);
+        ctx->batch_group_ms[(size_t)g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - group_t0).count();
     }
     ctx->executed = false;   // the search ran on the batch slot, see tls_search_batch
     return rc;

@@ -11,6 +11,7 @@ if [ -f gpurun_out/round_$TAG/pytest_debug.txt ]; then cp gpurun_out/round_$TAG/
 if [ -f gpurun_out/profile_post_$TAG.log ]; then grep -v "rocprofv3\]\|output_stream\|simple_timer" gpurun_out/profile_post_$TAG.log > profiles/${TAG}_post_search_kernels.txt; fi
 cp gpurun_out/prof_tess_27d_$TAG/trace/k_kernel_stats.csv profiles/${TAG}_tess_kernel_stats.csv
 cp gpurun_out/prof_kepler_${TAG}_default/trace/k_kernel_stats.csv profiles/${TAG}_kepler_sample_kernel_stats.csv
+if [ -f gpurun_out/prof_kepler_${TAG}_full/trace/k_kernel_stats.csv ]; then cp gpurun_out/prof_kepler_${TAG}_full/trace/k_kernel_stats.csv profiles/${TAG}_kepler_full_grid_kernel_stats.csv; fi
 python - <<PY
 import csv, glob, collections, json
 commit, tag = "$COMMIT", "$TAG"
@@ -19,14 +20,14 @@ for d in ("p1", "p2", "p3", "p4"):
     for f in glob.glob("gpurun_out/prof_%sb/%s/*counter_collection.csv" % (tag, d)):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "tls_search_kernel<true, true, false, unsigned short, false, false, false>" in r["Kernel_Name"] or "tls_slim_kernel<false>" in r["Kernel_Name"]:
+            if "tls_search_kernel<true, true, unsigned short, false, false, false>" in r["Kernel_Name"] or "tls_slim_kernel<false>" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in sorted(agg.items()):
             rows.append((k, sum(v) / len(v), len(v)))
 with open("profiles/%s_k2_90d_pmc_issue_mix.csv" % tag, "w") as fh:
     fh.write("# rocprofv3 --pmc passes (four separate runs, kernel-trace only) of bench.py --steps 10 --warmup 2 --no-cpu-baseline "
              "--no-extras (tools/profile_pmc2.sh): mean per launch of the plain search kernel "
-             "tls_slim_kernel<false> (the four-slot kernel config 2 takes; tls_search_kernel<true,true,false,unsigned short,false,false,false> before it), commit %s\n" % commit)
+             "tls_slim_kernel<false> (the four-slot kernel config 2 takes), commit %s\n" % commit)
     fh.write("counter,mean_per_launch,launches\n")
     for k, m, n in rows:
         fh.write("%s,%.6g,%d\n" % (k, m, n))

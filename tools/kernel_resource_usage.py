@@ -25,11 +25,10 @@ for line in err.splitlines():
         cur[k.strip()] = v.strip()
 demangled = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
 print("# %s" % " ".join(cmd[:-2] + ["<src>"]))
-print("# tls_search_kernel<RESIDENT, UNIFORM_W, STAGE_C, IdxT, WITH_PRUNING, COUNTING>: one workgroup per period, fold to argmin")
-print("# tls_fold_search_kernel<UNIFORM_W, STAGE_C, WITH_PRUNING, COUNTING>: HBM-slab series, fold role then search role over")
-print("#   (period, tile) items in one launch; its scratch is the fold role's (the sort3 path, the general fallback sort and the")
-print("#   inline exact prefix sum) -- built as kernels of their own (commit 0e15e2d) the search role needed 0-44 B/lane")
-print("#   (0 VGPR spills for uniform weights) and the fold role 436-456 B/lane")
+print("# tls_search_kernel<RESIDENT, UNIFORM_W, IdxT, WITH_PRUNING, COUNTING, SCREEN>: one workgroup per period, fold to argmin")
+print("# tls_fold_search_kernel<UNIFORM_W, COUNTING>: HBM-slab series, fold role then search role over (period, tile) items in one")
+print("#   launch; its scratch is the fold role's (the general fallback sort, the inline exact prefix sum) and the search role's")
+print("#   band bookkeeping; the hot dot-product loops of every slab kernel are free of scratch accesses (checked in the ISA)")
 print("%5s %5s %6s %6s %8s %5s %7s  %s" % ("VGPR", "SGPR", "vspill", "sspill", "scratchB", "occ", "LDS", "function"))
 for r, d in zip(rows, demangled):
     d = d.replace("tlsdev::", "").replace("(tlsdev::SearchArgs)", "").replace("unsigned short", "u16").replace("unsigned int", "u32")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): HBM traffic of the Kepler-size configuration (BASELINE config 3),
-# a spread sample of its periods, for the default slab sort and for the fused one (TLS_SORT3=1).
-# Separate --pmc passes, kernel trace for the duration.  Writes gpurun_out/prof_kepler_<tag>.json.
+# a spread sample of its periods (every 64th): separate --pmc passes, kernel trace for the duration -> gpurun_out/prof_kepler_<tag>.json;
+# and the rocprofv3 kernel-stats record of the FULL grid (182 388 periods, three launches) -> gpurun_out/prof_kepler_<tag>_full/.
 set -u
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -9,10 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/tools/gpu_kepler_time.py 64"
 echo "[" > $ROOT/gpurun_out/prof_kepler_$TAG.json
 SEP=""
-for VAR in default sort3; do
+for VAR in default; do
   OUT=$ROOT/gpurun_out/prof_kepler_${TAG}_$VAR
   mkdir -p "$OUT"
-  if [ $VAR = sort3 ]; then export TLS_SORT3=1; else unset TLS_SORT3; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- $CMD > "$OUT/trace.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o k -- $CMD > "$OUT/fetch.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o k -- $CMD > "$OUT/write.log" 2>&1
@@ -37,3 +36,7 @@ PY
 done
 echo "]" >> $ROOT/gpurun_out/prof_kepler_$TAG.json
 cat $ROOT/gpurun_out/prof_kepler_$TAG.json
+FULL=$ROOT/gpurun_out/prof_kepler_${TAG}_full
+mkdir -p "$FULL"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$FULL/trace" -o k -- python $ROOT/tools/gpu_config_time.py kepler_4yr 1 2 > "$FULL/trace.log" 2>&1
+tail -1 "$FULL/trace.log"; grep -h "tls_search" "$FULL"/trace/*kernel_stats.csv | cut -c1-200
