@@ -5,7 +5,7 @@ set -u
 CFG=${1:-tess_27d}; STRIDE=${2:-1}; TAG=${3:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/tools/gpu_config_time.py $CFG $STRIDE 3"
+CMD="python $ROOT/tools/gpu_config_time.py $CFG $STRIDE ${REPEATS:-40}"   # (many launches: the first few find the clocks down)
 OUT=$ROOT/gpurun_out/prof_${CFG}_$TAG
 mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- $CMD > "$OUT/trace.log" 2>&1
