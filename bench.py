@@ -153,10 +153,56 @@ def kernel_sources_digest():
     return h.hexdigest()[:16]
 
 
+_LIVE_TRAFFIC = {}   # config -> (bytes per launch, source) measured by this run (measure_traffic_live)
+
+
+def measure_traffic_live(config, stride=1, timeout_s=120):
+    """HBM bytes per launch of the search kernel measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate
+    passes, kernel trace only -- MI355X_MICROARCH.md's HBM recipe) of a child process that prepares the configuration and
+    launches its search a few times (tools/gpu_config_time.py); the read side doubled (gfx950 FETCH_SIZE counts 64 B per 128 B
+    request), KiB -> bytes.  None when rocprofv3 is not there, the run is itself being profiled, or a pass fails or times
+    out: recorded_traffic() then falls back to the committed record."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ) or \
+            "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None   # (this run is itself under a profiler)
+    child = [sys.executable, os.path.join(ROOT, "tools", "gpu_config_time.py"), config, str(stride), "6"]
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="tls_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "k", "--"] + child, cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            values = []
+            for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if r.get("Counter_Name") == counter and ("tls_search" in r.get("Kernel_Name", "") or "tls_slim" in r.get("Kernel_Name", "")
+                                                              or "tls_fold_search" in r.get("Kernel_Name", "")):
+                        values.append(float(r["Counter_Value"]))
+            if not values:
+                return None
+            got[counter] = (sum(values) / len(values), len(values))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    kib = 2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]
+    return kib * 1024.0, ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, %d / %d launches) of "
+                          "tools/gpu_config_time.py %s %d" % (got["FETCH_SIZE"][1], got["WRITE_SIZE"][1], config, stride))
+
+
 def recorded_traffic(config, n_periods):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json:
-    one record per configuration, each labelled with the commit it was measured at).  bench.py
-    cannot run the counter passes itself (they need their own rocprofv3 runs)."""
+    """HBM bytes per launch: measured by this run where measure_traffic_live has been called for the configuration (N = 1,
+    extras on), else from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json: one record per configuration, each
+    labelled with the commit and the kernel sources it was measured at)."""
+    if config in _LIVE_TRAFFIC:
+        b, source, measured_periods = _LIVE_TRAFFIC[config]
+        scale = n_periods / float(measured_periods)
+        return b * scale, source + ("" if scale == 1.0 else ", %d periods scaled to this launch's %d" % (measured_periods, n_periods))
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if not os.path.exists(path):
         return None, "no profiles/hbm_traffic.json"
@@ -516,6 +562,9 @@ def main():
                     help="skip the untimed extras (other configurations, 500 ppm variant, power() wall clock, "
                          "counted pass) so that a profiler sees only the timed workload's launches")
     ap.add_argument("--survey-curves", type=int, default=1024)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the rocprofv3 --pmc passes that measure roofline.traffic in this run (~10 s per configuration); "
+                         "the committed record of profiles/hbm_traffic.json is reported instead")
     ap.add_argument("--allow-host-fallback", action="store_true",
                     help="N > 1 with one device per rank: time over the host channel when RCCL does not come up "
                          "(default: fail with a non-zero status)")
@@ -621,6 +670,19 @@ def main():
                 model.power(verbose=False, show_progress_bar=False, context=ctx, **kw)
                 best = min(best, time.perf_counter() - t1)
             power_wall_ms = 1e3 * best
+
+        # roofline.traffic measured in THIS run (N = 1): two rocprofv3 --pmc passes per configuration in a child process, while
+        # this process idles (its context stays alive: the counters are per process)
+        if extras and not args.no_live_traffic and args.sigma is None:
+            for name, stride in ((args.config, 1),) + ((("tess_27d", 1), ("kepler_4yr", 64)) if args.config == "k2_90d" else ()):
+                try:
+                    live = measure_traffic_live(name, stride)
+                    if live is not None:
+                        t_l, f_l, kw_l = synthetic.config(name, seed=0)
+                        n_per_l = len(inp["periods"]) if name == args.config else len(synthetic.search_inputs(t_l, f_l, **kw_l)["periods"])
+                        _LIVE_TRAFFIC[name] = (live[0], live[1], len(range(0, n_per_l, stride)))
+                except Exception:
+                    pass
 
         other = {}
         if extras and args.config == "k2_90d":
