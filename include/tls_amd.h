@@ -238,7 +238,11 @@ int tls_power_batch(tls_ctx *ctx, const double *t, const double *y, const double
                     const tls_template *tmpl, const tls_params *params, int64_t median_kernel,
                     tls_power_summary *out_summary,
                     double *out_chi2 /* [n_curves][n_periods] or NULL */, int64_t *out_row /* with out_chi2 */,
-                    double *out_depth /* with out_chi2 */, double *out_power /* [n_curves][n_periods] or NULL */);
+                    double *out_depth /* with out_chi2 */, double *out_power /* [n_curves][n_periods] or NULL */,
+                    double *out_SR /* [n_curves][n_periods] or NULL */, double *out_power_raw /* likewise */);
+/* (ABI 5: out_SR / out_power_raw.  With n_curves = 1 and all arrays this is the device part of the drop-in power() call:
+ * search, spectra, pick, the final T0 fit's trial epochs and scaled template formed on the device, all fits of a group in one
+ * launch, ONE wait per group of 32 light curves.) */
 
 /* ---- host-only planning (no GPU needed) ------------------------------------------ */
 /* Trial cells (duration x T0 positions) each period will enumerate: the data-independent

@@ -132,7 +132,8 @@ def load():
                                      tp, pp, _c_double_p, _c_int64_p, _c_double_p]
     lib.tls_power_batch.restype = ci
     lib.tls_power_batch.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, i64, _c_double_p, i64,
-                                    tp, pp, i64, ctypes.c_void_p, _c_double_p, _c_int64_p, _c_double_p, _c_double_p]
+                                    tp, pp, i64, ctypes.c_void_p, _c_double_p, _c_int64_p, _c_double_p, _c_double_p,
+                                    _c_double_p, _c_double_p]
     lib.tls_prepare.restype = ci
     lib.tls_prepare.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, i64, _c_double_p, i64,
                                 tp, pp]
@@ -338,10 +339,11 @@ class Context(object):
         return chi2, row, depth
 
     def power_batch(self, t, y_batch, dy_batch, periods, table, params, median_kernel, with_arrays=False,
-                    with_power=False):
+                    with_power=False, with_spectra=False):
         """Survey-mode power(): structured array (POWER_SUMMARY_DTYPE) with one record per light curve -- SDE,
         SDE_raw, chi2_min, period, T0, depth, the argmin/argmax indices, the template row -- from search,
-        spectra and final T0 fit on the device (tls_power_batch); optionally the per-period arrays."""
+        spectra and final T0 fit on the device (tls_power_batch); optionally the per-period arrays.
+        with_spectra: also SR and power_raw (returned as two more arrays behind `power`)."""
         t, periods = _f8(t), _f8(periods)
         y_batch = numpy.ascontiguousarray(y_batch, dtype=numpy.float64)
         dy_batch = numpy.ascontiguousarray(dy_batch, dtype=numpy.float64)
@@ -356,15 +358,22 @@ class Context(object):
             chi2 = numpy.empty((n_c, n_p), dtype=numpy.float64)
             row = numpy.empty((n_c, n_p), dtype=numpy.int64)
             depth = numpy.empty((n_c, n_p), dtype=numpy.float64)
+        SR = power_raw = None
         if with_power:
             power = numpy.empty((n_c, n_p), dtype=numpy.float64)
+        if with_spectra:
+            SR = numpy.empty((n_c, n_p), dtype=numpy.float64)
+            power_raw = numpy.empty((n_c, n_p), dtype=numpy.float64)
         self._invalidate_results()
         self._check(self._lib.tls_power_batch(
             self._h, _dp(t), _dp(y_batch), _dp(dy_batch), len(t), n_c, _dp(periods), n_p, ctypes.byref(tm),
             ctypes.byref(pr), int(median_kernel), summary.ctypes.data_as(ctypes.c_void_p),
             None if chi2 is None else _dp(chi2), None if row is None else _ip(row),
-            None if depth is None else _dp(depth), None if power is None else _dp(power)))
+            None if depth is None else _dp(depth), None if power is None else _dp(power),
+            None if SR is None else _dp(SR), None if power_raw is None else _dp(power_raw)))
         self._n_periods = n_p
+        if with_spectra:
+            return summary, chi2, row, depth, power, SR, power_raw
         return summary, chi2, row, depth, power
 
     def _invalidate_results(self):

@@ -47,6 +47,9 @@ class transitleastsquares(object):
         hit = _GRID_CACHE.get(key)
         if hit is None:
             hit = self._build_grids_uncached()
+            # the ascending period grid (results come back ordered like it, main.py:190-196) and the flattened template table
+            # ride in the cache entry: a survey calling power() per light curve forms them once, not per call
+            hit = hit + (numpy.sort(numpy.asarray(hit[0], dtype=numpy.float64)), TemplateTable(hit[2], hit[3]))
             if len(_GRID_CACHE) >= 8:
                 _GRID_CACHE.pop(next(iter(_GRID_CACHE)))
             _GRID_CACHE[key] = hit
@@ -78,7 +81,7 @@ class transitleastsquares(object):
         if self.verbose:
             print(C.BACKEND_BANNER)
 
-        periods, durations, lc_cache_overview, lc_arr = self._build_grids()
+        periods, durations, lc_cache_overview, lc_arr, test_statistic_periods, table = self._build_grids()
         if self.verbose:
             print("Searching " + str(len(self.y)) + " data points, " + str(len(periods))
                   + " periods from " + str(round(numpy.min(periods), 3)) + " to "
@@ -92,26 +95,44 @@ class transitleastsquares(object):
 
         # one batched device call replaces the pool of main.py:140-185; results come
         # back ordered like the ascending period grid (main.py:190-196)
-        test_statistic_periods = numpy.sort(numpy.asarray(periods, dtype=numpy.float64))
-        table = TemplateTable(lc_cache_overview, lc_arr)
+        # (test_statistic_periods, table: from the grid cache entry)
         # devices: the period grid sharded over several GPUs of this process (tls_amd.search.DeviceGroup: one context and
         # one host thread per device, blocks by modelled time, one RCCL all-gather) -- the counterpart of the reference's
         # use_threads pool over periods (main.py:140-163).  Default "auto", like use_threads = cpu_count()
         # (validate.py:81): every visible GPU when the modelled one-GPU time exceeds the overhead of sharding, one GPU
         # otherwise (search.auto_devices); a list names the GPUs; device= / context= keep the search on one.
-        # (resolved inside search_periods, the one function that knows the HIP library; `used` brings back the context the
-        # rest of power() -- spectra, final T0 fit -- runs on: the single device's, or the group's first)
-        used = {}
-        chi2, test_statistic_rows, test_statistic_depths = _search.search_periods(
-            self.t, self.y, self.dy, test_statistic_periods, table,
-            transit_depth_min=self.transit_depth_min,
-            R_star_min=self.R_star_min, R_star_max=self.R_star_max,
-            M_star_min=self.M_star_min, M_star_max=self.M_star_max,
-            T0_fit_margin=self.T0_fit_margin,
-            context=kwargs.get("context"), device=kwargs.get("device"), devices=kwargs.get("devices", "auto"),
-            verbose=self.verbose, used=used)
-        if used.get("context") is not None:
-            kwargs = dict(kwargs, context=used["context"], device=None)
+        params = dict(transit_depth_min=self.transit_depth_min, R_star_min=self.R_star_min, R_star_max=self.R_star_max,
+                      M_star_min=self.M_star_min, M_star_max=self.M_star_max, T0_fit_margin=self.T0_fit_margin)
+        # One GPU (the usual case): the whole device part of this call -- search, spectra, pick, final T0 fit -- is ONE
+        # submission with one wait at its end (search.fused_power -> tls_power_batch with one light curve).  Several GPUs:
+        # the search over the group, then spectra and T0 fit on its first device, as before.  (Tests that inject a CPU
+        # search replace search_periods: the fused chain is taken only while that is the product's function.)
+        fused = None
+        if getattr(_search.search_periods, "_tls_amd_product", False):
+            kind, what = _search.resolve_devices(kwargs.get("devices", "auto"), kwargs.get("device"), kwargs.get("context"))
+            if kind == "auto":
+                ids = _search.auto_devices(self.t, self.y, test_statistic_periods, table, params)
+                kind, what = ("list", ids) if ids else ("one", None)
+                if kind == "list":
+                    kwargs = dict(kwargs, devices=ids)
+            if kind == "one":
+                fused = _search.fused_power(self.t, self.y, self.dy, test_statistic_periods, table, params,
+                                            self.oversampling_factor, context=kwargs.get("context"), device=what)
+        if fused is not None:
+            ctx_used, summary, chi2, test_statistic_rows, test_statistic_depths, SR, power_raw, power = fused
+            kwargs = dict(kwargs, context=ctx_used, device=None)
+            if self.verbose:
+                print("GPU search on " + ctx_used.name + ": " + str(len(chi2)) + " periods")
+        else:
+            # (resolved inside search_periods, the one function that knows the HIP library; `used` brings back the context the
+            # rest of power() -- spectra, final T0 fit -- runs on: the single device's, or the group's first)
+            used = {}
+            chi2, test_statistic_rows, test_statistic_depths = _search.search_periods(
+                self.t, self.y, self.dy, test_statistic_periods, table,
+                context=kwargs.get("context"), device=kwargs.get("device"), devices=kwargs.get("devices", "auto"),
+                verbose=self.verbose, used=used, **params)
+            if used.get("context") is not None:
+                kwargs = dict(kwargs, context=used["context"], device=None)
 
         idx_best = numpy.argmin(chi2)
         best_row = test_statistic_rows[idx_best]
@@ -131,21 +152,30 @@ class transitleastsquares(object):
             return self._results_without_fit(test_statistic_periods, chi2, chi2red, chi2_min,
                                              chi2red_min)
 
-        SR, power_raw, power, SDE_raw, SDE = _search.spectra(chi2, self.oversampling_factor, resident=True,
-                                                             context=kwargs.get("context"), device=kwargs.get("device"))
+        if fused is not None:
+            SDE_raw, SDE = float(summary["SDE_raw"]), float(summary["SDE"])
+        else:
+            SR, power_raw, power, SDE_raw, SDE = _search.spectra(chi2, self.oversampling_factor, resident=True,
+                                                                 context=kwargs.get("context"), device=kwargs.get("device"))
         # period and depth come from the detrended power peak, the template row from
         # the chi^2 minimum (main.py:198-200 vs 270-272)
         index_highest_power = numpy.argmax(power)
         period = test_statistic_periods[index_highest_power]
         depth = test_statistic_depths[index_highest_power]
         ctx, dev = kwargs.get("context"), kwargs.get("device")
-        T0 = final_T0_fit(signal=lc_arr[best_row], depth=depth, t=self.t, y=self.y, dy=self.dy,
-                          period=period, T0_fit_margin=self.T0_fit_margin,
-                          show_progress_bar=self.show_progress_bar, verbose=self.verbose,
-                          residuals_fn=lambda *a: _search.t0_fit_residuals(*a, context=ctx, device=dev))
+        if fused is not None:
+            if self.verbose:
+                print("Searching for best T0 for period", format(period, ".5f"), "days")
+            T0 = float(summary["T0"])   # (tls_power_prep + tls_t0fit_kernel + tls_first_min: stats.py:135-204 on the device)
+        else:
+            T0 = final_T0_fit(signal=lc_arr[best_row], depth=depth, t=self.t, y=self.y, dy=self.dy,
+                              period=period, T0_fit_margin=self.T0_fit_margin,
+                              show_progress_bar=self.show_progress_bar, verbose=self.verbose,
+                              residuals_fn=lambda *a: _search.t0_fit_residuals(*a, context=ctx, device=dev))
         transit_times = all_transit_times(T0, self.t, period)
+        fill_factor = calculate_fill_factor(self.t)   # (once: the model's fill_half below wants it too)
         transit_duration_in_days = calculate_transit_duration_in_days(
-            self.t, period, transit_times, duration)
+            self.t, period, transit_times, duration, fill_factor=fill_factor)
 
         phases = fold(self.t, period, T0=T0 + period / 2)
         sort_index = numpy.argsort(phases)
@@ -156,7 +186,7 @@ class transitleastsquares(object):
         # model phase is shifted by half a cadence: mid-transit at phase 0.5
         model_folded_phase = numpy.linspace(0 + 1 / n / 2, 1 + 1 / n / 2, n)
 
-        fill_half = 1 - ((1 - calculate_fill_factor(self.t)) * 0.5)
+        fill_half = 1 - ((1 - fill_factor) * 0.5)
         stretch = calculate_stretch(self.t, period, transit_times)
         internal_samples = (int(len(self.y) / len(transit_times))
                             * C.OVERSAMPLE_MODEL_LIGHT_CURVE)

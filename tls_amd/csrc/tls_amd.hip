@@ -964,40 +964,49 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
     return TLS_OK;
 }
 
-// T0-fit launch shared by tls_t0_fit and tls_power_batch: every pointer on the device, nothing waited for
+// T0-fit launch shared by tls_t0_fit and tls_power_batch: every pointer on the device, nothing waited for.
+// One fit (d_params == nullptr: period, dur, roll, n_epochs from the host) or `n_fits` fits in ONE launch (blockIdx.y = fit;
+// their parameters, epochs and signals written on the device by tls_power_prep, the arrays `*_stride` doubles apart).
 int launch_t0_fit(tls_ctx* ctx, const double* d_t, const double* d_y, const double* d_signal, const double* d_epochs,
                   double* d_residuals, unsigned int* d_queue, int64_t n, double period, int64_t dur, int64_t n_epochs,
-                  int64_t roll) {
+                  int64_t roll, const tlsdev::T0FitParams* d_params = nullptr, int64_t n_fits = 1, int64_t y_stride = 0,
+                  int64_t signal_stride = 0, int64_t epoch_stride = 0) {
     tlsdev::T0FitArgs a;
     a.t = d_t; a.y = d_y; a.signal = d_signal; a.epochs = d_epochs;
     a.residuals = d_residuals; a.queue = d_queue; a.scratch = nullptr; a.scratch_stride = 0;
     a.period = period; a.n = (int)n; a.dur = (int)dur; a.roll = (int)(roll % n); a.n_epochs = (int)n_epochs;
+    a.params = d_params; a.y_stride = y_stride; a.signal_stride = signal_stride; a.epoch_stride = epoch_stride;
     const size_t hdr = 272;
     const size_t resident_bytes = hdr + 16 * (size_t)n;
     const bool resident = resident_bytes <= kLdsPerCU && n <= 65535;
     size_t lds; int threads, blocks;
+    // (a batched launch does not know its fits' epoch counts on the host: every fit gets the full set of workgroups, those
+    // beyond its epochs leave at once)
+    const int64_t epochs_cap = d_params ? n : n_epochs;
     if (resident) {
         a.nb = (int)n; lds = resident_bytes;
         const size_t per_cu = kLdsPerCU / resident_bytes;
         threads = per_cu >= 2 ? 512 : 1024;
         const size_t wg_per_cu = std::min<size_t>(per_cu, 2048 / (size_t)threads);
-        blocks = (int)std::min<int64_t>(n_epochs, (int64_t)wg_per_cu * ctx->n_cu);
+        blocks = (int)std::min<int64_t>(epochs_cap, (int64_t)wg_per_cu * ctx->n_cu);
     } else {
         a.nb = (int)std::min<int64_t>(n, 16384); lds = hdr + 4 * (size_t)a.nb;
-        threads = 512; blocks = (int)std::min<int64_t>(n_epochs, (int64_t)2 * ctx->n_cu);
+        threads = 512; blocks = (int)std::min<int64_t>(epochs_cap, (int64_t)2 * ctx->n_cu);
         a.scratch_stride = 3 * n;
-        TLS_HIP(ctx, ctx->d_fscratch.reserve((size_t)blocks * (size_t)a.scratch_stride));
+        TLS_HIP(ctx, ctx->d_fscratch.reserve((size_t)blocks * (size_t)n_fits * (size_t)a.scratch_stride));
         a.scratch = ctx->d_fscratch.ptr;
     }
+    if (blocks < 1) return TLS_OK;
+    const dim3 grid((unsigned)blocks, (unsigned)std::max<int64_t>(n_fits, 1));
     hipError_t e;
     if (resident) {
         auto kernel = tlsdev::tls_t0fit_kernel<true, unsigned short>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
+        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
     } else {
         auto kernel = tlsdev::tls_t0fit_kernel<false, unsigned int>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
+        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
     }
     if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("t0 fit launch: ") + hipGetErrorString(e));
     return TLS_OK;
@@ -2066,14 +2075,14 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
 static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n, int64_t n_curves,
                             const double* periods, int64_t n_periods, const tls_template* tmpl, const tls_params* params,
                             int64_t median_kernel, tls_power_summary* out_summary, double* out_chi2, int64_t* out_row,
-                            double* out_depth, double* out_power);
+                            double* out_depth, double* out_power, double* out_SR, double* out_power_raw);
 
 int tls_power_batch(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n, int64_t n_curves,
                     const double* periods, int64_t n_periods, const tls_template* tmpl, const tls_params* params,
                     int64_t median_kernel, tls_power_summary* out_summary, double* out_chi2, int64_t* out_row,
-                    double* out_depth, double* out_power) {
+                    double* out_depth, double* out_power, double* out_SR, double* out_power_raw) {
     const int rc = power_batch_impl(ctx, t, y, dy, n, n_curves, periods, n_periods, tmpl, params, median_kernel, out_summary,
-                                    out_chi2, out_row, out_depth, out_power);
+                                    out_chi2, out_row, out_depth, out_power, out_SR, out_power_raw);
     if (ctx && rc != TLS_OK) {
         // EVERY failure leaves through here: nothing is still copying into or out of the pinned staging buffers or the
         // caller's arrays, and the context does not keep pointing at a batch slot
@@ -2090,7 +2099,7 @@ int tls_power_batch(tls_ctx* ctx, const double* t, const double* y, const double
 static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, const double* dy, int64_t n, int64_t n_curves,
                             const double* periods, int64_t n_periods, const tls_template* tmpl, const tls_params* params,
                             int64_t median_kernel, tls_power_summary* out_summary, double* out_chi2, int64_t* out_row,
-                            double* out_depth, double* out_power) {
+                            double* out_depth, double* out_power, double* out_SR, double* out_power_raw) {
     if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
     if (n_curves < 0) return fail(ctx, TLS_E_ARG, "negative number of light curves");
     if (n_curves == 0) return TLS_OK;
@@ -2103,7 +2112,7 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
     if (rc) return rc;
     int64_t kernel = median_kernel;
     if (kernel % 2 == 0) kernel += 1;                                   // stats.py:115-117
-    const int64_t group = 32;
+    const int64_t group = std::min<int64_t>(32, n_curves);              // (one light curve: the drop-in power() call)
     const size_t np = (size_t)n_periods, nn = (size_t)n;
     const bool uni = ctx->uniform_w;
     const int detrend = n_periods > 2 * kernel ? 1 : 0;
@@ -2129,19 +2138,20 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
     const size_t fit_stride = nn;                                       // epochs / residuals of one curve (<= n each)
     TLS_HIP(ctx, ctx->d_fep.reserve((size_t)group * fit_stride));
     TLS_HIP(ctx, ctx->d_fres.reserve((size_t)group * fit_stride));
-    TLS_HIP(ctx, ctx->d_fsig.reserve((size_t)group * (size_t)max_len + (size_t)group));   // signals | n_epochs (as int, behind)
-    DevBuf<unsigned int>& d_queues = ctx->d_pqueues;   // (a member: released with the context, whatever path leaves this call)
-    TLS_HIP(ctx, d_queues.reserve((size_t)group));
-    // pinned staging: flux in; summaries, T0 and (on request) the per-period arrays out; epochs + signals in
+    // signals | n_epochs (ints) | fit parameters (T0FitParams, 24 B each)
+    TLS_HIP(ctx, ctx->d_fsig.reserve((size_t)group * (size_t)max_len + (size_t)group + 3 * (size_t)group));
+    int* d_nep = reinterpret_cast<int*>(ctx->d_fsig.ptr + (size_t)group * (size_t)max_len);
+    tlsdev::T0FitParams* d_fit = reinterpret_cast<tlsdev::T0FitParams*>(ctx->d_fsig.ptr + (size_t)group * (size_t)max_len + (size_t)group);
+    static_assert(sizeof(tlsdev::T0FitParams) == 24, "three doubles of device scratch per fit");
+    // pinned staging: flux in; summaries, T0 and (on request) the per-period arrays out
     const size_t in_doubles = (size_t)group * nn * (uni ? 1 : 2) + 2 * (size_t)group;
-    const size_t fit_doubles = (size_t)group * fit_stride + (size_t)group * (size_t)max_len + (size_t)group;
-    const size_t out_doubles = 11 * (size_t)group + (out_chi2 ? 3 * (size_t)group * np : 0) + (out_power ? (size_t)group * np : 0);
-    const size_t want_in = std::max(in_doubles, fit_doubles);
-    if (sl.h_in_cap < want_in) {
+    const size_t arrays = (out_chi2 ? 3 : 0) + (out_power ? 1 : 0) + (out_SR ? 1 : 0) + (out_power_raw ? 1 : 0);
+    const size_t out_doubles = 11 * (size_t)group + arrays * (size_t)group * np;
+    if (sl.h_in_cap < in_doubles) {
         if (sl.h_in) TLS_HIP(ctx, hipHostFree(sl.h_in));
         sl.h_in = nullptr; sl.h_in_cap = 0;
-        TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.h_in), want_in * 8, hipHostMallocDefault));
-        sl.h_in_cap = want_in;
+        TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.h_in), in_doubles * 8, hipHostMallocDefault));
+        sl.h_in_cap = in_doubles;
     }
     if (sl.h_out_cap < out_doubles) {
         if (sl.h_out) TLS_HIP(ctx, hipHostFree(sl.h_out));
@@ -2150,7 +2160,6 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         sl.h_out_cap = out_doubles;
     }
     std::vector<double> w;
-    std::vector<int> n_epochs_h((size_t)group);
     rc = TLS_OK;
     const int64_t n_groups = (n_curves + group - 1) / group;
     ctx->batch_group_ms.assign((size_t)n_groups, 0.0);
@@ -2209,79 +2218,51 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         pa.chi2 = sl.d_chi2.ptr; pa.row = sl.d_row.ptr; pa.depth = sl.d_depth.ptr; pa.power = ctx->d_spec.ptr + 2 * np;
         pa.periods = ctx->d_periods.ptr; pa.out = d_pick; pa.power_stride = (long long)spec_stride; pa.n = (int)n_periods;
         hipLaunchKernelGGL(tlsdev::tls_power_pick, dim3((unsigned)gc), dim3(1024), 0, ctx->stream, pa);
+        // ---- final T0 fit of every curve (stats.py:135-204), WITHOUT a host round trip (round 6): trial epochs, the depth-scaled
+        // template and the fit's parameters are formed on the device from the pick (tls_power_prep), all fits of the group run
+        // in ONE launch (blockIdx.y = light curve), the first minimum is taken on the device
+        tlsdev::PrepArgs pr;
+        pr.pick = d_pick; pr.widths = ctx->d_widths.ptr; pr.n_widths = ctx->n_widths; pr.q = ctx->d_q.ptr;
+        pr.signal = ctx->d_fsig.ptr; pr.signal_stride = (long long)max_len; pr.epochs = ctx->d_fep.ptr; pr.epoch_stride = (long long)fit_stride;
+        pr.params = d_fit; pr.n_epochs = d_nep; pr.t_min = t_min; pr.margin = params->T0_fit_margin; pr.n = (int)n;
+        hipLaunchKernelGGL(tlsdev::tls_power_prep, dim3((unsigned)gc), dim3(256), 0, ctx->stream, pr);
         TLS_HIP(ctx, hipGetLastError());
-        double* h_pick = sl.h_out;                        // [group][8]
-        double* h_sde = sl.h_out + 8 * (size_t)group;     // [group][2]
-        double* h_T0 = h_sde + 2 * (size_t)group;         // [group]
-        double* h_arrays = h_T0 + group;                  // chi2 | row | depth | power, on request
-        TLS_HIP(ctx, hipMemcpyAsync(h_pick, d_pick, (size_t)gc * 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
-        TLS_HIP(ctx, hipMemcpyAsync(h_sde, d_sde, (size_t)gc * 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
-        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        // ---- final T0 fit of every curve (stats.py:135-204): trial epochs and the depth-scaled template on the host
-        // (a few KB per curve), the fold + sort + residual of every epoch on the device, first minimum on the device
-        double* h_ep = sl.h_in;                                            // [group][fit_stride]
-        double* h_sig = sl.h_in + (size_t)group * fit_stride;              // [group][max_len]
-        int* h_nep = reinterpret_cast<int*>(h_sig + (size_t)group * (size_t)max_len);
-        for (int64_t c = 0; c < gc; ++c) {
-            const double* pk = h_pick + 8 * c;
-            int points = 0;
-            if (pk[6] == 0.0) {   // a transit was fit (main.py:203-216 otherwise: T0 = 0)
-                const int64_t best_row = (int64_t)pk[5];
-                const int64_t dur = tmpl->length[best_row];
-                const double depth = pk[4], period = pk[3];
-                const double scale = 0.5 / (1 - depth);                   // SIGNAL_DEPTH / (1 - depth), stats.py:142
-                const double* sig = tmpl->values + tmpl->offset[best_row];
-                for (int64_t j = 0; j < dur; ++j) h_sig[(size_t)c * (size_t)max_len + (size_t)j] = 1 - ((1 - sig[j]) / scale);
-                if (params->T0_fit_margin == 0) points = (int)n;
-                else points = (int)((double)n / (params->T0_fit_margin * (double)dur));   // stats.py:150
-                if (points > n) points = (int)n;
-                if (points < 0) points = 0;
-                // numpy.linspace(min t, min t + period, points): arange * step + start, the end point set exactly
-                const double stop = t_min + period;
-                if (points == 1) h_ep[(size_t)c * fit_stride] = t_min;
-                else if (points > 1) {
-                    const double step = (stop - t_min) / (double)(points - 1);
-                    for (int i = 0; i < points; ++i) {
-                        volatile double prod = (double)i * step;           // two roundings, like numpy (no contraction)
-                        h_ep[(size_t)c * fit_stride + (size_t)i] = prod + t_min;
-                    }
-                    h_ep[(size_t)c * fit_stride + (size_t)points - 1] = stop;
-                }
-            }
-            n_epochs_h[(size_t)c] = points;
-            h_nep[c] = points;
-        }
-        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_fep.ptr, h_ep, (size_t)gc * fit_stride * 8, hipMemcpyHostToDevice, ctx->stream));
-        TLS_HIP(ctx, hipMemcpyAsync(ctx->d_fsig.ptr, h_sig, ((size_t)group * (size_t)max_len + (size_t)group) * 8,
-                                    hipMemcpyHostToDevice, ctx->stream));
-        TLS_HIP(ctx, hipMemsetAsync(d_queues.ptr, 0, (size_t)group * sizeof(unsigned int), ctx->stream));
-        for (int64_t c = 0; c < gc && rc == TLS_OK; ++c) {
-            if (n_epochs_h[(size_t)c] == 0) continue;
-            const double* pk = h_pick + 8 * c;
-            const int64_t dur = tmpl->length[(int64_t)pk[5]];
-            rc = launch_t0_fit(ctx, ctx->d_t.ptr, sl.d_y.ptr + (size_t)c * nn, ctx->d_fsig.ptr + (size_t)c * (size_t)max_len,
-                               ctx->d_fep.ptr + (size_t)c * fit_stride, ctx->d_fres.ptr + (size_t)c * fit_stride,
-                               d_queues.ptr + c, n, pk[3], dur, n_epochs_h[(size_t)c], dur / 2 + 1);
-        }
+        rc = launch_t0_fit(ctx, ctx->d_t.ptr, sl.d_y.ptr, ctx->d_fsig.ptr, ctx->d_fep.ptr, ctx->d_fres.ptr, nullptr, n, 1.0, 0, 0, 0,
+                           d_fit, gc, (int64_t)nn, max_len, (int64_t)fit_stride);
         if (rc) break;
         tlsdev::FirstMinArgs fa;
-        fa.residuals = ctx->d_fres.ptr; fa.epochs = ctx->d_fep.ptr;
-        fa.n_epochs = reinterpret_cast<const int*>(ctx->d_fsig.ptr + (size_t)group * (size_t)max_len);
+        fa.residuals = ctx->d_fres.ptr; fa.epochs = ctx->d_fep.ptr; fa.n_epochs = d_nep;
         fa.T0 = d_T0; fa.stride = (long long)fit_stride;
         hipLaunchKernelGGL(tlsdev::tls_first_min, dim3((unsigned)gc), dim3(1024), 0, ctx->stream, fa);
         TLS_HIP(ctx, hipGetLastError());
-        TLS_HIP(ctx, hipMemcpyAsync(h_T0, d_T0, (size_t)gc * 8, hipMemcpyDeviceToHost, ctx->stream));
+        // (sde | pick | T0 lie side by side behind the spectra on the device: ONE copy, the host keeps the layout)
+        double* h_sde = sl.h_out;                         // [group][2]
+        double* h_pick = h_sde + 2 * (size_t)group;       // [group][8]
+        double* h_T0 = h_pick + 8 * (size_t)group;        // [group]
+        double* h_arrays = h_T0 + group;                  // chi2 | row | depth | power | SR | power_raw, on request
+        TLS_HIP(ctx, hipMemcpyAsync(h_sde, d_sde, 11 * (size_t)group * 8, hipMemcpyDeviceToHost, ctx->stream));
+        double* h_next = h_arrays;
+        double *h_chi2 = nullptr, *h_power = nullptr, *h_SR = nullptr, *h_praw = nullptr;
         if (out_chi2) {
-            TLS_HIP(ctx, hipMemcpyAsync(h_arrays, sl.d_chi2.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
-            TLS_HIP(ctx, hipMemcpyAsync(h_arrays + (size_t)group * np, sl.d_row.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
-            TLS_HIP(ctx, hipMemcpyAsync(h_arrays + 2 * (size_t)group * np, sl.d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+            h_chi2 = h_next; h_next += 3 * (size_t)group * np;
+            TLS_HIP(ctx, hipMemcpyAsync(h_chi2, sl.d_chi2.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+            TLS_HIP(ctx, hipMemcpyAsync(h_chi2 + (size_t)group * np, sl.d_row.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+            TLS_HIP(ctx, hipMemcpyAsync(h_chi2 + 2 * (size_t)group * np, sl.d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
         }
-        double* h_power = h_arrays + (out_chi2 ? 3 * (size_t)group * np : 0);
-        if (out_power)
-            for (int64_t c = 0; c < gc; ++c)
-                TLS_HIP(ctx, hipMemcpyAsync(h_power + (size_t)c * np, ctx->d_spec.ptr + (size_t)c * spec_stride + 2 * np, np * 8,
-                                            hipMemcpyDeviceToHost, ctx->stream));
-        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // (SR | power_raw | power lie side by side per light curve: one strided copy each)
+        auto fetch_spec = [&](double* host, size_t which) -> hipError_t {
+            return hipMemcpy2DAsync(host, np * 8, ctx->d_spec.ptr + which * np, spec_stride * 8, np * 8, (size_t)gc, hipMemcpyDeviceToHost, ctx->stream);
+        };
+        double* h_spec3 = nullptr;   // all three spectra asked for: [curve][SR | power_raw | power] in one contiguous copy
+        if (out_power && out_SR && out_power_raw) {
+            h_spec3 = h_next; h_next += 3 * (size_t)group * np;
+            TLS_HIP(ctx, hipMemcpyAsync(h_spec3, ctx->d_spec.ptr, (size_t)gc * spec_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            if (out_power) { h_power = h_next; h_next += (size_t)group * np; TLS_HIP(ctx, fetch_spec(h_power, 2)); }
+            if (out_SR) { h_SR = h_next; h_next += (size_t)group * np; TLS_HIP(ctx, fetch_spec(h_SR, 0)); }
+            if (out_power_raw) { h_praw = h_next; h_next += (size_t)group * np; TLS_HIP(ctx, fetch_spec(h_praw, 1)); }
+        }
+        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the ONE wait of the group
         for (int64_t c = 0; c < gc; ++c) {
             const double* pk = h_pick + 8 * c;
             tls_power_summary& o = out_summary[c0 + c];
@@ -2295,11 +2276,21 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
             }
         }
         if (out_chi2) {
-            std::memcpy(out_chi2 + c0 * n_periods, h_arrays, (size_t)gc * np * 8);
-            std::memcpy(out_row + c0 * n_periods, h_arrays + (size_t)group * np, (size_t)gc * np * 8);
-            std::memcpy(out_depth + c0 * n_periods, h_arrays + 2 * (size_t)group * np, (size_t)gc * np * 8);
+            std::memcpy(out_chi2 + c0 * n_periods, h_chi2, (size_t)gc * np * 8);
+            std::memcpy(out_row + c0 * n_periods, h_chi2 + (size_t)group * np, (size_t)gc * np * 8);
+            std::memcpy(out_depth + c0 * n_periods, h_chi2 + 2 * (size_t)group * np, (size_t)gc * np * 8);
         }
-        if (out_power) std::memcpy(out_power + c0 * n_periods, h_power, (size_t)gc * np * 8);
+        if (h_spec3) {
+            for (int64_t c = 0; c < gc; ++c) {
+                std::memcpy(out_SR + (c0 + c) * n_periods, h_spec3 + (size_t)c * spec_stride, np * 8);
+                std::memcpy(out_power_raw + (c0 + c) * n_periods, h_spec3 + (size_t)c * spec_stride + np, np * 8);
+                std::memcpy(out_power + (c0 + c) * n_periods, h_spec3 + (size_t)c * spec_stride + 2 * np, np * 8);
+            }
+        } else {
+            if (out_power) std::memcpy(out_power + c0 * n_periods, h_power, (size_t)gc * np * 8);
+            if (out_SR) std::memcpy(out_SR + c0 * n_periods, h_SR, (size_t)gc * np * 8);
+            if (out_power_raw) std::memcpy(out_power_raw + c0 * n_periods, h_praw, (size_t)gc * np * 8);
+        }
         ctx->batch_group_ms[(size_t)g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - group_t0).count();
     }
     ctx->executed = false;   // the search ran on the batch slot, see tls_search_batch

@@ -3094,10 +3094,25 @@ struct T0FitArgs {
     long long scratch_stride;
     double period;
     int n, dur, roll, n_epochs, nb;
+    // survey batches / the fused power() chain: fit c = blockIdx.y takes period, dur, roll and n_epochs from params[c] (written
+    // on the device by tls_power_prep: no host round trip between the search and the fit) and its arrays at y + c * y_stride,
+    // signal + c * signal_stride, epochs / residuals + c * epoch_stride.  nullptr: one fit, the scalars above.
+    const struct T0FitParams* params;
+    long long y_stride, signal_stride, epoch_stride;
 };
+struct T0FitParams { double period; int dur, roll, n_epochs, pad_; };
 
 template <bool RESIDENT, typename IdxT>
-__global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a) {
+__global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a0) {
+    T0FitArgs a = a0;
+    if (a0.params != nullptr) {
+        const long long c = blockIdx.y;
+        const T0FitParams fp = a0.params[c];
+        a.period = fp.period; a.dur = fp.dur; a.roll = fp.roll; a.n_epochs = fp.n_epochs;
+        a.y = a0.y + c * a0.y_stride; a.signal = a0.signal + c * a0.signal_stride;
+        a.epochs = a0.epochs + c * a0.epoch_stride; a.residuals = a0.residuals + c * a0.epoch_stride;
+        if ((int)blockIdx.x >= a.n_epochs) return;   // (uniform for the workgroup)
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
@@ -3114,7 +3129,7 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a) {
         regB = regA + n;                                 // sort scratch
         cnt = reinterpret_cast<unsigned int*>(regB);
     } else {
-        regA = a.scratch + (long long)blockIdx.x * a.scratch_stride;
+        regA = a.scratch + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * a.scratch_stride;
         regB = regA + n;
         cnt = reinterpret_cast<unsigned int*>(smem + kHdr);
     }
@@ -3454,6 +3469,71 @@ __global__ void __launch_bounds__(1024) tls_first_min(const FirstMinArgs a) {
         for (int w = 1; w < nw; ++w) if (red_v[w] < v || (red_v[w] == v && red_i[w] < i)) { v = red_v[w]; i = red_i[w]; }
         a.T0[c] = (v < INFINITY && i < n) ? a.epochs[c * a.stride + i] : 0.0;
     }
+}
+
+// What the host did between the search and the final T0 fit of a light curve, on the device (stats.py:135-152 as
+// tls_power_batch's host loop wrote it): from the pick of tls_power_pick -- period and depth at the power peak, template row
+// at the chi^2 minimum -- the fit's parameters, its trial epochs numpy.linspace(min t, min t + period, points) (arange * step +
+// start, two roundings, the end point set exactly) and the template scaled to the fitted depth, 1 - (1 - signal) / (SIGNAL_DEPTH
+// / (1 - depth)).  One workgroup per light curve.  No host round trip: the fit is enqueued right behind.
+struct PrepArgs {
+    const double* pick;             // [n_curves][8] (tls_power_pick)
+    const WidthEntry* widths; int n_widths;
+    const double* q;                // 1 - template rows, the plan's layout
+    double* signal; long long signal_stride;
+    double* epochs; long long epoch_stride;
+    T0FitParams* params;            // [n_curves]
+    int* n_epochs;                  // [n_curves] (tls_first_min reads them)
+    double t_min, margin;
+    int n;
+};
+__global__ void __launch_bounds__(256) tls_power_prep(const PrepArgs a) {
+    __shared__ int s_k, s_points;
+    __shared__ double s_scale, s_step, s_stop;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const long long c = blockIdx.x;
+    const double* pk = a.pick + 8 * c;
+    if (tid == 0) {
+        int points = 0, k_row = 0;
+        if (pk[6] == 0.0) {   // a transit was fit (main.py:203-216 otherwise: T0 = 0)
+            const int best_row = (int)pk[5];
+            for (int k = 0; k < a.n_widths; ++k) if (a.widths[k].row == best_row) { k_row = k; break; }   // (reported rows are the first row of their width)
+            const int dur = a.widths[k_row].q_len;
+            if (a.margin == 0) points = a.n;
+            else points = (int)((double)a.n / (a.margin * (double)dur));   // stats.py:150
+            if (points > a.n) points = a.n;
+            if (points < 0) points = 0;
+            const double depth = pk[4], period = pk[3];
+            s_scale = 0.5 / (1 - depth);   // SIGNAL_DEPTH / (1 - depth), stats.py:142
+            s_stop = a.t_min + period;
+            s_step = points > 1 ? (s_stop - a.t_min) / (double)(points - 1) : 0.0;
+            T0FitParams fp;
+            fp.period = period; fp.dur = dur; fp.roll = (dur / 2 + 1) % a.n; fp.n_epochs = points; fp.pad_ = 0;
+            a.params[c] = fp;
+        } else {
+            T0FitParams fp;
+            fp.period = 1.0; fp.dur = 0; fp.roll = 0; fp.n_epochs = 0; fp.pad_ = 0;
+            a.params[c] = fp;
+        }
+        a.n_epochs[c] = points;
+        s_k = k_row; s_points = points;
+    }
+    __syncthreads();
+    const int points = s_points;
+    if (points == 0) return;
+    const int dur = a.widths[s_k].q_len;
+    const double* qr = a.q + a.widths[s_k].q_offset;
+    double* sig = a.signal + c * a.signal_stride;
+    for (int j = tid; j < dur; j += nt) sig[j] = 1 - (qr[j] / s_scale);   // (q = 1 - signal as the host formed it)
+    double* ep = a.epochs + c * a.epoch_stride;
+    if (points == 1) { if (tid == 0) ep[0] = a.t_min; return; }
+    for (int i = tid; i < points; i += nt) {
+        double prod = (double)i * s_step;
+        asm volatile("" : "+v"(prod));   // two roundings, like numpy's arange * step + start: the product must not fuse into the sum
+        ep[i] = prod + a.t_min;
+    }
+    __syncthreads();
+    if (tid == 0) ep[points - 1] = s_stop;
 }
 
 // Developer/test entry: the exact sequential cumsum on an arbitrary non-negative series

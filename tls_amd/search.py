@@ -269,6 +269,27 @@ def search_periods(t, y, dy, periods, table, transit_depth_min, R_star_min, R_st
     return chi2, row, depth
 
 
+search_periods._tls_amd_product = True   # (api.power() takes the fused device chain only while this is the product's function)
+
+
+def fused_power(t, y, dy, periods, table, params, oversampling_factor, context=None, device=None):
+    """The device part of power() for ONE light curve on ONE GPU in a single submission (tls_power_batch with one light curve):
+    search, SDE spectra (stats.py:105-132), the pick of main.py:198-212,269-272 and the final T0 fit (stats.py:135-204) -- trial
+    epochs and scaled template formed on the device, first minimum taken on the device -- with ONE wait at the end instead of
+    three (search fetch, spectra fetch, T0-fit fetch).  Returns (context, summary record, chi2, row, depth, SR, power_raw,
+    power); every value equals what search_periods + spectra + final_T0_fit return for the same light curve."""
+    from . import constants as C
+    kernel = oversampling_factor * C.SDE_MEDIAN_KERNEL_SIZE
+    if kernel != int(kernel):
+        raise ValueError("oversampling_factor * %d must be an integer" % C.SDE_MEDIAN_KERNEL_SIZE)
+    ctx = context if context is not None else default_context(device)
+    y2 = numpy.ascontiguousarray(y, dtype=numpy.float64)[None, :]
+    dy2 = numpy.ascontiguousarray(dy, dtype=numpy.float64)[None, :]
+    summary, chi2, row, depth, power, SR, power_raw = ctx.power_batch(t, y2, dy2, periods, table, params, int(kernel),
+                                                                      with_arrays=True, with_power=True, with_spectra=True)
+    return ctx, summary[0], chi2[0], row[0], depth[0], SR[0], power_raw[0], power[0]
+
+
 def t0_fit_residuals(t, y, period, signal, T0_array, roll, context=None, device=None):
     """Device evaluation of the final-T0-fit residuals (tls_t0_fit); same contract as
     tls_amd.stats.t0_fit_residuals_host."""

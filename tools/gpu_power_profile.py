@@ -17,3 +17,4 @@ for _ in range(20):
     m.power(verbose=False, show_progress_bar=False, context=ctx, **kw)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(32)
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
