@@ -1059,6 +1059,7 @@ def test_fast_prefix_mode_decides_the_reference_cells(gpu, oracle_lib, monkeypat
 
 @pytest.mark.parametrize("n,cadences_per_day,commensurate", [
     (4320, 48, [30 / 48.0, 1.0, 2.5, 2.0, 10.0, 45.0]),            # LDS-resident: the six periods of the parity test above
+    (7200, 48, [30 / 48.0, 1.0, 2.5, 2.0, 10.0, 45.0]),            # ... and in the four-slot kernel's 512-thread shape (piles of 240)
     (70128, 48, [78 / 48.0, 66.5 / 48.0, 1.0, 80 / 48.0, 131 / 48.0]),   # Kepler size: the slab sort's fallback
 ])
 def test_commensurate_periods_cost_no_more_than_their_neighbours(gpu, oracle_lib, n, cadences_per_day, commensurate):
@@ -1091,7 +1092,7 @@ def test_commensurate_periods_cost_no_more_than_their_neighbours(gpu, oracle_lib
         # 2.1-2.8 x an ordinary period, 120 piles of 36 1.4 x; before the pile path: 16 x.  (The classic kernel's bitonic
         # network, `slim = 0`: 1.7 x.)
         print("commensurate: worst %.0f cycles = %.2f x the median %.0f (%s)" % (worst, worst / median, median, gpu.last_kernel()))
-        assert worst <= (4.0 if gpu.last_kernel() == "slim" else 3.0) * median, (worst, median, periods[special][numpy.argmax(cycles[special])])
+        assert worst <= (4.0 if gpu.last_kernel().startswith("slim") else 3.0) * median, (worst, median, periods[special][numpy.argmax(cycles[special])])
     sel = numpy.nonzero(special)[0]
     want = oracle_search(oracle_lib, inp, periods=periods[sel])
     assert_parity(tuple(a[sel] for a in got[:3]), want, n)
@@ -1200,7 +1201,8 @@ def test_noted_band_windows_are_decided_on_the_exact_prefix_sum(gpu, oracle_lib,
 
 
 @pytest.mark.parametrize("sigma,stride,outlier,name", [(None, 1, None, "k2_90d"), (300e-6, 11, None, "k2_90d"), (None, 7, 3.0e4, "k2_90d"),
-                                                       (100e-6, 13, 2.0e6, "k2_90d"), (None, 3, None, "tutorial01")])
+                                                       (100e-6, 13, 2.0e6, "k2_90d"), (None, 3, None, "tutorial01"),
+                                                       (None, 7, None, "lc_150d"), (None, 23, 3.0e4, "lc_150d")])
 def test_four_slot_kernel_searches_the_reference_cells(gpu, oracle_lib, sigma, stride, outlier, name):
     """Short LDS-resident series, uniform weights: tls_slim_kernel (four 256-thread workgroups per CU, phase 3 on the
     prefix sum X alone, dot products by summation by parts) against the classic LDS-resident kernel
@@ -1208,7 +1210,9 @@ def test_four_slot_kernel_searches_the_reference_cells(gpu, oracle_lib, sigma, s
     what the two prefix-sum modes differ by.  A window the plain scan cannot decide is noted and decided on the exact
     prefix sum: ONE wild flux value widens the undecided band (1.25 * 2^-53 * (N + W) * max|flux|) until white noise puts
     windows inside -- a few dozen per period at 3e4, more than the list of 256 holds at 2e6 (the period is searched again
-    in exact mode).  Tutorial 01 (100 d): three workgroups per CU."""
+    in exact mode).  Tutorial 01 (100 d): three workgroups per CU.  150 d (7200 points; round 6): the kernel's 512-thread
+    shape, two workgroups per CU, 14 index bits in a sort record -- where the classic kernel runs one 1024-thread workgroup."""
+    slim_name = "slim512" if name == "lc_150d" else "slim"
     inp = _inputs(name) if sigma is None else _inputs(name, sigma=sigma)
     if outlier is not None:
         y = inp["y"].copy()
@@ -1222,9 +1226,9 @@ def test_four_slot_kernel_searches_the_reference_cells(gpu, oracle_lib, sigma, s
     assert gpu.last_kernel() == "resident"
     gpu.set_options(slim=1, exact_prefix=None)
     slim = gpu.search(*args, count_work=True)
-    assert gpu.last_kernel() == "slim", gpu.plan_info()
+    assert gpu.last_kernel() == slim_name, gpu.plan_info()
     plain = gpu.search(*args)
-    assert gpu.last_kernel() == "slim"
+    assert gpu.last_kernel() == slim_name
     for a, b in zip(slim[:3], plain[:3]):
         numpy.testing.assert_array_equal(a, b)       # counting and plain instantiation: the same bits
     assert slim[3]["evaluated_cells"] == classic[3]["evaluated_cells"]
@@ -1279,13 +1283,38 @@ def test_four_slot_kernel_batches_ties_and_the_series_it_does_not_fit(gpu, oracl
     inp_w = synthetic.search_inputs(tt[sh], yy[sh], dy, period_min=0.9, period_max=9.0, oversampling_factor=1)
     gpu.search(inp_w["t"], inp_w["y"], inp_w["dy"], inp_w["periods"][::9], inp_w["table"], inp_w["params"])
     assert gpu.last_kernel() == "resident"
-    # 120 days at 30 min: one region no longer fits a quarter of the LDS
+    # 120 days at 30 min: one region no longer fits a quarter of the LDS -- the 512-thread shape, two workgroups per CU (round 6);
+    # its survey batch equals the single searches, and ties / piles keep numpy's stable order with 14 index bits in a record
     n = 5760
-    t2 = numpy.arange(n) / 48.0
-    y2 = 1.0 + rng.normal(0, 1e-4, n)
-    inp2 = synthetic.search_inputs(t2, y2, None, period_min=1.0, period_max=30.0, oversampling_factor=1)
-    gpu.search(inp2["t"], inp2["y"], inp2["dy"], inp2["periods"][::20], inp2["table"], inp2["params"])
-    assert gpu.last_kernel().startswith("resident")
+    t2 = 1.0 + numpy.arange(n) / 48.0
+    y2 = numpy.stack([1.0 + numpy.random.RandomState(40 + s).normal(0, 1e-4, n) for s in range(3)])
+    per2, chi2_b, row_b, depth_b = survey.search_batch(t2, y2, context=gpu, period_min=1.0, period_max=30.0, oversampling_factor=1)
+    assert gpu.last_kernel() == "slim512"
+    for k in (0, 2):
+        inp2 = synthetic.search_inputs(t2, y2[k], None, period_min=1.0, period_max=30.0, oversampling_factor=1)
+        one2 = gpu.search(inp2["t"], inp2["y"], inp2["dy"], inp2["periods"], inp2["table"], inp2["params"])
+        assert gpu.last_kernel() == "slim512"
+        numpy.testing.assert_array_equal(chi2_b[k], one2[0])
+        numpy.testing.assert_array_equal(row_b[k], one2[1])
+        numpy.testing.assert_array_equal(depth_b[k], one2[2])
+    tt3 = numpy.repeat(numpy.arange(3500) * 0.02 + 1.0, 2)          # 7000 points, every time stamp twice
+    yy3 = 1.0 + rng.normal(0, 3e-4, tt3.size)
+    yy3[(tt3 % 2.7) < 0.12] -= 2e-3
+    sh3 = rng.permutation(tt3.size)
+    inp3 = synthetic.search_inputs(tt3[sh3], yy3[sh3], None, period_min=0.9, period_max=9.0, oversampling_factor=1)
+    sel3 = numpy.concatenate([inp3["periods"][::9], [1.0, 2.0, 3.0, 1.5, 1.0 + 1e-9]])
+    sel3 = sel3[(sel3 >= inp3["periods"].min()) & (sel3 <= inp3["periods"].max())]
+    got3 = gpu.search(inp3["t"], inp3["y"], inp3["dy"], sel3, inp3["table"], inp3["params"], count_work=True)
+    assert gpu.last_kernel() == "slim512"
+    want3 = oracle_search(oracle_lib, inp3, periods=sel3)
+    assert got3[3]["evaluated_cells"] == int(want3[3][1])
+    assert_parity(got3, want3, tt3.size)
+    # a series whose region does not fit half the LDS either (N + W beyond ~9.9 k): the classic kernel / the slab
+    n4 = 9500
+    t4 = numpy.arange(n4) / 48.0
+    inp4 = synthetic.search_inputs(t4, 1.0 + rng.normal(0, 1e-4, n4), None, period_min=1.0, period_max=30.0, oversampling_factor=1)
+    gpu.search(inp4["t"], inp4["y"], inp4["dy"], inp4["periods"][::40], inp4["table"], inp4["params"])
+    assert gpu.last_kernel() in ("resident", "slab", "slab+split")
 
 
 def test_results_do_not_depend_on_what_the_lds_held_before(gpu):
@@ -1300,7 +1329,7 @@ def test_results_do_not_depend_on_what_the_lds_held_before(gpu):
         g, table, params = load_search_golden(name)
         cases.append((name, (g["t"], g["y"], g["dy"], g["periods"], table, params)))
     for name, sigma, stride, weights in (("k2_90d", None, 40, False), ("k2_90d", 200e-6, 40, False), ("k2_90d", 500e-6, 40, False),
-                                         ("k2_90d", None, 40, True), ("tutorial01", None, 60, False), ("tess_27d", None, 120, False),
+                                         ("k2_90d", None, 40, True), ("tutorial01", None, 60, False), ("lc_150d", None, 90, False), ("tess_27d", None, 120, False),
                                          ("tess_27d", None, 120, True), ("kepler_4yr", None, 9000, False)):
         t, f, kw = synthetic.config(name, sigma=sigma)
         dy = numpy.random.RandomState(5).uniform(0.7, 1.5, len(f)) * synthetic.CONFIGS[name][2] if weights else None

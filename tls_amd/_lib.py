@@ -482,13 +482,14 @@ class Context(object):
                                                       len(out)))
         return out
 
-    def batch_group_ms(self):
-        """Host wall time (ms) of every group of 32 light curves of the last power_batch / search_batch call."""
+    def batch_group_ms(self, with_wait=False):
+        """Host wall time (ms) of every group of 32 light curves of the last power_batch / search_batch call; with_wait: also
+        the part of each group's time spent in its one wait for the device (power_batch)."""
         n = self._lib.tls_debug_batch_group_ms(self._h, None, 0)
-        out = numpy.zeros(max(n, 0), dtype=numpy.float64)
+        out = numpy.zeros(2 * max(n, 0), dtype=numpy.float64)
         if n > 0:
-            self._lib.tls_debug_batch_group_ms(self._h, _dp(out), n)
-        return out
+            self._lib.tls_debug_batch_group_ms(self._h, _dp(out), 2 * n)
+        return (out[:n], out[n:]) if with_wait else out[:n]
 
     def check_counts(self):
         """(checked_build, {check name: violations}) -- device-side bound checks of the debug build."""

@@ -204,6 +204,7 @@ struct tls_ctx {
     PlanLayout layout;
     int64_t plan_reuses = 0;   // tls_prepare calls answered from the held plan
     std::vector<double> batch_group_ms;   // wall time of every group of 32 light curves of the last tls_power_batch / tls_search_batch (tls_debug_batch_group_ms)
+    std::vector<double> batch_group_wait_ms;   // ... of which the group's one wait for the device (tls_power_batch)
     DevBuf<double> d_scratch, d_pack, d_gather, d_scalar, d_stage;
     DevBuf<unsigned long long> d_phase, d_check;
     DevBuf<unsigned int> d_queue, d_squeue, d_lists, d_perm, d_pqueues;   // d_pqueues: tls_power_batch's T0-fit queues   // d_squeue: the search kernel's self-rewinding queue
@@ -250,6 +251,7 @@ struct tls_ctx {
     const char* last_kernel = "";    // tls_last_kernel
     int slim_blocks = 0;              // > 0: the plan fits the four-slots-per-CU kernel (tls_slim_kernel): its workgroups in flight
     size_t slim_lds = 0;              // ... and its dynamic LDS
+    int slim_threads = 256;           // ... and its workgroup size: 256 (four or three to a CU) or 512 (two to a CU: series of 5-10 k points)
     int cumsum_round = 2 * tlsdev::kCumsumChunk;
     size_t lds_bytes = 0;
     double S0 = 0, w0 = 1, depth_min = 0;
@@ -928,10 +930,13 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
         // four period slots per CU (tls_slim_kernel.hip.h): plain variant, uniform weights, 256-thread workgroups
         kernel_name = "slim";
         a.lds_bytes = (long long)ctx->slim_lds;
-        auto kernel = count_work ? tlsdev::tls_slim_kernel<true> : tlsdev::tls_slim_kernel<false>;
+        const bool wide = ctx->slim_threads == tlsdev::kSlimThreadsWide;
+        auto kernel = wide ? (count_work ? tlsdev::tls_slim_kernel<true, tlsdev::kSlimThreadsWide> : tlsdev::tls_slim_kernel<false, tlsdev::kSlimThreadsWide>)
+                           : (count_work ? tlsdev::tls_slim_kernel<true, tlsdev::kSlimThreads> : tlsdev::tls_slim_kernel<false, tlsdev::kSlimThreads>);
+        if (wide) kernel_name = "slim512";
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->slim_lds);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->slim_blocks), dim3((unsigned)tlsdev::kSlimThreads), ctx->slim_lds, ctx->stream, a);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->slim_blocks), dim3((unsigned)ctx->slim_threads), ctx->slim_lds, ctx->stream, a);
             e = hipGetLastError();
         }
     } else if (ctx->resident) e = TLS_LAUNCH_RESIDENT(ctx->blocks);
@@ -1220,7 +1225,7 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         if (regular) {
             // (the four-slot kernel ranks piles from 9 points on by themselves, 2-3 x an ordinary period: a short series
             // looks for smaller piles and higher resonances -- flagging too many only reorders the queue)
-            const bool fine_piles = uniform && n <= (int64_t)tlsdev::kSlimThreads * tlsdev::kSlimPer;
+            const bool fine_piles = uniform && n <= (int64_t)tlsdev::kSlimThreadsWide * tlsdev::kSlimPer;
             const int k_max = fine_piles ? 8 : 4;
             const double a_max = (double)n / (fine_piles ? 9.0 : 48.0);       // `a` distinct phase values: piles of n / a points
             const double n_buckets = fine_piles ? 0.5 * (double)n : (double)ctx_nb_for(n, widths.size());
@@ -1286,9 +1291,16 @@ int tls_prepare(tls_ctx* ctx, const double* t, const double* y, const double* dy
         const bool slim_wanted = ctx->opt.exact_prefix != 1 && (ctx->opt.slim == 1 || (ctx->opt.slim < 0 && ctx->opt.prune < 0 && ctx->opt.screen32 < 0));
         if (uniform && slim_wanted && ctx->opt.threads <= 0) {
             const long long need = tlsdev::slim_lds_bytes((int)n, (int)M, ctx->region_pad, (int)widths.size());
+            // (a series beyond 5120 points -- 107-200 d at 30 min, two TESS sectors at 10 min --: the same kernel with 512-thread
+            // workgroups, two to a CU, where the classic kernel runs ONE 1024-thread workgroup per CU; round 6)
+            const long long need_wide = tlsdev::slim_lds_bytes((int)n, (int)M, ctx->region_pad, (int)widths.size(), tlsdev::kSlimThreadsWide);
             if (need > 0 && kSlimMinSlots * (size_t)need <= kLdsPerCU) {
-                ctx->slim_lds = (size_t)need;
+                ctx->slim_lds = (size_t)need; ctx->slim_threads = tlsdev::kSlimThreads;
                 ctx->slim_blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)std::min<size_t>(4, kLdsPerCU / (size_t)need) * ctx->n_cu);
+                if (ctx->opt.blocks > 0) ctx->slim_blocks = std::max(1, std::min(ctx->slim_blocks, ctx->opt.blocks));
+            } else if (need == 0 && need_wide > 0 && 2 * (size_t)need_wide <= kLdsPerCU) {
+                ctx->slim_lds = (size_t)need_wide; ctx->slim_threads = tlsdev::kSlimThreadsWide;
+                ctx->slim_blocks = (int)std::min<int64_t>(std::max<int64_t>(n_periods, 1), (int64_t)2 * ctx->n_cu);
                 if (ctx->opt.blocks > 0) ctx->slim_blocks = std::max(1, std::min(ctx->slim_blocks, ctx->opt.blocks));
             }
         }
@@ -1815,7 +1827,12 @@ int tls_debug_poison_lds(tls_ctx* ctx, uint32_t word) {
 int tls_debug_batch_group_ms(const tls_ctx* ctx, double* out, int64_t capacity) {
     if (!ctx) return TLS_E_ARG;
     const int64_t n = (int64_t)ctx->batch_group_ms.size();
-    if (out) for (int64_t i = 0; i < std::min(n, capacity); ++i) out[i] = ctx->batch_group_ms[(size_t)i];
+    if (out) {
+        for (int64_t i = 0; i < std::min(n, capacity); ++i) out[i] = ctx->batch_group_ms[(size_t)i];
+        // (capacity for twice the groups: the second half is the part of each group's time spent in its wait for the device)
+        const int64_t nw = (int64_t)ctx->batch_group_wait_ms.size();
+        for (int64_t i = 0; i < nw && n + i < capacity; ++i) out[n + i] = ctx->batch_group_wait_ms[(size_t)i];
+    }
     return (int)std::min<int64_t>(n, 0x7fffffff);
 }
 
@@ -2002,6 +2019,7 @@ int tls_search_batch(tls_ctx* ctx, const double* t, const double* y, const doubl
     // both streams -- asynchronous copies may still target the pinned slots and the caller's arrays -- and clears
     // the launch overrides)
     ctx->batch_group_ms.assign((size_t)n_groups, 0.0);
+    ctx->batch_group_wait_ms.clear();
     auto run = [&]() -> int {
     int rc = TLS_OK;
     for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
@@ -2163,6 +2181,7 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
     rc = TLS_OK;
     const int64_t n_groups = (n_curves + group - 1) / group;
     ctx->batch_group_ms.assign((size_t)n_groups, 0.0);
+    ctx->batch_group_wait_ms.assign((size_t)n_groups, 0.0);
     for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
         const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
         const auto group_t0 = std::chrono::steady_clock::now();
@@ -2262,7 +2281,9 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
             if (out_SR) { h_SR = h_next; h_next += (size_t)group * np; TLS_HIP(ctx, fetch_spec(h_SR, 0)); }
             if (out_power_raw) { h_praw = h_next; h_next += (size_t)group * np; TLS_HIP(ctx, fetch_spec(h_praw, 1)); }
         }
+        const auto wait_t0 = std::chrono::steady_clock::now();
         TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the ONE wait of the group
+        ctx->batch_group_wait_ms[(size_t)g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wait_t0).count();
         for (int64_t c = 0; c < gc; ++c) {
             const double* pk = h_pick + 8 * c;
             tls_power_summary& o = out_summary[c0 + c];
@@ -2373,8 +2394,11 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         // plain and screen is the noise level's)
         const long long slim_need = tlsdev::slim_lds_bytes((int)n, (int)M, tlsdev::region_pad_for(widest_stride), (int)widths.size());
         const bool slim_wanted = po.exact_prefix != 1 && (po.slim == 1 || (po.slim < 0 && po.prune < 0 && po.screen32 < 0));
-        const bool slim = resident && slim_wanted && po.threads <= 0 && slim_need > 0 && kSlimMinSlots * (size_t)slim_need <= kLdsPerCU && !prune &&
-                          !screen_pays(po, widths, sigma, params->transit_depth_min, true);
+        const bool slim_base = resident && slim_wanted && po.threads <= 0 && !prune && !screen_pays(po, widths, sigma, params->transit_depth_min, true);
+        const long long slim_need_wide = tlsdev::slim_lds_bytes((int)n, (int)M, tlsdev::region_pad_for(widest_stride), (int)widths.size(), tlsdev::kSlimThreadsWide);
+        const bool slim_narrow = slim_base && slim_need > 0 && kSlimMinSlots * (size_t)slim_need <= kLdsPerCU;
+        const bool slim_wide = slim_base && !slim_narrow && slim_need == 0 && slim_need_wide > 0 && 2 * (size_t)slim_need_wide <= kLdsPerCU;   // (512-thread shape, two to a CU)
+        const bool slim = slim_narrow || slim_wide;
         double a0, aN, b, c;
         if (!resident) { a0 = 458384.0; aN = 4.5716; b = 0.4604; c = 0.03275; }        // HBM slab variant (TESS 27 d + Kepler 4 yr)
         else if (slim) { a0 = 59538.0; aN = 0.0; b = 1.553; c = 0.2125; }               // LDS-resident, four 256-thread workgroups per CU (90 d at 50 ppm, round 5)
@@ -2403,7 +2427,7 @@ int tls_period_costs(const double* t, int64_t n, const double* periods, int64_t 
         // device is asked, a process without one plans for an MI355X), two workgroups per CU when two folded series fit
         // its LDS.  A block of n periods takes ceil(n / this) rounds, not n / this.  (The cycle coefficients above are
         // MI355X measurements; only their ratios matter.)
-        if (workgroups_in_flight) *workgroups_in_flight = (slim ? (int)std::min<size_t>(4, kLdsPerCU / (size_t)slim_need) : two_per_cu ? 2 : 1) * visible_compute_units();
+        if (workgroups_in_flight) *workgroups_in_flight = (slim_narrow ? (int)std::min<size_t>(4, kLdsPerCU / (size_t)slim_need) : slim_wide ? 2 : two_per_cu ? 2 : 1) * visible_compute_units();
     } else if (workgroups_in_flight) {
         *workgroups_in_flight = visible_compute_units();
     }

@@ -17,9 +17,14 @@
 // values differ from it by the rounding of the difference taps (chi^2 to ~1e-13).
 //
 // Reference mapping as tls_search_body.inc.h: core.py:15-18,113-188, helpers.py:70-73.
-constexpr int kSlimThreads = 256;
-constexpr int kSlimWaves = kSlimThreads / kWave;
+// Two launch shapes (round 6): 256-thread workgroups, four (three) to a CU, for series up to 5120 points; 512-thread
+// workgroups, two to a CU, for series up to 10 240 points whose region fits half the LDS (N + W <= ~9.9 k: 107-200 d at
+// 30 min, two TESS sectors at 10 min) -- the classic kernel needs two regions and runs those as ONE 1024-thread workgroup per
+// CU.  The shape is a template parameter (THREADS); a sort record holds 13 index bits for the first, 14 for the second.
+constexpr int kSlimThreads = 256;     // the smaller shape (host: the look-out for piles, the default)
+constexpr int kSlimThreadsWide = 512;
 constexpr int kSlimPer = 20;          // samples of the folded order a thread keeps in registers across the gather
+__host__ __device__ constexpr int slim_idx_bits(int threads) { return threads <= 256 ? 13 : 14; }
 constexpr int kSlimScratchBytes = 1328;   // >= sizeof(Cumsum2Scratch); the per-row tables share its first bytes
 #ifndef TLS_SLIM_TAIL_MAX
 #define TLS_SLIM_TAIL_MAX 20
@@ -35,9 +40,9 @@ constexpr int kSlimTailSingles = TLS_SLIM_TAIL_SINGLES;  // ... if that leaves a
 constexpr int kSlimBig = TLS_SLIM_BIG;            // a bucket beyond this many points (a commensurate period's pile) is ranked by the workgroup on exact phases
 constexpr int kSlimPileMembers = 3;     // members of one pile a thread ranks, at most
 constexpr int kSlimStageBytes = 2048;  // at least this much of the region stays free for the phases of such a pile
-constexpr int kSlimIdxBits = 13;      // a sort record: sub-bucket key (19 bits) | original index (13 bits)
-__host__ __device__ constexpr int slim_header_bytes() { return 128 + kSlimWaves * 24 + 48 + kSlimScratchBytes; }   // wsum | wbest | s_work | scratch
-static_assert(slim_header_bytes() % 16 == 0, "the region behind the header holds doubles read in pairs");
+// (a sort record: sub-bucket key (19 or 18 bits) | original index (13 or 14 bits))
+__host__ __device__ constexpr int slim_header_bytes(int threads) { return 128 + (threads / kWave) * 24 + 48 + kSlimScratchBytes; }   // wsum | wbest | s_work | scratch
+static_assert(slim_header_bytes(kSlimThreads) % 16 == 0 && slim_header_bytes(kSlimThreadsWide) % 16 == 0, "the region behind the header holds doubles read in pairs");
 static_assert(sizeof(Cumsum2Scratch) <= kSlimScratchBytes, "exact_cumsum's scratch does not fit the slim header");
 // sort buckets: as many as the region holds beside the records and the order, at most one per two points
 // (measured: giving the pile stage 4800 bytes at the price of 3 % fewer buckets cost the ordinary periods 2 %)
@@ -47,22 +52,22 @@ __host__ __device__ inline int slim_buckets(int n, int RS) {
     return (int)(room < want ? room : want);
 }
 // what the kernel needs of the LDS for a plan, 0 when the plan does not fit it
-__host__ __device__ inline long long slim_lds_bytes(int n, int M, int region_pad, int n_widths) {
+__host__ __device__ inline long long slim_lds_bytes(int n, int M, int region_pad, int n_widths, int threads = kSlimThreads) {
     const int RS = M + 1 + region_pad;
-    if (n > kSlimThreads * kSlimPer || n >= (1 << kSlimIdxBits) || n < 64) return 0;
+    if (n > threads * kSlimPer || n >= (1 << slim_idx_bits(threads)) || n < 64) return 0;
     if (slim_buckets(n, RS) < n / 8 || slim_buckets(n, RS) < 16) return 0;
     if (4LL * (3 * n_widths + 2) > kSlimScratchBytes) return 0;
-    return slim_header_bytes() + 8LL * RS;
+    return slim_header_bytes(threads) + 8LL * RS;
 }
 
 // The piles of a commensurate period: buckets beyond kSlimBig points whose records tie on their key bits (slim_is_pile).
 // Every member's exact phase is formed ONCE into a stage, then every member counts the members in front of it -- (phase,
 // index), numpy's stable order.  Four, two or one pile at a time (what the largest one leaves of the stage), a group of threads
 // each.  Out of line: its registers are its own (called by every thread of the workgroup: it holds barriers).
-__device__ __forceinline__ bool slim_is_pile(const unsigned int* recs, int lo, int hi, int stage_cap) {
+__device__ __forceinline__ bool slim_is_pile(const unsigned int* recs, int lo, int hi, int stage_cap, int idx_bits) {
     const int size = hi - lo;
     if (size <= kSlimBig || size > stage_cap) return false;
-    const unsigned int r0 = recs[lo] >> kSlimIdxBits, rm = recs[lo + size / 2] >> kSlimIdxBits, r1 = recs[hi - 1] >> kSlimIdxBits;
+    const unsigned int r0 = recs[lo] >> idx_bits, rm = recs[lo + size / 2] >> idx_bits, r1 = recs[hi - 1] >> idx_bits;
     return r0 == rm || rm == r1;
 }
 // (the pointers are kept in their address spaces by TYPE: through generic pointers the member loops came out as FLAT loads)
@@ -73,7 +78,7 @@ __device__ __forceinline__ __attribute__((address_space(3))) T* slim_lds_ptr(T* 
     return (lds_t)(uintptr_t)v;
 }
 __device__ __noinline__ void slim_rank_piles(const double* t_, double period_, const unsigned int* recs_, const unsigned int* cnt_,
-                                             unsigned short* perm_, double* stage_, int stage_cap_, const unsigned short* big_list_, int n_big_, int* flags_, int nb_, unsigned long long* clk_) {
+                                             unsigned short* perm_, double* stage_, int stage_cap_, const unsigned short* big_list_, int n_big_, int* flags_, int nb_, unsigned long long* clk_, int idx_bits_) {
     typedef __attribute__((address_space(1))) const double* glob_f64;
     typedef __attribute__((address_space(3))) const unsigned int* lds_u32;
     typedef __attribute__((address_space(3))) unsigned short* lds_u16;
@@ -89,7 +94,8 @@ __device__ __noinline__ void slim_rank_piles(const double* t_, double period_, c
     __attribute__((address_space(3))) int* const flags = slim_lds_ptr(flags_);
     const int stage_cap = uniform_i32(stage_cap_), n_big = uniform_i32(n_big_), nb = uniform_i32(nb_);
     const int tid = threadIdx.x, nt = blockDim.x;
-    constexpr unsigned int kIdx = (1u << kSlimIdxBits) - 1u;
+    const int idx_bits = uniform_i32(idx_bits_);
+    const unsigned int kIdx = (1u << idx_bits) - 1u;
     // the largest pile decides how many are ranked side by side, a group of threads and a share of the stage each
     // (every thread looks at its share of the list; the sizes meet in an LDS word the caller has zeroed)
 #if TLS_PHASE_CLOCKS
@@ -145,7 +151,7 @@ __device__ __noinline__ void slim_rank_piles(const double* t_, double period_, c
 #pragma unroll
         for (int a = 0; a < kMine; ++a) {
             const unsigned long long pattern = (unsigned long long)__double_as_longlong(fold_phase(ahead_t[a], period, 0.0));
-            ahead[a] = packed ? ((pattern - base) << kSlimIdxBits) | (ahead_rec[a] & kIdx) : pattern;
+            ahead[a] = packed ? ((pattern - base) << idx_bits) | (ahead_rec[a] & kIdx) : pattern;
         }
     };
     int lo = 0, m = 0, lo_next = 0, m_next = 0, b_next = 0;
@@ -216,9 +222,11 @@ __device__ __noinline__ int slim_tie_before(const double* t, double period, int 
 
 // Phase 1 of a period: fold + stable sort by phase (core.py:119-120) -> perm[k] = original index of the k-th folded point, in
 // the last 2n bytes of the region.
+template <int THREADS>
 __device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, double period, int RS, double* X, unsigned int* wsum, int* s_work,
                                                 unsigned char* scratch, PhaseClock& pc) {
-    constexpr int nt = kSlimThreads;
+    constexpr int nt = THREADS;
+    constexpr int kSlimIdxBits = slim_idx_bits(THREADS);
     const int tid = threadIdx.x;
     const int nb = slim_buckets(n, RS);
     unsigned int* recs = reinterpret_cast<unsigned int*>(X);                           // [n] sort records, bucket by bucket
@@ -304,7 +312,7 @@ __device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, doubl
                 lo[g] = b ? (int)cnt[b - 1] : 0;
                 hi[g] = i < n ? (int)cnt[b] : lo[g];
                 if (hi[g] - lo[g] > kSlimBig) {   // (rare)
-                    if (slim_is_pile(recs, lo[g], hi[g], stage_cap)) {
+                    if (slim_is_pile(recs, lo[g], hi[g], stage_cap, kSlimIdxBits)) {
                         if (recs[lo[g]] == mine[g]) heads |= 1u << (j0 + g);   // the member whose record heads the bucket lists it
                         hi[g] = lo[g];   // ranked below: nothing to do here
                     }
@@ -337,18 +345,19 @@ __device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, doubl
     {
         const int n_big = __builtin_amdgcn_readfirstlane(s_work[5]);
         pc.mark(8);
-        if (n_big > 0) slim_rank_piles(t, period, recs, cnt, perm, stage, stage_cap, big_list, n_big, &s_work[6], nb, pc.out);
+        if (n_big > 0) slim_rank_piles(t, period, recs, cnt, perm, stage, stage_cap, big_list, n_big, &s_work[6], nb, pc.out, kSlimIdxBits);
     }
 }
 
-template <bool COUNTING>
-__global__ void __launch_bounds__(kSlimThreads, 4)
+template <bool COUNTING, int THREADS = kSlimThreads>
+__global__ void __launch_bounds__(THREADS, 4)
 tls_slim_kernel(const SearchArgs) {
     constexpr bool UNIFORM_W = true;
+    constexpr int kSlimWaves = THREADS / kWave;
     args_ptr ap = (args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    constexpr int nt = kSlimThreads, nw = kSlimWaves;
+    constexpr int nt = THREADS, nw = kSlimWaves;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int n = ap->n, W = ap->W, M = ap->M;
@@ -365,11 +374,11 @@ tls_slim_kernel(const SearchArgs) {
     rt.singles = rt.live + ap->n_widths;
     rt.batch_start = rt.singles + ap->n_widths;
     rt.next_batch = rt.batch_start + (ap->n_widths + 1);
-    double* X = reinterpret_cast<double*>(smem + slim_header_bytes());                 // f, then X: RS doubles
+    double* X = reinterpret_cast<double*>(smem + slim_header_bytes(THREADS));          // f, then X: RS doubles
     unsigned short* perm = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(X) + 8LL * RS) - n;   // [n], the region's last bytes
     unsigned int* chunk_list = ap->chunk_lists + (long long)blockIdx.x * ap->list_stride;
     if (tid == 0) {
-        TLS_CHECK(*ap, slim_lds_bytes(n, M, region_pad, ap->n_widths) != 0 && slim_lds_bytes(n, M, region_pad, ap->n_widths) <= ap->lds_bytes && 6LL * n + 4LL * slim_buckets(n, RS) <= 8LL * RS, kChkLdsCarve);
+        TLS_CHECK(*ap, slim_lds_bytes(n, M, region_pad, ap->n_widths, THREADS) != 0 && slim_lds_bytes(n, M, region_pad, ap->n_widths, THREADS) <= ap->lds_bytes && 6LL * n + 4LL * slim_buckets(n, RS) <= 8LL * RS, kChkLdsCarve);
     }
     const const_width_ptr widths_c = (const_width_ptr)ap->widths;
     const const_rows_ptr rows_c = (const_rows_ptr)ap->rows;
@@ -414,14 +423,19 @@ tls_slim_kernel(const SearchArgs) {
         // the other workgroups' dot products, which fill whatever slots are left -- a latency-bound wave that waits for an
         // issue slot behind four FMAs a cycle loses more than the FMA-bound one that lets it pass.  Same box: 1.079 -> 1.046 ms
         // (the other way round: 1.103; the predicate at low priority too: 1.061).
+#ifndef TLS_SLIM_PRIO
+#define TLS_SLIM_PRIO 1
+#endif
+#if TLS_SLIM_PRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
         long long t_period = 0;
         if (ap->period_cycles && tid == 0) t_period = clock64();
         PhaseClock pc;
         pc.start(ap->phase_cycles);
 
         // ---- phase 1: fold + stable sort by phase (core.py:119-120), on 32-bit keys (slim_fold_and_sort) -------------------
-        slim_fold_and_sort(ap->t, n, period, RS, X, wsum, s_work, scratch, pc);
+        slim_fold_and_sort<THREADS>(ap->t, n, period, RS, X, wsum, s_work, scratch, pc);
         pc.mark(3);
         // survey mode: the permutation outlives the light curves of the batch in global memory
         const unsigned short* perm_g = nullptr;
@@ -735,7 +749,9 @@ tls_slim_kernel(const SearchArgs) {
 
         // ---- phase 3b: sliding dot products ON X, 64 live units of one duration per wave (core.py:59-74) ----
         {
+#if TLS_SLIM_PRIO
             __builtin_amdgcn_s_setprio(0);   // (the FMA-bound phase yields the issue slots: see the period's start)
+#endif
             const unsigned int total_batches = (unsigned int)__builtin_amdgcn_readfirstlane((int)rt.batch_start[n_rows]);
             int row = n_rows > 0 ? n_rows - 1 : 0;
             for (;;) {
@@ -802,7 +818,9 @@ tls_slim_kernel(const SearchArgs) {
                 if constexpr (COUNTING) n_steps += (unsigned long long)(n_eval - evals_before) * (unsigned long long)L;
             }
         }
+#if TLS_SLIM_PRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
         pc.mark(7);
         } else {
             // The noted windows, one wavefront each: decided by the reference's expression on X = k - numpy.cumsum; a window

@@ -18,6 +18,9 @@ CONFIGS = {
     "k2_90d": (90.0, 48, 50e-6, {}),
     "kepler_4yr": (1461.0, 48, 50e-6, {"period_min": 0.5, "period_max": 400}),
     "tess_27d": (27.0, 720, 200e-6, {}),
+    # (not a BASELINE configuration: a series between the four-slot kernel's 5120 points and the LDS-resident limit -- two
+    # Kepler quarters, two TESS sectors at 10 min -- for the 512-thread shape of that kernel; tests and probes)
+    "lc_150d": (150.0, 48, 50e-6, {}),
 }
 
 

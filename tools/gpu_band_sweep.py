@@ -1,4 +1,4 @@
-"""Developer sweep: slab-variant kernel time against tls_options::band_max (expected band hits above which a period starts
+"""Developer sweep: slab-variant kernel time against the developer switch band_max (expected band hits above which a period starts
 in exact mode), full grids and the first / last blocks of an 8-way shard."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
