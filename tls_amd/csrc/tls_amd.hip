@@ -1799,7 +1799,7 @@ __global__ void __launch_bounds__(1024) tls_poison_lds_kernel(unsigned int word,
     extern __shared__ unsigned int lds_words[];
     const unsigned int total = 160u * 1024u / 4u;
     for (unsigned int k = threadIdx.x; k < total; k += blockDim.x) lds_words[k] = word;
-    __syncthreads();
+    tlsdev::wg_sync();
     if (lds_words[(threadIdx.x * 97u) % total] != word && sink) sink[0] = 1u;   // (keeps the stores alive)
 }
 }  // namespace
@@ -2182,9 +2182,15 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
     const int64_t n_groups = (n_curves + group - 1) / group;
     ctx->batch_group_ms.assign((size_t)n_groups, 0.0);
     ctx->batch_group_wait_ms.assign((size_t)n_groups, 0.0);
+    // developer aid (TLS_AMD_STALL_DIAG set): per-period shader cycles of every group's search launch; a group whose wait
+    // exceeds a second prints where the cycles went (tools/gpu_stall_probe2.py)
+    const bool diag = std::getenv("TLS_AMD_STALL_DIAG") != nullptr;
+    DevBuf<unsigned long long> d_diag;
+    if (diag) TLS_HIP(ctx, d_diag.reserve(np));
     for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
         const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
         const auto group_t0 = std::chrono::steady_clock::now();
+        if (diag) TLS_HIP(ctx, hipMemsetAsync(d_diag.ptr, 0, np * 8, ctx->stream));
         // ---- flux of the group into the device, search (tls_search_batch's launch: fold + sort shared by the group)
         double* h_y = sl.h_in;
         double* h_w = sl.h_in + (size_t)group * nn;
@@ -2215,7 +2221,7 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         ctx->batch_curves = (int)gc;
         ctx->over_y = sl.d_y.ptr; ctx->over_w = uni ? nullptr : sl.d_w.ptr; ctx->over_S0 = sl.d_S0.ptr; ctx->over_w0 = sl.d_w0.ptr;
         ctx->over_chi2 = sl.d_chi2.ptr; ctx->over_row = sl.d_row.ptr; ctx->over_depth = sl.d_depth.ptr;
-        rc = enqueue(ctx, false);
+        rc = enqueue(ctx, false, diag, nullptr, nullptr, diag ? d_diag.ptr : nullptr);
         ctx->batch_curves = 1;
         ctx->over_y = ctx->over_w = ctx->over_S0 = ctx->over_w0 = nullptr;
         ctx->over_chi2 = nullptr; ctx->over_row = nullptr; ctx->over_depth = nullptr;
@@ -2284,6 +2290,22 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         const auto wait_t0 = std::chrono::steady_clock::now();
         TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the ONE wait of the group
         ctx->batch_group_wait_ms[(size_t)g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wait_t0).count();
+        if (diag && ctx->batch_group_wait_ms[(size_t)g] > 1000.0) {
+            std::vector<unsigned long long> cyc(np), ph(tlsdev::kPhases);
+            TLS_HIP(ctx, hipMemcpy(cyc.data(), d_diag.ptr, np * 8, hipMemcpyDeviceToHost));
+            TLS_HIP(ctx, hipMemcpy(ph.data(), ctx->d_phase.ptr, ph.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<size_t> idx(np);
+            for (size_t i = 0; i < np; ++i) idx[i] = i;
+            std::sort(idx.begin(), idx.end(), [&](size_t a_, size_t b_) { return cyc[a_] > cyc[b_]; });
+            unsigned long long total = 0;
+            for (auto c : cyc) total += c;
+            std::fprintf(stderr, "[stall diag] group %lld wait %.1f ms: period cycles total %.4g, median %llu; top:", (long long)g,
+                         ctx->batch_group_wait_ms[(size_t)g], (double)total, cyc[idx[np / 2]]);
+            for (size_t k = 0; k < std::min<size_t>(8, np); ++k) std::fprintf(stderr, " p%zu(%.6g d)=%.4g", idx[k], periods[idx[k]], (double)cyc[idx[k]]);
+            std::fprintf(stderr, "\n[stall diag] phases:");
+            for (size_t k = 0; k < ph.size(); ++k) if (ph[k]) std::fprintf(stderr, " %zu:%.4g", k, (double)ph[k]);
+            std::fprintf(stderr, "\n");
+        }
         for (int64_t c = 0; c < gc; ++c) {
             const double* pk = h_pick + 8 * c;
             tls_power_summary& o = out_summary[c0 + c];

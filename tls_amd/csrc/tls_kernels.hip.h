@@ -269,6 +269,19 @@ __device__ __forceinline__ T* global_arg(T* p) {
     return (T*)(glob_t)(uintptr_t)(((unsigned long long)hi << 32) | lo);
 }
 
+// The workgroup barrier of every kernel here: __syncthreads() with the wait for the wave's own LDS operations written out.
+// hipcc (ROCm 7.2, gfx950) drops the `s_waitcnt lgkmcnt(0)` of __syncthreads()'s release fence in front of some s_barriers
+// whose wave still has a ds_write in flight (seen in the ISA of tls_slim_kernel: the store of a row's counts at the end of a
+// loop, the barrier behind the loop's exit, no wait between them) -- the waves of a workgroup sit on different SIMDs, each with
+// its own queue to the LDS, and a read issued behind the barrier by another wave can overtake that write.  Round 6 met it as
+// a stale batch count: one period in ~3e6 spun through 2^26 empty batches, tens of seconds (PERF_LOG "the stalled group").
+__device__ __forceinline__ void wg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // Workgroup barrier that orders LDS traffic only: the LDS operations of every wave are complete, global
 // loads and stores STAY IN FLIGHT across it.  __syncthreads() also drains the vector-memory counter,
 // i.e. every barrier between two LDS steps would expose a full HBM round trip of whatever was
@@ -618,11 +631,11 @@ __device__ __forceinline__ void block_exclusive_scan(unsigned int* cnt, int nb, 
     for (int b = lo; b < hi; ++b) local += cnt[b];
     const unsigned int incl = wave_inclusive_sum_u32(local);
     if (lane == kWave - 1) wsum[wave] = incl;
-    __syncthreads();
+    wg_sync();
     unsigned int run = incl - local;
     for (int v = 0; v < wave; ++v) run += wsum[v];
     for (int b = lo; b < hi; ++b) { unsigned int c = cnt[b]; cnt[b] = run; run += c; }
-    __syncthreads();
+    wg_sync();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -787,7 +800,7 @@ __device__ __forceinline__ void sequential_cumsum_by_binade(const double* f, dou
     const int lane = tid & (kWave - 1), nw = nt / kWave;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     if (tid == 0) { C[k_a0] = s_a; cs->state_s = s_a; cs->state_k = k_a0; }
-    __syncthreads();
+    wg_sync();
     constexpr int kMaxPerThread = 8;
     for (;;) {
         const int k_a = cs->state_k;
@@ -814,7 +827,7 @@ __device__ __forceinline__ void sequential_cumsum_by_binade(const double* f, dou
             if (lane >= dlt) inc = compose(o, inc);
         }
         if (lane == kWave - 1) cs->wave_tot[wave] = inc;
-        __syncthreads();
+        wg_sync();
         ParityInc pre; pre.i0 = 0; pre.i1 = 0;
         for (int v = 0; v < wave; ++v) pre = compose(pre, cs->wave_tot[v]);
         ParityInc excl;
@@ -838,7 +851,7 @@ __device__ __forceinline__ void sequential_cumsum_by_binade(const double* f, dou
             my_cross = o < my_cross ? o : my_cross;
         }
         if (lane == 0) cs->cross[wave] = my_cross;
-        __syncthreads();
+        wg_sync();
         if (tid == 0) {
             int k_c = cs->cross[0];
             for (int v = 1; v < nw; ++v) k_c = cs->cross[v] < k_c ? cs->cross[v] : k_c;
@@ -852,7 +865,7 @@ __device__ __forceinline__ void sequential_cumsum_by_binade(const double* f, dou
                 cs->state_k = k_b;
             }
         }
-        __syncthreads();
+        wg_sync();
     }
 }
 
@@ -902,7 +915,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             if (lane >= dlt) incl += o;
         }
         if (lane == kWave - 1) cs->dtot[wave] = incl;
-        __syncthreads();
+        wg_sync();
         {
             double run = s0;
             for (int v = 0; v < wave; ++v) run += cs->dtot[v];
@@ -910,7 +923,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             for (int k = lo; k < hi; ++k) { C[k] = run; run += f[k]; }
             if (hi == kb && lo < hi) C[kb] = run;
         }
-        __syncthreads();
+        wg_sync();
         cpc.mark(14);
         // ---- B1: predicted binade changes and their running count ----
         unsigned int crossmask = 0;   // bit e: element lo+e changes the binade (or opens the block)
@@ -932,7 +945,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             if (lane >= dlt) cnt_incl += o;
         }
         if (lane == kWave - 1) cs->cross[wave] = cnt_incl;
-        __syncthreads();
+        wg_sync();
         int cnt_pre = cnt_incl - n_cross_local;
         int n_seg = 0;
         for (int v = 0; v < nw; ++v) { const int c = cs->cross[v]; n_seg += c; if (v < wave) cnt_pre += c; }
@@ -979,7 +992,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
         }
         int* const wave_end_m = reinterpret_cast<int*>(cs->dtot);   // dtot is idle since the end of phase A
         if (lane == kWave - 1) { cs->seg_tot[wave] = inc; wave_end_m[wave] = m_hi; }
-        __syncthreads();
+        wg_sync();
         // prefix over the wave totals: every wave scans them itself (lane v holds wave v's total), a
         // log-step scan instead of a chain of up to 15 dependent LDS reads and combines
         SegAcc pre; pre.map.i0 = 0.0; pre.map.i1 = 0.0; pre.cnt = 0; pre.reset = 0;
@@ -1027,7 +1040,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
                 cs->tab_T[j_in] = compose(pre.map, head, b_lo);
             }
         }
-        __syncthreads();
+        wg_sync();
         cpc.mark(17);
         // ---- D: wave 0 chains the binade changes in fp64 and verifies the prediction ----
         // Inside a verified binade the whole segment behind change j adds the step t_j (chosen by the
@@ -1082,7 +1095,7 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
             if (lane < ok) cs->tab_S[lane] = keep_new;
             if (lane == 0) { cs->n_ok = ok; cs->fail_k = fail_k; cs->fail_s = fail_s; }
         }
-        __syncthreads();
+        wg_sync();
         cpc.mark(18);
         // ---- E: exact values of every element inside a verified segment ----
         {
@@ -1106,16 +1119,16 @@ __device__ __forceinline__ void exact_sequential_cumsum(const double* f, double*
                 }
             }
         }
-        __syncthreads();
+        wg_sync();
         cpc.mark(19);
         const int fail_k = cs->fail_k;
         const double fail_s = cs->fail_s;
-        __syncthreads();
+        wg_sync();
         if (dbg && tid == 0) { atomicAdd(&dbg[10], 1ull); if (fail_k < kb) atomicAdd(&dbg[11], 1ull); }
         if (fail_k < kb) sequential_cumsum_by_binade(f, C, fail_k, kb, fail_s, cs);
         k0 = kb;
         s0 = C[kb];
-        __syncthreads();
+        wg_sync();
     }
 }
 
@@ -1404,14 +1417,14 @@ __device__ __forceinline__ double exact_cumsum_block_inline(const double* f, dou
     }
 #endif
     if (failed) {
-        __syncthreads();                            // everybody has read the scratch: its slot is reused below
+        wg_sync();                            // everybody has read the scratch: its slot is reused below
         if constexpr (ALIASED) {
 #pragma unroll
             for (int e = 0; e < PER; ++e) if (e < mine) const_cast<double*>(f)[lo + e] = x[e];
-            __syncthreads();
+            wg_sync();
         }
         sequential_cumsum_by_binade(f, C, k0, kb, s0, reinterpret_cast<CumsumScratch*>(cs));
-        __syncthreads();
+        wg_sync();
         return C[kb];
     }
     return s_end;
@@ -2225,7 +2238,7 @@ __device__ __forceinline__ void sort_big_bucket(const double* ph_orig, IdxT* idx
                                                 IdxT* out) {
     const int tid = WAVE ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
     const int nt = WAVE ? kWave : (int)blockDim.x;
-    auto step_sync = [&]() { if constexpr (WAVE) wave_sync(); else __syncthreads(); };
+    auto step_sync = [&]() { if constexpr (WAVE) wave_sync(); else wg_sync(); };
     if constexpr (STAGED) {
         for (int j = tid; j < m; j += nt) { const unsigned int i = (unsigned int)idx_seg[j]; idx_l[j] = i; key_l[j] = ph_orig[i]; }
     }
@@ -2278,7 +2291,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
     // from idx_tmp in global memory while other waves reorder that segment need not be the same for every reader)
     if (tid == 0 && big_cap > 0) big_list[0] = 0u;
     const int list_slots = (big_cap - 1) / 2;
-    __syncthreads();
+    wg_sync();
     {
         // kF time stamps per step: their L2 round trips overlap (the compiler keeps a global load behind the LDS atomic
         // of the step before it)
@@ -2298,7 +2311,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
             }
         }
     }
-    __syncthreads();
+    wg_sync();
     pc.mark(0);
     block_exclusive_scan(cnt, nb, wsum);
     pc.mark(1);
@@ -2307,7 +2320,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
         unsigned int slot = atomicAdd(&cnt[b], 1u);  // arbitrary order inside a bucket...
         idx_tmp[slot] = (IdxT)i;
     }
-    __syncthreads();
+    wg_sync();
     pc.mark(2);
     // ...made deterministic here: rank by (phase, original index) inside the bucket.
     // cnt[b] now holds the END of bucket b.
@@ -2348,7 +2361,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
         }
         perm[lo + rank] = (IdxT)i;
     }
-    __syncthreads();
+    wg_sync();
     if (big_cap > 0) {
         const int n_big_all = (int)big_list[0];
         const int n_big = n_big_all < list_slots ? n_big_all : list_slots;
@@ -2361,7 +2374,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
                 const int m = __builtin_amdgcn_readfirstlane((int)big_list[2 + 2 * q]);
                 if (m <= kWaveSortMax) sort_big_bucket<IdxT, false, true>(ph_orig, idx_tmp + lo, m, nullptr, nullptr, perm + lo);
             }
-            __syncthreads();
+            wg_sync();
             for (int q = 0; q < n_big; ++q) {
                 const int lo = (int)big_list[1 + 2 * q];
                 const int m = (int)big_list[2 + 2 * q];
@@ -2396,7 +2409,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
                         const unsigned int i = (unsigned int)idx_tmp[lo_b[g] + j];
                         stage_idx[off_b[g] + j] = i; stage_key[off_b[g] + j] = ph_orig[i];
                     }
-                __syncthreads();
+                wg_sync();
                 const int half_pairs = (1 << lg_max) >> 1;
                 auto exchange = [&](int g, int x, int y) {
                     if (y >= m_b[g]) return;
@@ -2413,19 +2426,19 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
                         const int blk = ii >> lh, pos = ii & ((1 << lh) - 1);
                         exchange(g, (blk << lk) + pos, (blk << lk) + ((1 << lk) - 1 - pos));
                     }
-                    __syncthreads();
+                    wg_sync();
                     for (int lj = lk - 2; lj >= 0; --lj) {
                         for (int i = tid; i < count * half_pairs; i += nt) {
                             const int g = i >> (lg_max - 1), ii = i & (half_pairs - 1);
                             const int x = ((ii >> lj) << (lj + 1)) + (ii & ((1 << lj) - 1));
                             exchange(g, x, x + (1 << lj));
                         }
-                        __syncthreads();
+                        wg_sync();
                     }
                 }
                 for (int g = 0; g < count; ++g)
                     for (int j = tid; j < m_b[g]; j += nt) perm[lo_b[g] + j] = (IdxT)stage_idx[off_b[g] + j];
-                __syncthreads();
+                wg_sync();
                 q0 += count;
             }
         }
@@ -2449,7 +2462,7 @@ __device__ __forceinline__ void fold_and_sort(const double* t, int n, double per
                 }
                 perm[lo + rank] = (IdxT)i;
             }
-            __syncthreads();
+            wg_sync();
         }
     }
     pc.mark(3);
@@ -2540,7 +2553,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
 
     // ---- counts per coarse bin ------------------------------------------------------------------
     for (int b = tid; b <= B; b += nt) { g_start[b] = 0; l_cnt[b] = 0; }
-    __syncthreads();
+    wg_sync();
     for (int i0 = 0; i0 < n; i0 += 8 * nt) {   // eight time stamps in flight per thread; whole waves take part
         double tv[8];
 #pragma unroll
@@ -2549,7 +2562,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
         for (int j = 0; j < 8; ++j)
             bin_inc<false>(g_start, i0 + tid + j * nt < n ? bucket_of(fold_phase(tv[j], period, epoch), B_d, B) : -1);
     }
-    __syncthreads();
+    wg_sync();
     // exclusive scan over the bins by wave 0 (B <= 1024: 16 per lane), and the overflow test
     if (wave == 0) {
         const int per = (B + kWave - 1) / kWave;
@@ -2572,7 +2585,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
         if (lane == kWave - 1) g_start[B] = run;
         if (lane == 0) g_cur[B] = biggest;   // parked here for everybody to read
     }
-    __syncthreads();
+    wg_sync();
     // A bin beyond a wavefront's window (phases piled up: a period commensurate with the cadence folds a regularly sampled
     // series onto P / cadence phase values) is skipped by pass 2 and sorted by the WORKGROUP afterwards, in the staging
     // area of pass 1: exact phase and index of every point side by side, a bitonic network on (phase, index) -- the order
@@ -2580,7 +2593,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
     // fewer than ~9 cadences on a Kepler-size series) still sends the period to the general sort.
     const unsigned int biggest_bin = g_cur[B];
     const int stage_pts = (int)((kPerStage * nt < kSort2Chunk ? kPerStage * nt : kSort2Chunk) * 10LL / 12);   // 12 B a point
-    if (biggest_bin > (unsigned int)stage_pts) { __syncthreads(); return false; }
+    if (biggest_bin > (unsigned int)stage_pts) { wg_sync(); return false; }
     pc.mark(0);
 
     // ---- pass 1: partition, one chunk of points per round ---------------------------------------
@@ -2639,7 +2652,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
             lds_barrier();
         }
     }
-    __syncthreads();   // (the barriers inside the rounds order LDS only: the partitioned points are in memory HERE)
+    wg_sync();   // (the barriers inside the rounds order LDS only: the partitioned points are in memory HERE)
     pc.mark(2);
 
     // ---- pass 2: one coarse bin per wavefront, sorted inside its LDS window -----------------------
@@ -2814,15 +2827,15 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
             wave_lds_sync();
         }
     }
-    __syncthreads();
+    wg_sync();
     if (biggest_bin > (unsigned int)kSort2BinCap) {
         // ---- the piled-up bins, by the whole workgroup ------------------------------------------------
         unsigned int* big_list = l_cnt;   // [0] count, then the bins (pass 1's chunk counters are idle; l_start follows them: 2 (B + 1) words)
         if (tid == 0) big_list[0] = 0u;
-        __syncthreads();
+        wg_sync();
         for (int b = tid; b < B; b += nt)
             if (g_start[b + 1] - g_start[b] > (unsigned int)kSort2BinCap) big_list[1 + atomicAdd(&big_list[0], 1u)] = (unsigned int)b;
-        __syncthreads();
+        wg_sync();
         const int n_big = (int)big_list[0];
         double* stage_key = reinterpret_cast<double*>(area);
         unsigned int* stage_idx = reinterpret_cast<unsigned int*>(stage_key + stage_pts);
@@ -2857,7 +2870,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                 if ((unsigned int)j < m) { i = (unsigned int)g_rec[first + j]; key = fold_phase(t[i], period, epoch); }
                 stage_idx[x] = i; stage_key[x] = key;
             }
-            __syncthreads();   // (also: every record of the run has been read -- f_out may be g_rec)
+            wg_sync();   // (also: every record of the run has been read -- f_out may be g_rec)
             const int limit = padded ? total : stage_pts;   // entries that exist
             auto exchange4 = [&](int x0, int x1, int x2, int x3, int d0, int d1, int d2, int d3, int valid) {
                 // four independent compare-exchanges (x, x + d): all reads first, then the stores
@@ -2917,7 +2930,7 @@ __device__ __forceinline__ bool fold_and_sort_tiled(const double* t, int n, doub
                     if constexpr (HAS_W) { if (y_gather) w_out_g[first + j] = w_gather[i]; }
                 }
             }
-            __syncthreads();
+            wg_sync();
             q0 += count;
         }
     }
@@ -3023,7 +3036,7 @@ __device__ __noinline__ void slab_exact_prefix_call(global_ptr<const double> f_,
         lds_barrier();
     }
     for (int k = tid; k < region_pad; k += nt) regB[M + 1 + k] = -(double)(k + 1) * 1.0e300;
-    __syncthreads();
+    wg_sync();
 }
 
 typedef const __attribute__((address_space(4))) SearchArgs* args_ptr;
@@ -3065,7 +3078,7 @@ tls_fold_search_kernel(const SearchArgs) {
         constexpr int ROLE = kRoleFold;
 #include "tls_search_body.inc.h"
     }
-    __syncthreads();
+    wg_sync();
     {
         constexpr bool RESIDENT = false, UNIFORM_W = UNI_, WITH_PRUNING = false, COUNTING = COUNT_, SCREEN = false;
         typedef unsigned int IdxT;
@@ -3150,7 +3163,7 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a0) {
     // its round trip per epoch)
     for (int work = blockIdx.x; work < a.n_epochs; work += gridDim.x) {
         if (tid == 0) { s_work[1] = 0; s_work[2] = 0; }
-        __syncthreads();
+        wg_sync();
         const double epoch = a.epochs[work];
         int start = 0;          // sorted position k holds the kept order's entry (k + start) mod n
         bool rotated = false;
@@ -3203,10 +3216,10 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a0) {
                     }
                 }
                 if (descents) { atomicAdd(&s_work[1], descents); s_work[2] = where; }
-                __syncthreads();
+                wg_sync();
                 rotated = s_work[1] == 1 || n < 2;
                 start = n < 2 ? 0 : s_work[2];
-                __syncthreads();
+                wg_sync();
             }
         }
         if (!rotated) {
@@ -3214,7 +3227,7 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a0) {
             fold_and_sort<IdxT>(a.t, n, a.period, epoch, regA, cnt, a.nb, idx_tmp, perm, wsum, pc,
                                 reinterpret_cast<unsigned int*>(wred), 2 * kMaxWaves);
             for (int k = tid; k < n; k += nt) regA[k] = a.y[(int)perm[k]];   // phases are dead
-            __syncthreads();
+            wg_sync();
             have_base = RESIDENT;   // (series in HBM: the sort's scratch is shared with the order; every epoch sorts)
             start = 0;
         }
@@ -3232,13 +3245,13 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a0) {
 #pragma unroll
         for (int dlt = kWave / 2; dlt > 0; dlt >>= 1) acc += __shfl_down(acc, dlt, kWave);
         if (lane == 0) wred[wave] = acc;
-        __syncthreads();
+        wg_sync();
         if (tid == 0) {
             double tot = 0.0;
             for (int v = 0; v < nw; ++v) tot += wred[v];
             a.residuals[work] = tot;
         }
-        __syncthreads();
+        wg_sync();
     }
 }
 
@@ -3274,15 +3287,15 @@ __device__ __forceinline__ double block_reduce(double v, Op op, double* red /* L
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nw = blockDim.x / kWave;
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) v = op(v, __shfl_down(v, d, kWave));
-    __syncthreads();
+    wg_sync();
     if (lane == 0) red[wave] = v;
-    __syncthreads();
+    wg_sync();
     if (threadIdx.x == 0) {
         double r = red[0];
         for (int k = 1; k < nw; ++k) r = op(r, red[k]);
         red[kMaxWaves] = r;
     }
-    __syncthreads();
+    wg_sync();
     return red[kMaxWaves];
 }
 
@@ -3331,7 +3344,7 @@ __global__ void __launch_bounds__(256) tls_spectra_median(const SpectraArgs a0) 
     // a window that holds a NaN has no candidate of the right rank (every comparison is false): its median is NaN,
     // as numpy.median's (helpers.py:96)
     for (int i = tid; i < kMedianWindows; i += nt) med[i] = __longlong_as_double(0x7ff8000000000000LL);
-    __syncthreads();
+    wg_sync();
     for (int pair = tid; pair < windows * k; pair += nt) {
         const int i = pair / k, j = pair - i * k;
         const double* x = w + i;
@@ -3340,7 +3353,7 @@ __global__ void __launch_bounds__(256) tls_spectra_median(const SpectraArgs a0) 
         for (int l = 0; l < k; ++l) rank += (x[l] < xj || (x[l] == xj && l < j)) ? 1 : 0;
         if (rank == k / 2) med[i] = xj;   // exactly one candidate of a window has this rank
     }
-    __syncthreads();
+    wg_sync();
     // helpers.py:100-108: the medians sit in the middle, the first/last one pads the edges
     const int missing = n - n_med, front = (int)((double)missing * 0.5);
     for (int i = tid; i < windows; i += nt) a.power[front + first + i] = a.power_raw[front + first + i] - med[i];   // stats.py:120
@@ -3411,9 +3424,9 @@ __global__ void __launch_bounds__(1024) tls_power_pick(const PickArgs a) {
             const bool take = want_min ? (ov < v || (ov == v && oi < i)) : (ov > v || (ov == v && oi < i));
             if (take) { v = ov; i = oi; }
         }
-        __syncthreads();
+        wg_sync();
         if (lane == 0) { red_v[wave] = v; red_i[wave] = i; }
-        __syncthreads();
+        wg_sync();
         if (tid == 0) {
             for (int w = 1; w < nw; ++w) {
                 const double ov = red_v[w]; const int oi = red_i[w];
@@ -3422,7 +3435,7 @@ __global__ void __launch_bounds__(1024) tls_power_pick(const PickArgs a) {
             }
             red_i[0] = i; red_v[0] = v;
         }
-        __syncthreads();
+        wg_sync();
         return red_i[0];
     };
     const int best = reduce_first(vmin, imin, true);
@@ -3464,7 +3477,7 @@ __global__ void __launch_bounds__(1024) tls_first_min(const FirstMinArgs a) {
         if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
     }
     if (lane == 0) { red_v[wave] = v; red_i[wave] = i; }
-    __syncthreads();
+    wg_sync();
     if (tid == 0) {
         for (int w = 1; w < nw; ++w) if (red_v[w] < v || (red_v[w] == v && red_i[w] < i)) { v = red_v[w]; i = red_i[w]; }
         a.T0[c] = (v < INFINITY && i < n) ? a.epochs[c * a.stride + i] : 0.0;
@@ -3518,7 +3531,7 @@ __global__ void __launch_bounds__(256) tls_power_prep(const PrepArgs a) {
         a.n_epochs[c] = points;
         s_k = k_row; s_points = points;
     }
-    __syncthreads();
+    wg_sync();
     const int points = s_points;
     if (points == 0) return;
     const int dur = a.widths[s_k].q_len;
@@ -3532,7 +3545,7 @@ __global__ void __launch_bounds__(256) tls_power_prep(const PrepArgs a) {
         asm volatile("" : "+v"(prod));   // two roundings, like numpy's arange * step + start: the product must not fuse into the sum
         ep[i] = prod + a.t_min;
     }
-    __syncthreads();
+    wg_sync();
     if (tid == 0) ep[points - 1] = s_stop;
 }
 

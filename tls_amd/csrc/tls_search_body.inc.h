@@ -100,9 +100,9 @@
         // ---- fetch the next period from the queue ----------------------------------
         if (!retry_exact) {
             if (tid == 0) { s_work[0] = (int)atomicAdd(ap->queue + (ROLE == kRoleSearch ? 2 : 0), 1u); s_work[1] = 0; s_work[2] = 0; s_work[4] = 0; }
-            __syncthreads();
+            wg_sync();
             work_raw = __builtin_amdgcn_readfirstlane(s_work[0]);
-            __syncthreads();
+            wg_sync();
         } else if (tid == 0) {
             s_work[1] = 0; s_work[2] = 0;   // (published by the barriers of the sort, long before any thread may raise them again)
         }
@@ -163,7 +163,7 @@
                 while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(16);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
-            __syncthreads();
+            wg_sync();
         }
         const int p = ap->order[work];
         TLS_CHECK(*ap, p >= 0 && p < ap->n_periods, kChkWorkItem);
@@ -241,7 +241,7 @@
             IdxT* perm_g = reinterpret_cast<IdxT*>(ap->perm_scratch + (long long)blockIdx.x * n);
             for (int k = tid; k < n; k += nt) perm_g[k] = perm[k];
             perm_use = perm_g;
-            __syncthreads();
+            wg_sync();
         }
         for (int curve = 0; curve < ap->n_curves; ++curve) {
         const bool exact_mode = period_exact || curve_exact;
@@ -290,10 +290,10 @@
 #pragma unroll
             for (int g = 0; g < kG; ++g) if (k0 + g * nt < n) regA[k0 + g * nt] = v[g];
         }
-        __syncthreads();
+        wg_sync();
         if (ap->debug_folded && curve == 0) {   // test entry: the folded flux as the sort left it (core.py:120-123)
             for (int k = tid; k < n; k += nt) ap->debug_folded[(long long)p * n + k] = regA[k];
-            __syncthreads();
+            wg_sync();
         }
         // ---- phase 2: patch (core.py:126-132) and sequential cumsum ----------------
         if (RESIDENT) {   // (the slab keeps the folded series once; its patch is an index mapping)
@@ -310,7 +310,7 @@
                 if constexpr (!UNIFORM_W) regW[M] = 0.0;
             }
         }
-        __syncthreads();
+        wg_sync();
         pc.mark(4);
 
         }   // (search role: the fold kernel has done it)
@@ -418,11 +418,11 @@
         // sentinels FALL (-k * 1e300 at index M + k) so that a window whose both ends lie in the
         // sentinels (possible for widths below kR) still sees a huge negative sum.
         for (int k = tid; k < region_pad; k += nt) regB[M + 1 + k] = -(double)(k + 1) * 1.0e300;
-        __syncthreads();
+        wg_sync();
         if (ap->debug_prefix && curve == 0) {   // test entry: C as numpy.cumsum gives it (helpers.py:72); exact mode is forced
             if constexpr (RESIDENT) { for (int k = tid; k <= M; k += nt) ap->debug_prefix[(long long)p * (M + 1) + k] = regB[k]; }
             else { for (int k = tid; k <= M; k += nt) ap->debug_prefix[(long long)p * (M + 1) + k] = (double)k - regB[k]; }
-            __syncthreads();
+            wg_sync();
         }
         pc.mark(5);
         }   // (search role: X is in the period's slab)
@@ -433,7 +433,7 @@
             // L2; ONE lane writes the L2's dirty lines back, waits, and only then raises the flag.  Measured alternatives:
             // every thread fencing -- +30 %; write-through (`sc1`) stores of the slab's final content, 8 bytes a lane, so
             // that the write-back finds nothing -- Kepler-size sample 6.33 instead of 5.43 ms, the stores themselves slow down)
-            __syncthreads();
+            wg_sync();
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -453,7 +453,7 @@
                 }
             }
         }
-        __syncthreads();
+        wg_sync();
         pc.mark(8);
         // fp32 screen: the samples leave their fp64 form -- high halves twice in LDS (hi[k] and, one sample later, hi1[k] =
         // hi[k + 1]: a lane reads PAIRS of samples with 8-byte-aligned ds_read_b64 whatever the parity of its first
@@ -535,7 +535,7 @@
         if constexpr (!RESIDENT) {
             double* tile_e = reinterpret_cast<double*>(smem + ap->hdr_bytes);
             const int staged = ap->tile_len + ap->tile_halo;
-            __syncthreads();  // the previous tile (or the sort histogram) is no longer read
+            wg_sync();  // the previous tile (or the sort histogram) is no longer read
             pc.mark(20);
             {
                 // no room for C beside the samples: the predicate pass gets C in the samples' place
@@ -566,7 +566,7 @@
             }
             for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;
             if (tid == 0) s_work[3] = 0;
-            __syncthreads();
+            wg_sync();
             pc.mark(12);
         }
 
@@ -774,7 +774,7 @@
             // for the next ticket, the other 63 lanes took the row again, for ever)
             if (ROLE != kRoleAll || lane == 0) rt.live[k - k_lo] = n_listed;
         }
-        __syncthreads();
+        wg_sync();
         pc.mark(9);
         if constexpr (!RESIDENT) {
             // a tile in which no cell passed the depth predicate has nothing to evaluate: its samples are
@@ -782,7 +782,7 @@
             unsigned int tile_live = 0;
 #pragma unroll 1
             for (int row = 0; row < n_rows; ++row) tile_live += rt.live[row];
-            if (__builtin_amdgcn_readfirstlane((int)tile_live) == 0) { __syncthreads(); continue; }
+            if (__builtin_amdgcn_readfirstlane((int)tile_live) == 0) { wg_sync(); continue; }
         }
         // Uniform weights, fast mode with X formed at staging time: the dot products are evaluated ON X -- summation by
         // parts, sum_j q_j e_{i+j} = sum_{j<=L} g_j X_{i+j} with the difference taps g (host: L.g) --, so the tile keeps its X
@@ -819,7 +819,7 @@
             e_base = tile_e - p_lo;
             w_base = tile_w - p_lo;
             c_base = regB;
-            __syncthreads();
+            wg_sync();
             pc.mark(12);
           }
         }
@@ -907,7 +907,7 @@
                         if (lane == 0) P2[b + 1] = acc;
                     }
                 }
-                __syncthreads();
+                wg_sync();
                 if (wave == 0) {    // inclusive scan of at most kP2MaxBlocks block sums
                     const int per = (p2_blocks + kWave - 1) / kWave;
                     const int lo = lane * per < p2_blocks ? lane * per : p2_blocks;
@@ -922,7 +922,7 @@
                     if (lane == 0) P2[0] = 0.0;
                 }
             }
-            __syncthreads();
+            wg_sync();
             p2_blocks = (M + (1 << ap->p2_shift) - 1) >> ap->p2_shift;
             n_groups = __builtin_amdgcn_readfirstlane((int)rt.batch_start[n_rows]);
             pc.mark(22);
@@ -1058,7 +1058,7 @@
 #pragma unroll
             for (int delta = kWave / 2; delta > 0; delta >>= 1) mstat = fmin(mstat, __shfl_down(mstat, delta, kWave));
             if (lane == 0) wbest[wave].stat = mstat;   // wbest is idle until phase 4
-            __syncthreads();
+            wg_sync();
             double g = wbest[0].stat;
             for (int v = 1; v < nw; ++v) g = fmin(g, wbest[v].stat);
             T = lane_value(-g, 0);                     // uniform (scalar registers); -inf while nothing has been evaluated
@@ -1111,10 +1111,10 @@
                 }
             }
             }
-            __syncthreads();
+            wg_sync();
             for (int r2 = tid; r2 < n_rows; r2 += nt) { rt.live[r2] = rt.singles[r2]; rt.singles[r2] = 0; }
             active_list = kept_list;
-            __syncthreads();
+            wg_sync();
         }
         // Per row: (5b) re-list SPARSE rows.  A handful of
         // live chunks would still occupy a whole 64-lane batch with kR FMAs per tap, so such rows
@@ -1178,7 +1178,7 @@
             if (lane == 0) { rt.live[row] = (unsigned int)n_live; rt.singles[row] = count; }
         }
         pc.mark(25);
-        __syncthreads();
+        wg_sync();
         if (wave == 0) {  // exclusive scan of the batch counts over the rows
             unsigned int carry = 0;
             for (int r0 = 0; r0 < n_rows; r0 += kWave) {
@@ -1205,7 +1205,7 @@
                 atomicAdd(&ap->phase_cycles[35], (unsigned long long)carry);
             }
         }
-        __syncthreads();
+        wg_sync();
         pc.mark(6);
 
         // ---- phase 3b: sliding dot products, 64 live units of one duration per wave ----
@@ -1459,7 +1459,7 @@
             for (int delta = kWave / 2; delta > 0; delta >>= 1) u_min = fmin(u_min, __shfl_down(u_min, delta, kWave));
             if (lane == 0) reinterpret_cast<double*>(wsum)[wave] = u_min;
         }
-        __syncthreads();
+        wg_sync();
         const int any_undecided = __builtin_amdgcn_readfirstlane(s_work[flag_slot]);
         if (tid == 0) s_work[3 - flag_slot] = 0;   // the next attempt's flag: nobody touches it before several barriers from now
         flag_slot = 3 - flag_slot;
@@ -1495,7 +1495,7 @@
             for (int v = 1; v < nw; ++v) U = fmin(U, reinterpret_cast<const double*>(wsum)[v]);
             // the slot cells that reach it join the parked ones; then every wavefront takes its share of the list
             if (scr_slot.hi < INFINITY && scr_slot.lo <= U) park_cell(lead, scr_slot.lo, scr_slot.k, scr_slot.i, rule, widths_c, regB, scr_env);
-            __syncthreads();
+            wg_sync();
             const int n_parked = (int)(scr_env.park->n < (unsigned int)kParkCap ? scr_env.park->n : (unsigned int)kParkCap);
             // (one wavefront values them, one after the other: a period has one or two that still reach U; the others wait
             // at phase 4's barrier.  The list is read 64 cells at a time, one per lane.)
@@ -1526,7 +1526,7 @@
             if (better(o, best)) best = o;
         }
         if (lane == 0) wbest[wave] = best;
-        __syncthreads();
+        wg_sync();
         if (tid == 0) {
             Best g = wbest[0];
             for (int v = 1; v < nw; ++v) if (better(wbest[v], g)) g = wbest[v];
@@ -1602,7 +1602,7 @@
             }
             if (lane == 0 && n_issued) atomicAdd(&ap->counters[2], n_issued * kWave);
         }
-        __syncthreads();
+        wg_sync();
         }  // light curves of the batch
         if (ap->period_cycles && tid == 0) atomicAdd(&ap->period_cycles[p], (unsigned long long)(clock64() - t_period));
         // (a retry re-enters the period loop with the same work item)

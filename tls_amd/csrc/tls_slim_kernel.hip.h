@@ -110,7 +110,7 @@ __device__ __noinline__ void slim_rank_piles(const double* t_, double period_, c
         m_mine = max(m_mine, (int)cnt[b] - (b ? (int)cnt[b - 1] : 0));
     }
     if (m_mine) __hip_atomic_fetch_max(flags, m_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __syncthreads();
+    wg_sync();
     const int m_max = __builtin_amdgcn_readfirstlane(*flags);
     // as many piles side by side as the largest leaves room for: its members fit the group's share of the stage and its
     // threads' registers (a round is a chain of dependent round trips whatever it ranks: few rounds matter more than wide groups)
@@ -240,7 +240,7 @@ __device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, doubl
     // order) for the pairs whose 19 bits tie: two phases within 2^-30, or the piled-up phases of a commensurate period.
     for (int b = tid; b < nb; b += nt) cnt[b] = 0;
     if (tid == 0) { s_work[5] = 0; s_work[6] = 0; }
-    __syncthreads();
+    wg_sync();
     unsigned int key[kSlimPer];
     {
         // every time stamp of the thread is requested before the first is used: ONE L2 round trip per period, not one per
@@ -264,7 +264,7 @@ __device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, doubl
             }
         }
     }
-    __syncthreads();
+    wg_sync();
     pc.mark(0);
     block_exclusive_scan(cnt, nb, wsum);
     pc.mark(1);
@@ -276,7 +276,7 @@ __device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, doubl
             recs[slot] = ((key[j] * (unsigned int)nb) & ~((1u << kSlimIdxBits) - 1u)) | (unsigned int)i;
         }
     }
-    __syncthreads();
+    wg_sync();
     pc.mark(2);
     // piles: a period commensurate with the cadence folds the series onto a few dozen phase values; ranking a pile record
     // by record would be quadratic in exact-phase comparisons (two divisions each).  A bucket beyond kSlimBig points whose
@@ -341,7 +341,7 @@ __device__ __forceinline__ void slim_fold_and_sort(const double* t, int n, doubl
             }
         }
     }
-    __syncthreads();
+    wg_sync();
     {
         const int n_big = __builtin_amdgcn_readfirstlane(s_work[5]);
         pc.mark(8);
@@ -399,9 +399,9 @@ tls_slim_kernel(const SearchArgs) {
     for (;;) {
         if (!retry_exact) {
             if (tid == 0) { s_work[0] = (int)atomicAdd(ap->queue, 1u); s_work[1] = 0; s_work[2] = 0; s_work[4] = 0; }
-            __syncthreads();
+            wg_sync();
             work = __builtin_amdgcn_readfirstlane(s_work[0]);
-            __syncthreads();
+            wg_sync();
         } else if (tid == 0) {
             s_work[1] = 0; s_work[2] = 0;
         }
@@ -443,7 +443,7 @@ tls_slim_kernel(const SearchArgs) {
             unsigned short* pg = reinterpret_cast<unsigned short*>(ap->perm_scratch + (long long)blockIdx.x * n);
             for (int k = tid; k < n; k += nt) pg[k] = perm[k];
             perm_g = pg;
-            __syncthreads();
+            wg_sync();
         }
         for (int curve = 0; curve < ap->n_curves; ++curve) {
         const bool exact_mode = period_exact || curve_exact;
@@ -469,16 +469,16 @@ tls_slim_kernel(const SearchArgs) {
                 const int k = tid_g + j * nt;
                 idx[j] = k < n ? (perm_g ? (int)perm_g[k] : (int)perm[k]) : 0;
             }
-            __syncthreads();   // (every thread has its part of the order; global reads of perm_g included)
+            wg_sync();   // (every thread has its part of the order; global reads of perm_g included)
             double* fdst = exact_mode ? X + 1 : X;   // exact mode: C[k+1] goes over f[k] (exact_cumsum's aliased form)
             double v[kSlimPer];
 #pragma unroll
             for (int j = 0; j < kSlimPer; ++j) v[j] = y_c[idx[j]];
 #pragma unroll
             for (int j = 0; j < kSlimPer; ++j) { const int k = tid_g + j * nt; if (k < n) fdst[k] = v[j]; }
-            __syncthreads();
+            wg_sync();
             for (int k = tid; k < W; k += nt) fdst[n + k] = fdst[k];   // core.py:126
-            __syncthreads();
+            wg_sync();
             pc.mark(4);
             if (!exact_mode) {
                 // X[k] = sum of e over [0, k), e = 1 - f: a plain scan in place (every thread its own stretch)
@@ -499,13 +499,13 @@ tls_slim_kernel(const SearchArgs) {
                 if (tid == nt - 1) X[M] = total;
             } else {
                 if (tid == 0) X[0] = 0.0;
-                __syncthreads();
+                wg_sync();
                 (void)exact_cumsum<true>(X + 1, X, M, reinterpret_cast<Cumsum2Scratch*>(scratch), ap->phase_cycles, 0.0);
-                __syncthreads();
+                wg_sync();
                 for (int k = tid; k <= M; k += nt) X[k] = (double)k - X[k];   // X = k - numpy.cumsum: an exact subtraction
             }
             for (int k = tid; k < region_pad; k += nt) X[M + 1 + k] = -(double)(k + 1) * 1.0e300;   // sentinels (see the other kernel)
-            __syncthreads();
+            wg_sync();
             pc.mark(5);
         }
         const int k_lo = __builtin_amdgcn_readfirstlane(rows_c[p].k_lo);
@@ -514,7 +514,7 @@ tls_slim_kernel(const SearchArgs) {
         const int n_rows = k_hi - k_lo;
         for (int row = tid; row < n_rows; row += nt) rt.live[row] = 0;
         if (tid == 0) { s_work[3] = 0; if (!resolving) s_work[4] = 0; }
-        __syncthreads();
+        wg_sync();
 
         Lead lead = resolving ? kept_lead : no_lead();
         unsigned int n_eval = resolving ? kept_eval : 0u;
@@ -680,7 +680,7 @@ tls_slim_kernel(const SearchArgs) {
             TLS_CHECK(*ap, n_listed <= (unsigned int)widths_c[k].n_chunks, kChkListCap);
             rt.live[k - k_lo] = n_listed;   // (every lane stores the same value: see the other kernel on the ticket loop)
         }
-        __syncthreads();
+        wg_sync();
         pc.mark(9);
         // sparse rows and mostly empty last batches: re-listed one window per lane (as the other kernel)
         for (int row = wave; row < n_rows; row += nw) {
@@ -724,7 +724,7 @@ tls_slim_kernel(const SearchArgs) {
             if (lane == 0) { rt.live[row] = (unsigned int)n_live; rt.singles[row] = count; }
         }
         pc.mark(25);
-        __syncthreads();
+        wg_sync();
         if (wave == 0) {   // exclusive scan of the batch counts over the rows
             unsigned int carry = 0;
             for (int r0 = 0; r0 < n_rows; r0 += kWave) {
@@ -744,7 +744,7 @@ tls_slim_kernel(const SearchArgs) {
                 atomicAdd(&ap->phase_cycles[35], (unsigned long long)carry);
             }
         }
-        __syncthreads();
+        wg_sync();
         pc.mark(6);
 
         // ---- phase 3b: sliding dot products ON X, 64 live units of one duration per wave (core.py:59-74) ----
@@ -855,7 +855,7 @@ tls_slim_kernel(const SearchArgs) {
         }
         // fast mode: a window too close to transit_depth_min to call sends the period (this light curve) through exact mode
         if (undecided) s_work[flag_slot] = 1;
-        __syncthreads();
+        wg_sync();
         const int any_undecided = __builtin_amdgcn_readfirstlane(s_work[flag_slot]);
         if (tid == 0) s_work[3 - flag_slot] = 0;
         flag_slot = 3 - flag_slot;
@@ -895,7 +895,7 @@ tls_slim_kernel(const SearchArgs) {
             if (better(o, best)) best = o;
         }
         if (lane == 0) wbest[wave] = best;
-        __syncthreads();
+        wg_sync();
         if (tid == 0) {
             Best gb = wbest[0];
             for (int u = 1; u < nw; ++u) if (better(wbest[u], gb)) gb = wbest[u];
@@ -929,7 +929,7 @@ tls_slim_kernel(const SearchArgs) {
             }
             if (lane == 0 && n_issued) atomicAdd(&ap->counters[2], n_issued * kWave);
         }
-        __syncthreads();
+        wg_sync();
         }  // light curves of the batch
         if (ap->period_cycles && tid == 0) atomicAdd(&ap->period_cycles[p], (unsigned long long)(clock64() - t_period));
     }
