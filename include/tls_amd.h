@@ -196,8 +196,9 @@ int tls_kernel_timing(tls_ctx *ctx, int reset, double *total_ms, int64_t *launch
 int tls_plan_info(const tls_ctx *ctx, tls_counters *counters, int64_t *lds_bytes,
                   int64_t *n_blocks, int64_t *resident /* 1: folded series kept in LDS */);
 /* Which search kernel the context's last tls_execute launched: "resident" (LDS-resident series, two or one workgroups
- * per CU), "resident+prune", "resident+screen32", "slim" (LDS-resident, four 256-thread workgroups per CU), "slab",
- * "slab+split"; "" before the first launch.  The string is static. */
+ * per CU), "resident+prune", "resident+screen32", "slim" (LDS-resident, four 256-thread workgroups per CU), "slim512"
+ * (the same kernel as two 512-thread workgroups per CU: series of 5280-8640 points), "slab", "slab+split"; "" before the
+ * first launch.  The string is static. */
 const char *tls_last_kernel(const tls_ctx *ctx);
 
 /* ---- final T0 fit: the batched counterpart of stats.py:135-204 ------------------------ */
