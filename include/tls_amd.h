@@ -98,8 +98,8 @@ int tls_get_options(const tls_ctx *ctx, tls_options *out);
 int tls_set_options(tls_ctx *ctx, const tls_options *opt);
 /* Developer / test switches, by name (not part of the stable ABI; negative value = the library decides): exact_prefix, slim
  * (the two of tls_options), prune, screen32, no_screen (kernel variant of an LDS-resident series), fast_slab, x_staged,
- * sort2, split, split_batch, parts (series in the HBM slab: prefix-sum mode, sort, two-role kernel, sub-period work items),
- * threads, blocks, plan_threads (launch shape, host planning), prune_min_live, band_max.  A context starts with the values
+ * sort2, split, split_batch (series in the HBM slab: prefix-sum mode, sort, two-role kernel), threads, blocks, plan_threads
+ * (launch shape, host planning), t0_rot (0: the final T0 fit checks every pair of every epoch), prune_min_live, band_max.  A context starts with the values
  * of the TLS_<NAME> environment variables, read once per process; no call reads the environment after that.
  * tls_debug_get_switches writes all of them as "name=value,name=value" (ctx NULL: the process's) -- the text
  * tls_period_costs takes, so that the planning call prices the kernel the searching context will run. */

@@ -546,6 +546,55 @@ def test_t0_fit_kernel_vs_oracle_and_reference_residuals(gpu, oracle_lib):
     numpy.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
 
 
+def test_t0_fit_rotation_path_equals_the_general_kernel(gpu, oracle_lib):
+    """Final T0 fit, round 6: the epochs of a fit as rotations of one sorted order (tls_t0fit_rot: one wavefront an epoch, the
+    out-of-transit terms summed once per fit) against the general kernel (switch t0_rot = 0: every epoch checks every pair of
+    neighbours, every term divided again) -- the same order per epoch, so residuals agree to the rounding of a sum taken in
+    another order (1e-13) and the first minimum is the same epoch -- at the FULL epoch counts of the three sizes (the series
+    in LDS and in HBM scratch), on unevenly sampled times, and where the rotation path must hand the fit back: tied phases
+    (duplicate time stamps, a period commensurate with the cadence)."""
+    rng = numpy.random.RandomState(11)
+    cases = []
+    for name, period in (("k2_90d", 10.12452), ("tess_27d", 3.377), ("kepler_4yr", 10.12452)):
+        t, f, kw = synthetic.config(name)
+        inp = synthetic.search_inputs(t, f, **kw)
+        row = len(inp["rows"]) // 3
+        signal = 1 - (1 - inp["rows"][row]) * 0.002
+        points = min(len(t), int(len(t) / (0.01 * len(signal))))
+        cases.append((name, inp["t"], inp["y"], period, signal, numpy.linspace(t.min(), t.min() + period, points)))
+    t = numpy.sort(5.0 + rng.uniform(0, 40.0, 3000))
+    f = 1 + rng.normal(0, 3e-4, len(t))
+    cases.append(("uneven", t, f, 2.7183, numpy.linspace(0.9990, 0.9996, 41), numpy.linspace(t.min(), t.min() + 2.7183, 3000)))
+    t2 = t.copy(); t2[100:104] = t2[100]
+    cases.append(("ties", t2, f, 2.7183, numpy.linspace(0.9990, 0.9996, 41), numpy.linspace(t.min(), t.min() + 2.7183, 500)))
+    tk, fk, _ = synthetic.config("k2_90d")
+    cases.append(("commensurate", tk, fk, 78 / 48.0, numpy.linspace(0.9990, 0.9996, 9), numpy.linspace(tk.min(), tk.min() + 78 / 48.0, 400)))
+    for k in range(24):   # random sizes, periods, template lengths; epochs anywhere (tls_t0_fit takes the caller's)
+        n = int(rng.choice([17, 64, 500, 2000, 6000, 12000]))
+        t = numpy.sort(rng.uniform(0, 30.0, n)) if k % 2 else numpy.linspace(2.0, 32.0, n)
+        f = 1 + rng.normal(0, float(rng.choice([1e-5, 1e-3])), n)
+        period = float(rng.uniform(0.4, 14.0))
+        dur = int(rng.randint(1, max(2, min(n, 400))))
+        lo = float(rng.choice([t.min(), t.min() - 50.0, t.max()]))
+        epochs = numpy.sort(rng.uniform(lo, lo + 2 * period, int(rng.randint(1, 1500))))
+        cases.append(("random%d" % k, t, f, period, rng.uniform(0.99, 1.0, dur), epochs))
+    try:
+        for name, t, y, period, signal, epochs in cases:
+            roll = int(len(signal) / 2) + 1
+            gpu.set_options(t0_rot=None)
+            got = gpu.t0_fit_residuals(t, y, period, signal, epochs, roll)
+            gpu.set_options(t0_rot=0)
+            want = gpu.t0_fit_residuals(t, y, period, signal, epochs, roll)
+            numpy.testing.assert_allclose(got, want, rtol=1e-13, atol=0, err_msg=name)
+            assert int(numpy.argmin(got)) == int(numpy.argmin(want)), name
+            if len(epochs) <= 3000 and len(t) <= 5000:
+                ref = oracle_lib.t0_residuals(t, y, period, signal, epochs, roll)
+                numpy.testing.assert_allclose(got, ref, rtol=1e-12, atol=0, err_msg=name)
+                assert int(numpy.argmin(got)) == int(numpy.argmin(ref)), name
+    finally:
+        gpu.set_options(t0_rot=None)
+
+
 def test_spectra_kernel_vs_reference_and_oracle(gpu, oracle_lib):
     """tls_spectra (stats.py:105-132 + helpers.py:93-108 on the device) against outputs of the unmodified
     reference (tests/golden/spectra_*.npz) and against the oracle at benchmark size, both for a chi^2

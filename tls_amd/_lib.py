@@ -53,7 +53,7 @@ class Options(ctypes.Structure):
 
 # every switch tls_debug_set_switch knows (the two public ones included): Context.set_options(**switches) takes them all
 SWITCH_NAMES = ("exact_prefix", "slim", "prune", "screen32", "no_screen", "fast_slab", "x_staged", "split", "split_batch", "sort2",
-                "threads", "blocks", "plan_threads", "prune_min_live", "band_max")
+                "threads", "blocks", "plan_threads", "t0_rot", "prune_min_live", "band_max")
 
 
 def switches_text(switches):

@@ -86,7 +86,7 @@ struct View {
 // of the stable ABI).  -1 (band_max, prune_min_live: negative) = the library decides.
 struct Switches {
     int32_t exact_prefix, slim;
-    int32_t prune, screen32, no_screen, fast_slab, x_staged, split, split_batch, sort2, threads, blocks, plan_threads;
+    int32_t prune, screen32, no_screen, fast_slab, x_staged, split, split_batch, sort2, threads, blocks, plan_threads, t0_rot;
     int64_t prune_min_live;
     double band_max;
 };
@@ -97,7 +97,7 @@ const SwitchName kSwitchNames[] = {
     TLS_SW(screen32, "TLS_SCREEN32", 0), TLS_SW(no_screen, "TLS_NO_SCREEN", 0), TLS_SW(fast_slab, "TLS_FAST_SLAB", 0),
     TLS_SW(x_staged, "TLS_X_STAGED", 0), TLS_SW(split, "TLS_SPLIT", 0), TLS_SW(split_batch, "TLS_SPLIT_BATCH", 0),
     TLS_SW(sort2, "TLS_SORT2", 0), TLS_SW(threads, "TLS_THREADS", 0), TLS_SW(blocks, "TLS_BLOCKS", 0),
-    TLS_SW(plan_threads, "TLS_PLAN_THREADS", 0), TLS_SW(prune_min_live, "TLS_PRUNE_MIN_LIVE", 1),
+    TLS_SW(plan_threads, "TLS_PLAN_THREADS", 0), TLS_SW(t0_rot, "TLS_T0_ROT", 0), TLS_SW(prune_min_live, "TLS_PRUNE_MIN_LIVE", 1),
     TLS_SW(band_max, "TLS_BAND_MAX", 2),
 };
 #undef TLS_SW
@@ -225,6 +225,8 @@ struct tls_ctx {
     bool sort2 = false;                      // tiled variant: two-level sort
     int batch_curves = 1;                    // light curves the next launch searches (tls_search_batch)
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
+    DevBuf<double> d_frot;          // ... its rotation path: per fit flux | phases | quotients of the base order, state
+    DevBuf<int> d_frperm;           // ... and the base order itself
     DevBuf<double> d_spec;                                         // SDE spectra: SR | power_raw | power | sde[2] | chi2 copy
     size_t list_stride = 0;
     // two-kernel slab path (series in HBM, one light curve): fold kernel + search kernel per batch of periods
@@ -972,15 +974,19 @@ int enqueue(tls_ctx* ctx, bool count_work, bool phase_clock = false, double* deb
 // T0-fit launch shared by tls_t0_fit and tls_power_batch: every pointer on the device, nothing waited for.
 // One fit (d_params == nullptr: period, dur, roll, n_epochs from the host) or `n_fits` fits in ONE launch (blockIdx.y = fit;
 // their parameters, epochs and signals written on the device by tls_power_prep, the arrays `*_stride` doubles apart).
+// Three launches (round 6): the base order of every fit (one workgroup a fit), the epochs as rotations of it (one wavefront
+// an epoch: tls_t0fit_rot), and the general kernel for the fits the rotation path handed back (ties, gaps the folds' rounding
+// could close: its workgroups leave at once otherwise).  Switch t0_rot = 0: the general kernel alone.
 int launch_t0_fit(tls_ctx* ctx, const double* d_t, const double* d_y, const double* d_signal, const double* d_epochs,
                   double* d_residuals, unsigned int* d_queue, int64_t n, double period, int64_t dur, int64_t n_epochs,
-                  int64_t roll, const tlsdev::T0FitParams* d_params = nullptr, int64_t n_fits = 1, int64_t y_stride = 0,
-                  int64_t signal_stride = 0, int64_t epoch_stride = 0) {
+                  int64_t roll, double t_lo, double t_hi, const tlsdev::T0FitParams* d_params = nullptr, int64_t n_fits = 1,
+                  int64_t y_stride = 0, int64_t signal_stride = 0, int64_t epoch_stride = 0) {
     tlsdev::T0FitArgs a;
     a.t = d_t; a.y = d_y; a.signal = d_signal; a.epochs = d_epochs;
     a.residuals = d_residuals; a.queue = d_queue; a.scratch = nullptr; a.scratch_stride = 0;
     a.period = period; a.n = (int)n; a.dur = (int)dur; a.roll = (int)(roll % n); a.n_epochs = (int)n_epochs;
     a.params = d_params; a.y_stride = y_stride; a.signal_stride = signal_stride; a.epoch_stride = epoch_stride;
+    a.mode = 0; a.rot = nullptr; a.rot_perm = nullptr; a.rot_stride = 0; a.t_lo = t_lo; a.t_hi = t_hi;
     const size_t hdr = 272;
     const size_t resident_bytes = hdr + 16 * (size_t)n;
     const bool resident = resident_bytes <= kLdsPerCU && n <= 65535;
@@ -1002,16 +1008,42 @@ int launch_t0_fit(tls_ctx* ctx, const double* d_t, const double* d_y, const doub
         a.scratch = ctx->d_fscratch.ptr;
     }
     if (blocks < 1) return TLS_OK;
-    const dim3 grid((unsigned)blocks, (unsigned)std::max<int64_t>(n_fits, 1));
-    hipError_t e;
-    if (resident) {
-        auto kernel = tlsdev::tls_t0fit_kernel<true, unsigned short>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
+    const unsigned fits = (unsigned)std::max<int64_t>(n_fits, 1);
+    const bool rotation = ctx->opt.t0_rot != 0 && n >= tlsdev::kT0RotMinPoints;
+    if (rotation) {
+        a.rot_stride = 3 * (long long)n + 4;
+        TLS_HIP(ctx, ctx->d_frot.reserve((size_t)fits * (size_t)a.rot_stride));
+        TLS_HIP(ctx, ctx->d_frperm.reserve((size_t)fits * (size_t)n));
+        a.rot = ctx->d_frot.ptr; a.rot_perm = ctx->d_frperm.ptr;
+    }
+    auto launch = [&](int mode, unsigned grid_x) -> hipError_t {
+        tlsdev::T0FitArgs b = a;
+        b.mode = mode;
+        const dim3 grid(grid_x, fits);
+        hipError_t e;
+        if (resident) {
+            auto kernel = tlsdev::tls_t0fit_kernel<true, unsigned short>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) { hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, ctx->stream, b); e = hipGetLastError(); }
+        } else {
+            auto kernel = tlsdev::tls_t0fit_kernel<false, unsigned int>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) { hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, ctx->stream, b); e = hipGetLastError(); }
+        }
+        return e;
+    };
+    hipError_t e = hipSuccess;
+    if (rotation) {
+        e = launch(1, 1u);
+        if (e == hipSuccess) {
+            const unsigned waves_per_wg = 4;
+            const dim3 grid((unsigned)((epochs_cap + waves_per_wg - 1) / waves_per_wg), fits);
+            hipLaunchKernelGGL(tlsdev::tls_t0fit_rot, grid, dim3(waves_per_wg * 64), 0, ctx->stream, a);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = launch(2, (unsigned)blocks);
     } else {
-        auto kernel = tlsdev::tls_t0fit_kernel<false, unsigned int>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) { hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, ctx->stream, a); e = hipGetLastError(); }
+        e = launch(0, (unsigned)blocks);
     }
     if (e != hipSuccess) return fail(ctx, TLS_E_HIP, std::string("t0 fit launch: ") + hipGetErrorString(e));
     return TLS_OK;
@@ -1139,7 +1171,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release();
     ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_pqueues.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
-    ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release();
+    ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release(); ctx->d_frot.release(); ctx->d_frperm.release();
     ctx->d_split.release(); ctx->d_park.release(); ctx->d_band.release();
     if (ctx->h_band) (void)hipHostFree(ctx->h_band);
     for (auto& ev : ctx->ev_band) if (ev) (void)hipEventDestroy(ev);
@@ -1645,8 +1677,10 @@ int tls_t0_fit(tls_ctx* ctx, const double* t, const double* y, int64_t n, double
     if ((rc = upload(ctx, ctx->d_fep, epochs, (size_t)n_epochs))) return rc;
     TLS_HIP(ctx, ctx->d_fres.reserve((size_t)n_epochs));
     TLS_HIP(ctx, hipMemsetAsync(ctx->d_queue.ptr, 0, sizeof(unsigned int), ctx->stream));
+    double t_lo = t[0], t_hi = t[0];
+    for (int64_t i = 1; i < n; ++i) { t_lo = std::min(t_lo, t[i]); t_hi = std::max(t_hi, t[i]); }
     if ((rc = launch_t0_fit(ctx, ctx->d_ft.ptr, ctx->d_fy.ptr, ctx->d_fsig.ptr, ctx->d_fep.ptr, ctx->d_fres.ptr, ctx->d_queue.ptr,
-                            n, period, dur, n_epochs, roll))) return rc;
+                            n, period, dur, n_epochs, roll, t_lo, t_hi))) return rc;
     TLS_HIP(ctx, hipMemcpyAsync(out_residuals, ctx->d_fres.ptr, (size_t)n_epochs * 8, hipMemcpyDeviceToHost, ctx->stream));
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TLS_OK;
@@ -1821,6 +1855,8 @@ int tls_debug_poison_lds(tls_ctx* ctx, uint32_t word) {
     TLS_HIP(ctx, smear(ctx->d_split.ptr, ctx->d_split.cap * sizeof(float)));
     TLS_HIP(ctx, smear(ctx->d_park.ptr, ctx->d_park.cap * sizeof(double)));
     TLS_HIP(ctx, smear(ctx->d_fscratch.ptr, ctx->d_fscratch.cap * sizeof(double)));
+    TLS_HIP(ctx, smear(ctx->d_frot.ptr, ctx->d_frot.cap * sizeof(double)));
+    TLS_HIP(ctx, smear(ctx->d_frperm.ptr, ctx->d_frperm.cap * sizeof(int)));
     return TLS_OK;
 }
 
@@ -2134,8 +2170,8 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
     const size_t np = (size_t)n_periods, nn = (size_t)n;
     const bool uni = ctx->uniform_w;
     const int detrend = n_periods > 2 * kernel ? 1 : 0;
-    double t_min = t[0];
-    for (int64_t i = 1; i < n; ++i) t_min = std::min(t_min, t[i]);
+    double t_min = t[0], t_max = t[0];
+    for (int64_t i = 1; i < n; ++i) { t_min = std::min(t_min, t[i]); t_max = std::max(t_max, t[i]); }
     int64_t max_len = 1;
     for (int64_t r = 0; r < tmpl->n_rows; ++r) max_len = std::max(max_len, tmpl->length[r]);
     // device buffers of one group: flux (weights), per-curve constants, search results, spectra, summaries, T0-fit inputs
@@ -2253,7 +2289,7 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         hipLaunchKernelGGL(tlsdev::tls_power_prep, dim3((unsigned)gc), dim3(256), 0, ctx->stream, pr);
         TLS_HIP(ctx, hipGetLastError());
         rc = launch_t0_fit(ctx, ctx->d_t.ptr, sl.d_y.ptr, ctx->d_fsig.ptr, ctx->d_fep.ptr, ctx->d_fres.ptr, nullptr, n, 1.0, 0, 0, 0,
-                           d_fit, gc, (int64_t)nn, max_len, (int64_t)fit_stride);
+                           t_min, t_max, d_fit, gc, (int64_t)nn, max_len, (int64_t)fit_stride);
         if (rc) break;
         tlsdev::FirstMinArgs fa;
         fa.residuals = ctx->d_fres.ptr; fa.epochs = ctx->d_fep.ptr; fa.n_epochs = d_nep;

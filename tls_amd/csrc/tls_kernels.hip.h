@@ -3112,8 +3112,19 @@ struct T0FitArgs {
     // signal + c * signal_stride, epochs / residuals + c * epoch_stride.  nullptr: one fit, the scalars above.
     const struct T0FitParams* params;
     long long y_stride, signal_stride, epoch_stride;
+    // Rotation path (round 6; tls_t0fit_rot below).  mode 0: every epoch of every fit in this kernel (the original form).
+    // mode 1 ("base"): one workgroup per fit sorts the fit's FIRST epoch and leaves, per fit, in `rot` (rot_stride doubles a
+    // fit): the flux in that order Fb[n] | the phases phb[n] | the out-of-transit quotients c[n] | state[4] = (sum of c,
+    // flag: != 0 the fit must take this kernel for every epoch, smallest gap between neighbouring phases, |q| bound of the
+    // base epoch), and the order itself in rot_perm[n].  mode 2: only the fits whose flag is set (mode 0's work for them).
+    int mode;
+    double* rot;
+    int* rot_perm;
+    long long rot_stride;
+    double t_lo, t_hi;      // min and max of t (the |q| bound of an epoch's fold)
 };
 struct T0FitParams { double period; int dur, roll, n_epochs, pad_; };
+constexpr int kT0RotMinPoints = 16;   // (the rotation path looks at eight neighbours of the wrap)
 
 template <bool RESIDENT, typename IdxT>
 __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a0) {
@@ -3126,6 +3137,9 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a0) {
         a.epochs = a0.epochs + c * a0.epoch_stride; a.residuals = a0.residuals + c * a0.epoch_stride;
         if ((int)blockIdx.x >= a.n_epochs) return;   // (uniform for the workgroup)
     }
+    double* const rot_fit = a.rot ? a.rot + (long long)blockIdx.y * a.rot_stride : nullptr;
+    if (a.mode == 2 && rot_fit[3LL * a.n + 1] == 0.0) return;   // (the rotation path has done this fit)
+    if (a.mode == 1) a.n_epochs = a.n_epochs > 0 ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), nw = nt / kWave;
@@ -3231,6 +3245,47 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a0) {
             have_base = RESIDENT;   // (series in HBM: the sort's scratch is shared with the order; every epoch sorts)
             start = 0;
         }
+        if (a.mode == 1) {
+            // base of the rotation path: order, flux, phases and out-of-transit quotients of this epoch; the sum of the
+            // quotients; the smallest gap between neighbouring phases around the cycle (a gap the folds' rounding could close
+            // under another epoch, or a tie, sends the fit through every epoch's own check: mode 2)
+            double* Fb = rot_fit; double* phb = Fb + n; double* cq = phb + n; double* state = cq + n;
+            int* order = a.rot_perm + (long long)blockIdx.y * n;
+            const int r1 = a.roll % n;
+            double c_sum = 0.0, gap_min = INFINITY;
+            for (int k = tid; k < n; k += nt) {
+                const int i = (int)perm[k], i_next = (int)perm[k + 1 < n ? k + 1 : 0];
+                const double ph = fold_phase(a.t[i], a.period, epoch), ph_next = fold_phase(a.t[i_next], a.period, epoch);
+                int kk = k - r1; if (kk < 0) kk += n;
+                const double f1 = regA[k], f2 = regA[kk];
+                const double dlt = f1 - 1.0;
+                const double c = (dlt * dlt) / (f2 * f2);
+                order[k] = i; Fb[k] = f1; phb[k] = ph; cq[k] = c;
+                c_sum += c;
+                gap_min = fmin(gap_min, k + 1 < n ? ph_next - ph : (ph_next + 1.0) - ph);
+            }
+#pragma unroll
+            for (int dlt = kWave / 2; dlt > 0; dlt >>= 1) {
+                c_sum += __shfl_down(c_sum, dlt, kWave);
+                gap_min = fmin(gap_min, __shfl_down(gap_min, dlt, kWave));
+            }
+            if (lane == 0) wred[wave] = c_sum;
+            wg_sync();
+            double tot = 0.0;
+            if (tid == 0) for (int v = 0; v < nw; ++v) tot += wred[v];
+            wg_sync();
+            if (lane == 0) wred[wave] = gap_min;
+            wg_sync();
+            if (tid == 0) {
+                double gm = INFINITY;
+                for (int v = 0; v < nw; ++v) gm = fmin(gm, wred[v]);
+                const double q_b = fmax(fabs(a.t_lo - epoch), fabs(a.t_hi - epoch)) / a.period + 1.0;
+                state[0] = tot;
+                state[1] = (n >= kT0RotMinPoints && gm > 0.0 && tot == tot) ? 0.0 : 1.0;   // (ties, tiny series, NaN flux: the general kernel)
+                state[2] = gm; state[3] = q_b;
+            }
+            return;
+        }
         // flux rolled once: F1[k] = F[(k - roll) mod n]; weights: F2[k] = F[(k - 2 roll) mod n]
         const int r1 = a.roll % n, r2 = (2 * a.roll) % n;
         double acc = 0.0;
@@ -3253,6 +3308,80 @@ __global__ void __launch_bounds__(1024) tls_t0fit_kernel(const T0FitArgs a0) {
         }
         wg_sync();
     }
+}
+
+// The epochs of a fit as rotations of ONE sorted order (round 6).  fold(t, P, T0) of another trial epoch shifts every real
+// phase by the same amount, so -- rounding aside -- every epoch's stable order is the base epoch's (tls_t0fit_kernel, mode 1)
+// started somewhere else.  Rounding: a computed phase is within err = 2^-52 (|q| + 1) of the real one (q = (t - T0) / P: one
+// rounded subtraction, one rounded division, an exact x - floor(x)); two neighbours of the base order whose computed phases
+// differ by more than 6e-15 (Q + 2) >= 6 err compare the same way under EVERY epoch unless the wrap at 0 / 1 lies between
+// them, and at most one point sits within err of the wrap.  So with every gap above that bound an epoch's order has exactly
+// one descent, at most one place from where the real phases wrap: the wave looks the wrap up in the base phases
+// (lower bound of 1 - shift), folds the eight neighbours exactly, and takes the one descent it finds there; no descent or
+// two, or a gap below the epoch's bound: the fit's flag is raised and tls_t0fit_kernel (mode 2) redoes the whole fit with its
+// per-epoch check of every pair.  The residual: out of transit the term of a point, (F[j] - 1)^2 / F[j - roll]^2, does not
+// depend on the epoch (the doubly rolled weights are positions in the same cyclic order), so
+//   residual = sum_j c[j]  +  sum_{k < dur} ( (F[j_k] - signal[k])^2 / F[j_k - roll]^2 - c[j_k] ),   j_k = k - roll + start:
+// N + dur terms a fit and dur an epoch instead of N an epoch (and no sort of N points per epoch where the series does not fit
+// the LDS: TESS 6.6 -> 0.1 ms, Kepler 216 -> 1 ms a fit).  One wavefront per epoch.
+__global__ void __launch_bounds__(256) tls_t0fit_rot(const T0FitArgs a0) {
+    T0FitArgs a = a0;
+    if (a0.params != nullptr) {
+        const long long c = blockIdx.y;
+        const T0FitParams fp = a0.params[c];
+        a.period = fp.period; a.dur = fp.dur; a.roll = fp.roll; a.n_epochs = fp.n_epochs;
+        a.signal = a0.signal + c * a0.signal_stride;
+        a.epochs = a0.epochs + c * a0.epoch_stride; a.residuals = a0.residuals + c * a0.epoch_stride;
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int e = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave));
+    const int n = a.n;
+    if (e >= a.n_epochs) return;
+    double* const rot_fit = a.rot + (long long)blockIdx.y * a.rot_stride;
+    const double* Fb = rot_fit; const double* phb = Fb + n; const double* cq = phb + n; double* state = rot_fit + 3LL * n;
+    const int* order = a.rot_perm + (long long)blockIdx.y * n;
+    if (state[1] != 0.0) return;
+    const double epoch = a.epochs[e], epoch_b = a.epochs[0];
+    const double q_e = fmax(fabs(a.t_lo - epoch), fabs(a.t_hi - epoch)) / a.period + 1.0;
+    if (!(state[2] > 6.0e-15 * (fmax(q_e, state[3]) + 2.0))) { if (lane == 0) state[1] = 1.0; return; }
+    // where the real phases wrap under this epoch: the first base phase >= 1 - shift (64-ary search, the lanes probe)
+    const double shift = fold_phase(epoch_b, a.period, epoch);
+    const double target = 1.0 - shift;
+    int lo = 0, hi = n;   // every base phase in front of lo is < target; the one at hi (if any) is not
+    while (lo < hi) {
+        const int step = (hi - lo + kWave - 1) / kWave;
+        const int idx = lo + lane * step;
+        const bool less = idx < hi && phb[idx] < target;
+        const int cnt = __popcll(ballot64(less));          // (the base phases ascend: the lanes that see `less` are the first cnt)
+        if (cnt == 0) break;
+        const int first_not = lo + cnt * step;
+        lo = lo + (cnt - 1) * step + 1;
+        hi = first_not < hi ? first_not : hi;
+    }
+    const int m = lo < n ? lo : 0;
+    // the eight entries around it, folded exactly as the reference folds them: one descent among the seven pairs
+    int pos = m - 4 + (lane & 7); if (pos < 0) pos += n; if (pos >= n) pos -= n;
+    const int i_mine = order[pos];
+    const double ph = fold_phase(a.t[i_mine], a.period, epoch);
+    const double ph_next = __shfl_down(ph, 1, kWave);
+    const int i_next = __shfl_down(i_mine, 1, kWave), pos_next = __shfl_down(pos, 1, kWave);
+    const bool down = lane < 7 && (ph_next < ph || (ph_next == ph && i_next < i_mine));
+    const unsigned long long downs = ballot64(down);
+    if (__popcll(downs) != 1) { if (lane == 0) state[1] = 1.0; return; }
+    const int start = __builtin_amdgcn_readlane(pos_next, __ffsll((long long)downs) - 1);
+    // the template's samples against the flux behind the rolls, minus what these points weigh out of transit
+    const int r1 = a.roll % n, dur = a.dur < n ? a.dur : n;
+    double acc = 0.0;
+    for (int k = lane; k < dur; k += kWave) {
+        int j = k - r1 + start; if (j < 0) j += n; if (j >= n) j -= n;
+        int jj = j - r1; if (jj < 0) jj += n;
+        const double f1 = Fb[j], f2 = Fb[jj];
+        const double dlt = f1 - a.signal[k];
+        acc += (dlt * dlt) / (f2 * f2) - cq[j];
+    }
+#pragma unroll
+    for (int dlt = kWave / 2; dlt > 0; dlt >>= 1) acc += __shfl_down(acc, dlt, kWave);
+    if (lane == 0) a.residuals[e] = state[0] + acc;
 }
 
 // ---------------------------------------------------------------------------------------
