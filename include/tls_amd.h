@@ -211,6 +211,13 @@ int tls_t0_fit(tls_ctx *ctx, const double *t, const double *y, int64_t n, double
                const double *signal, int64_t dur, const double *epochs, int64_t n_epochs,
                int64_t roll, double *out_residuals);
 
+/* ---- pink noise of the out-of-transit flux: the counterpart of stats.py:72-77 (pink_noise) ---- */
+/* mean over all n - width + 1 windows of `width` consecutive points of numpy.std(window) / width ** 0.5, with the reference's
+ * roundings: every window's two sums in numpy's pairwise association, the running total added window by window from the left.
+ * `root_width` = width ** 0.5 as the caller's language forms it (Python's float power; sqrt(width) otherwise).  data finite;
+ * 1 <= width <= n.  (Called per power() by the statistics layer: 3 ms of numpy at TESS size.) */
+int tls_pink_noise(tls_ctx *ctx, const double *data, int64_t n, int64_t width, double root_width, double *out);
+
 /* ---- SDE spectra: the counterpart of stats.py:105-132 (spectra) with helpers.py:93-108 ---- */
 /* SR, power_raw (scaled to SDE_raw) and power (running-median detrended, scaled to SDE) for the
  * chi^2 of every period; out_sde[0] = SDE_raw, out_sde[1] = SDE.  chi2 == NULL takes the chi^2 array

@@ -315,3 +315,35 @@ def test_survey_batches_over_a_devices_list_equal_the_one_device_batch():
     numpy.testing.assert_array_equal(p1, p2)
     for name in s1.dtype.names:
         numpy.testing.assert_array_equal(s1[name], s2[name], err_msg=name)
+
+
+@pytest.mark.gpu
+def test_pink_noise_on_the_device_returns_the_bits_of_the_reference_loop():
+    """tls_pink_noise (stats.py:72-77 on the device: numpy's pairwise association inside every window, the terms added from
+    the left by the exact sequential prefix sum) against the reference's own loop over numpy.std on small inputs and against
+    the vectorised numpy form (tls_amd.stats.pink_noise, itself pinned to that loop) at every branch of the pairwise sum:
+    widths below 8, up to 128, beyond (halved runs), one window, width = n."""
+    from tls_amd import _lib, stats, search
+    ctx = _lib.Context(0)
+    rng = numpy.random.RandomState(5)
+
+    def reference(data, width):   # stats.py:72-77, verbatim arithmetic
+        std = 0
+        datapoints = len(data) - width + 1
+        for i in range(datapoints):
+            std += numpy.std(data[i: i + width]) / width ** 0.5
+        return std / datapoints
+
+    for n, widths in ((40, (1, 3, 7, 8, 9, 40)), (700, (1, 8, 16, 127, 128, 129, 300, 700)), (19000, (5, 92, 257, 1000, 4097))):
+        data = 1 + rng.normal(0, 3e-4, n)
+        for width in widths:
+            got = ctx.pink_noise(data, width)
+            assert got == stats.pink_noise(data, width), (n, width)
+            if n <= 700:
+                assert got == reference(data, width), (n, width)
+    # what power() calls: small inputs stay with numpy, large ones go to the device; the same number either way
+    data = 1 + rng.normal(0, 1e-3, 30000)
+    assert search.pink_noise(data, 100, context=ctx) == stats.pink_noise(data, 100)
+    assert search.pink_noise(data[:500], 10, context=ctx) == stats.pink_noise(data[:500], 10)
+    with pytest.raises(RuntimeError):
+        ctx.pink_noise(data[:10], 11)

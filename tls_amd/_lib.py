@@ -23,7 +23,7 @@ ABI_VERSION = 5   # include/tls_amd.h TLS_AMD_ABI_VERSION: checked against the l
 SYMBOLS = (
     "tls_device_count", "tls_ctx_create", "tls_ctx_destroy", "tls_last_error", "tls_version", "tls_abi_version",
     "tls_device_name", "tls_get_options", "tls_set_options", "tls_debug_set_switch", "tls_debug_get_switches", "tls_search", "tls_search_batch", "tls_power_batch", "tls_prepare", "tls_update_flux", "tls_execute",
-    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_last_kernel", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_poison_lds", "tls_debug_period_cycles", "tls_debug_batch_group_ms",
+    "tls_synchronize", "tls_fetch", "tls_execute_timed", "tls_plan_info", "tls_last_kernel", "tls_grid_cells", "tls_period_costs", "tls_t0_fit", "tls_pink_noise", "tls_spectra", "tls_kernel_timing", "tls_debug_phase_cycles", "tls_debug_cumsum", "tls_debug_folded", "tls_debug_prefix", "tls_debug_check_counts", "tls_debug_poison_lds", "tls_debug_period_cycles", "tls_debug_batch_group_ms",
     "tls_comm_unique_id", "tls_comm_init", "tls_comm_destroy", "tls_comm_info", "tls_comm_allgather_results", "tls_comm_allgather_device", "tls_comm_fetch_gathered",
     "tls_comm_stage_results", "tls_comm_allgather_staged", "tls_comm_fetch_staged",
     "tls_comm_barrier", "tls_comm_max",
@@ -162,6 +162,8 @@ def load():
     lib.tls_t0_fit.restype = ci
     lib.tls_t0_fit.argtypes = [vp, _c_double_p, _c_double_p, i64, dbl, _c_double_p, i64, _c_double_p,
                                i64, i64, _c_double_p]
+    lib.tls_pink_noise.restype = ci
+    lib.tls_pink_noise.argtypes = [vp, _c_double_p, i64, i64, ctypes.c_double, _c_double_p]
     lib.tls_spectra.restype = ci
     lib.tls_spectra.argtypes = [vp, _c_double_p, i64, i64, _c_double_p, _c_double_p, _c_double_p, _c_double_p]
     lib.tls_debug_folded.restype = ci
@@ -435,6 +437,14 @@ class Context(object):
         self._check(self._lib.tls_spectra(self._h, None if c is None else _dp(c), n, int(kernel), _dp(SR), _dp(praw),
                                           _dp(power), _dp(sde)))
         return SR, praw, power, float(sde[0]), float(sde[1])
+
+    def pink_noise(self, data, width):
+        """Mean over all windows of `width` points of std(window) / width ** 0.5 (stats.py:72-77) on the device, with
+        the roundings of the reference's loop over numpy.std."""
+        d = _f8(data)
+        out = numpy.empty(1, dtype=numpy.float64)
+        self._check(self._lib.tls_pink_noise(self._h, _dp(d), len(d), int(width), float(int(width) ** 0.5), _dp(out)))
+        return float(out[0])
 
     def debug_cumsum(self, values, threads=512):
         """[0, cumsum(values)] computed by the kernel's exact parallel sequential-order scan."""

@@ -217,7 +217,9 @@ class transitleastsquares(object):
             t=self.t, y=self.y, period=period, duration=duration, T0=T0,
             transit_times=transit_times, transit_duration_in_days=transit_duration_in_days,
             per_transit_count=per_transit_count, chunks=chunks, flux_ootr=flux_ootr,
-            mean_flux=transit_depths, std_ootr=std_ootr)
+            mean_flux=transit_depths, std_ootr=std_ootr,
+            pink_noise_fn=((lambda d, w: _search.pink_noise(d, w, context=ctx, device=dev))
+                           if getattr(_search.search_periods, "_tls_amd_product", False) else None))
         depth_mean = numpy.mean(all_flux_intransit)
         depth_mean_std = numpy.std(all_flux_intransit) / numpy.sum(per_transit_count) ** (0.5)
         snr = ((1 - depth_mean) / std_ootr) * len(all_flux_intransit) ** (0.5)

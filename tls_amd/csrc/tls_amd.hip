@@ -225,6 +225,7 @@ struct tls_ctx {
     bool sort2 = false;                      // tiled variant: two-level sort
     int batch_curves = 1;                    // light curves the next launch searches (tls_search_batch)
     DevBuf<double> d_ft, d_fy, d_fsig, d_fep, d_fres, d_fscratch;  // final T0 fit
+    DevBuf<double> d_pink;          // tls_pink_noise: data | terms | running sums
     DevBuf<double> d_frot;          // ... its rotation path: per fit flux | phases | quotients of the base order, state
     DevBuf<int> d_frperm;           // ... and the base order itself
     DevBuf<double> d_spec;                                         // SDE spectra: SR | power_raw | power | sde[2] | chi2 copy
@@ -1171,7 +1172,7 @@ void tls_ctx_destroy(tls_ctx* ctx) {
     ctx->d_scratch.release(); ctx->d_pack.release();
     ctx->d_gather.release(); ctx->d_scalar.release(); ctx->d_stage.release();
     ctx->d_partials.release(); ctx->d_tiles_done.release(); ctx->d_check.release(); ctx->d_spec.release(); ctx->d_queue.release(); ctx->d_squeue.release(); ctx->d_pqueues.release(); ctx->d_phase.release(); ctx->d_lists.release(); ctx->d_perm.release(); ctx->d_curve_S0.release(); ctx->d_curve_w0.release();
-    ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release(); ctx->d_frot.release(); ctx->d_frperm.release();
+    ctx->d_ft.release(); ctx->d_fy.release(); ctx->d_fsig.release(); ctx->d_fep.release(); ctx->d_fres.release(); ctx->d_fscratch.release(); ctx->d_frot.release(); ctx->d_frperm.release(); ctx->d_pink.release();
     ctx->d_split.release(); ctx->d_park.release(); ctx->d_band.release();
     if (ctx->h_band) (void)hipHostFree(ctx->h_band);
     for (auto& ev : ctx->ev_band) if (ev) (void)hipEventDestroy(ev);
@@ -1683,6 +1684,31 @@ int tls_t0_fit(tls_ctx* ctx, const double* t, const double* y, int64_t n, double
                             n, period, dur, n_epochs, roll, t_lo, t_hi))) return rc;
     TLS_HIP(ctx, hipMemcpyAsync(out_residuals, ctx->d_fres.ptr, (size_t)n_epochs * 8, hipMemcpyDeviceToHost, ctx->stream));
     TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TLS_OK;
+}
+
+int tls_pink_noise(tls_ctx* ctx, const double* data, int64_t n, int64_t width, double root_width, double* out) {
+    if (!ctx) return fail(nullptr, TLS_E_ARG, "null context");
+    if (!data || !out) return fail(ctx, TLS_E_ARG, "null argument");
+    if (n < 1 || n > 100000000 || width < 1 || width > n) return fail(ctx, TLS_E_ARG, "pink noise: 1 <= width <= n wanted");
+    if (!(root_width > 0.0)) return fail(ctx, TLS_E_ARG, "pink noise: root_width must be width ** 0.5");
+    TLS_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n_windows = n - width + 1;
+    // data | terms | running sums (n_windows + 1)
+    TLS_HIP(ctx, ctx->d_pink.reserve((size_t)n + 2 * (size_t)n_windows + 1));
+    double* d_data = ctx->d_pink.ptr; double* d_terms = d_data + n; double* d_sums = d_terms + n_windows;
+    TLS_HIP(ctx, hipMemcpyAsync(d_data, data, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(tlsdev::tls_pink_terms, dim3((unsigned)((n_windows + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double*)d_data, (int)n_windows, (int)width, root_width, d_terms);
+    TLS_HIP(ctx, hipGetLastError());
+    // (the reference adds the terms one by one from the left: the exact sequential prefix sum of the search, terms >= 0)
+    hipLaunchKernelGGL(tlsdev::tls_cumsum_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)d_terms, d_sums, (int)n_windows, 0,
+                       static_cast<unsigned long long*>(nullptr));
+    TLS_HIP(ctx, hipGetLastError());
+    double last = 0.0;
+    TLS_HIP(ctx, hipMemcpyAsync(&last, d_sums + n_windows, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = last / (double)n_windows;
     return TLS_OK;
 }
 

@@ -3678,6 +3678,45 @@ __global__ void __launch_bounds__(256) tls_power_prep(const PrepArgs a) {
     if (tid == 0) ep[points - 1] = s_stop;
 }
 
+// Pink noise (reference stats.py:72-77): term i = numpy.std(data[i : i + width]) / width ** 0.5, one thread a window.
+// numpy.std = sqrt(sum((x - sum(x) / n)^2) / n) with both sums in numpy's pairwise association (loops_utils.h.src,
+// pairwise_sum: fewer than 8 elements from the left starting at -0.0; up to 128 as eight interleaved partial sums, combined
+// ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), the tail from the left; longer runs halved at a multiple of 8).
+template <typename At>
+__device__ double numpy_pairwise_sum(const At& at, int lo, int n) {
+    if (n < 8) {
+        double res = -0.0;
+        for (int i = 0; i < n; ++i) res += at(lo + i);
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = at(lo + j);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += at(lo + i + j);
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += at(lo + i);
+        return res;
+    }
+    int half = n / 2;
+    half -= half % 8;
+    return numpy_pairwise_sum(at, lo, half) + numpy_pairwise_sum(at, lo + half, n - half);
+}
+__global__ void __launch_bounds__(256) tls_pink_terms(const double* data, int n_windows, int width, double root_width, double* terms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_windows) return;
+    const double* w = data + i;
+    const double wd = (double)width;
+    const double mean = numpy_pairwise_sum([w](int k) { return w[k]; }, 0, width) / wd;
+    // (the square is rounded before it is added, as numpy.multiply leaves it: hipcc would contract it into the sum's FMA)
+    const double var = numpy_pairwise_sum([w, mean](int k) { const double d = w[k] - mean; double sq = d * d; asm volatile("" : "+v"(sq)); return sq; }, 0, width) / wd;
+    terms[i] = sqrt(var) / root_width;
+}
+
 // Developer/test entry: the exact sequential cumsum on an arbitrary non-negative series
 // (one workgroup, global memory).  out has count + 1 entries.
 __global__ void __launch_bounds__(1024) tls_cumsum_kernel(const double* f, double* out, int count, int variant,

@@ -297,6 +297,24 @@ def t0_fit_residuals(t, y, period, signal, T0_array, roll, context=None, device=
     return ctx.t0_fit_residuals(t, y, period, signal, T0_array, roll)
 
 
+# below this many window elements the numpy form of stats.pink_noise is quicker than a round trip to the device
+PINK_NOISE_ON_DEVICE = 60000
+
+
+def pink_noise(data, width, context=None, device=None):
+    """stats.pink_noise (reference stats.py:72-77) on the device (tls_pink_noise): the same value bit for bit -- every
+    window's two sums in numpy's pairwise association, the terms added one by one from the left.  Small inputs, and the
+    inputs the reference itself fails on, stay with the numpy form."""
+    from . import stats as _stats
+    data = numpy.ascontiguousarray(data, dtype=float)
+    width = int(width)
+    n_windows = len(data) - width + 1
+    if width < 1 or n_windows < 1 or n_windows * width < PINK_NOISE_ON_DEVICE or not numpy.all(numpy.isfinite(data)):
+        return _stats.pink_noise(data, width)
+    ctx = context if context is not None else default_context(device)
+    return ctx.pink_noise(data, width)
+
+
 def spectra(chi2, oversampling_factor, context=None, device=None, resident=False):
     """SR, power_raw, power, SDE_raw, SDE from the chi^2 of every period (reference stats.py:105-132),
     evaluated on the device (tls_spectra: reductions + running-median detrend)."""

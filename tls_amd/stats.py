@@ -339,13 +339,14 @@ def intransit_stats(t, y, transit_times, transit_duration_in_days, chunks=None):
 
 
 def snr_stats(t, y, period, duration, T0, transit_times, transit_duration_in_days,
-              per_transit_count, chunks=None, flux_ootr=None, mean_flux=None, std_ootr=None):
+              per_transit_count, chunks=None, flux_ootr=None, mean_flux=None, std_ootr=None, pink_noise_fn=None):
     """Per-epoch white-noise and pink-noise SNR (reference stats.py:419-469).  `mean_flux` (the per-epoch means
-    intransit_stats has just formed from the same chunks) and `std_ootr` (numpy.std(flux_ootr)) may be handed in."""
+    intransit_stats has just formed from the same chunks) and `std_ootr` (numpy.std(flux_ootr)) may be handed in;
+    `pink_noise_fn(data, width)`: power() hands in the device form (search.pink_noise, the same bits)."""
     if flux_ootr is None:
         flux_ootr = y[~transit_mask(t, period, 2 * duration, T0)]
     try:
-        pinknoise = pink_noise(flux_ootr, int(numpy.mean(per_transit_count)))
+        pinknoise = (pink_noise_fn or pink_noise)(flux_ootr, int(numpy.mean(per_transit_count)))
     except Exception:
         pinknoise = numpy.nan
     if std_ootr is not None and len(flux_ootr) > 0:
