@@ -2223,21 +2223,30 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
     int* d_nep = reinterpret_cast<int*>(ctx->d_fsig.ptr + (size_t)group * (size_t)max_len);
     tlsdev::T0FitParams* d_fit = reinterpret_cast<tlsdev::T0FitParams*>(ctx->d_fsig.ptr + (size_t)group * (size_t)max_len + (size_t)group);
     static_assert(sizeof(tlsdev::T0FitParams) == 24, "three doubles of device scratch per fit");
-    // pinned staging: flux in; summaries, T0 and (on request) the per-period arrays out
+    // pinned staging: flux in; summaries, T0 and (on request) the per-period arrays out.  TWO sets (the device buffers are
+    // one: the stream runs the groups in order): while the device works on group g the host forms group g + 1 in the other
+    // set and enqueues it, THEN waits for g -- the device never waits for the host between two groups (round 6)
     const size_t in_doubles = (size_t)group * nn * (uni ? 1 : 2) + 2 * (size_t)group;
     const size_t arrays = (out_chi2 ? 3 : 0) + (out_power ? 1 : 0) + (out_SR ? 1 : 0) + (out_power_raw ? 1 : 0);
     const size_t out_doubles = 11 * (size_t)group + arrays * (size_t)group * np;
-    if (sl.h_in_cap < in_doubles) {
-        if (sl.h_in) TLS_HIP(ctx, hipHostFree(sl.h_in));
-        sl.h_in = nullptr; sl.h_in_cap = 0;
-        TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.h_in), in_doubles * 8, hipHostMallocDefault));
-        sl.h_in_cap = in_doubles;
-    }
-    if (sl.h_out_cap < out_doubles) {
-        if (sl.h_out) TLS_HIP(ctx, hipHostFree(sl.h_out));
-        sl.h_out = nullptr; sl.h_out_cap = 0;
-        TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), out_doubles * 8, hipHostMallocDefault));
-        sl.h_out_cap = out_doubles;
+    for (auto& hs : ctx->slot) {
+        if (!hs.ev_out) {
+            TLS_HIP(ctx, hipEventCreateWithFlags(&hs.ev_in, hipEventDisableTiming));
+            TLS_HIP(ctx, hipEventCreateWithFlags(&hs.ev_kernel, hipEventDisableTiming));
+            TLS_HIP(ctx, hipEventCreateWithFlags(&hs.ev_out, hipEventDisableTiming));
+        }
+        if (hs.h_in_cap < in_doubles) {
+            if (hs.h_in) TLS_HIP(ctx, hipHostFree(hs.h_in));
+            hs.h_in = nullptr; hs.h_in_cap = 0;
+            TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&hs.h_in), in_doubles * 8, hipHostMallocDefault));
+            hs.h_in_cap = in_doubles;
+        }
+        if (hs.h_out_cap < out_doubles) {
+            if (hs.h_out) TLS_HIP(ctx, hipHostFree(hs.h_out));
+            hs.h_out = nullptr; hs.h_out_cap = 0;
+            TLS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&hs.h_out), out_doubles * 8, hipHostMallocDefault));
+            hs.h_out_cap = out_doubles;
+        }
     }
     std::vector<double> w;
     rc = TLS_OK;
@@ -2245,49 +2254,80 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
     ctx->batch_group_ms.assign((size_t)n_groups, 0.0);
     ctx->batch_group_wait_ms.assign((size_t)n_groups, 0.0);
     // developer aid (TLS_AMD_STALL_DIAG set): per-period shader cycles of every group's search launch; a group whose wait
-    // exceeds a second prints where the cycles went (tools/gpu_stall_probe2.py)
+    // exceeds a second prints where the cycles went (tools/gpu_stall_probe2.py).  (Not pipelined: a group is waited for at once.)
     const bool diag = std::getenv("TLS_AMD_STALL_DIAG") != nullptr;
     DevBuf<unsigned long long> d_diag;
     if (diag) TLS_HIP(ctx, d_diag.reserve(np));
-    for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
+    struct GroupState { double sigma_sum, y_max, e_max; };
+    GroupState gs[2];
+    // ---- host side of group g: flux into the pinned staging area, weights, S0 (core.py:127)
+    auto prepare_group = [&](int64_t g) -> int {
+        auto& hs = ctx->slot[g & 1];
         const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
-        const auto group_t0 = std::chrono::steady_clock::now();
-        if (diag) TLS_HIP(ctx, hipMemsetAsync(d_diag.ptr, 0, np * 8, ctx->stream));
-        // ---- flux of the group into the device, search (tls_search_batch's launch: fold + sort shared by the group)
-        double* h_y = sl.h_in;
-        double* h_w = sl.h_in + (size_t)group * nn;
-        double* h_S0 = sl.h_in + (size_t)group * nn * (uni ? 1 : 2);
+        double* h_y = hs.h_in;
+        double* h_w = hs.h_in + (size_t)group * nn;
+        double* h_S0 = hs.h_in + (size_t)group * nn * (uni ? 1 : 2);
         double* h_w0 = h_S0 + group;
-        double sigma_sum = 0.0, group_y_max = 0.0, group_e_max = 0.0;
+        GroupState& st = gs[g & 1];
+        st.sigma_sum = 0.0; st.y_max = 0.0; st.e_max = 0.0;
         for (int64_t c = 0; c < gc; ++c) {
             bool uniform; double w0, S0;
-            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0, &group_y_max, &group_e_max);
-            if (uniform != uni) { rc = fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy"); break; }
+            weights_from(y + (c0 + c) * n, dy + (c0 + c) * n, n, uniform, w0, w, S0, &st.y_max, &st.e_max);
+            if (uniform != uni) return fail(ctx, TLS_E_ARG, "light curves of a batch must all have uniform or all have per-point dy");
             h_S0[c] = S0; h_w0[c] = w0;
             std::memcpy(h_y + (size_t)c * nn, y + (c0 + c) * n, nn * 8);
             if (!uniform) std::memcpy(h_w + (size_t)c * nn, w.data(), nn * 8);
-            sigma_sum += flux_scatter(y + (c0 + c) * n, n);
+            st.sigma_sum += flux_scatter(y + (c0 + c) * n, n);
         }
-        if (rc) break;
+        return TLS_OK;
+    };
+    // host layout of a group's results (the same in both sets)
+    struct OutLayout { double *sde, *pick, *T0, *chi2, *power, *SR, *praw, *spec3; };
+    auto out_layout = [&](int64_t g) -> OutLayout {
+        OutLayout o{};
+        double* base = ctx->slot[g & 1].h_out;
+        o.sde = base; o.pick = o.sde + 2 * (size_t)group; o.T0 = o.pick + 8 * (size_t)group;
+        double* h_next = o.T0 + group;                   // chi2 | row | depth | power | SR | power_raw, on request
+        if (out_chi2) { o.chi2 = h_next; h_next += 3 * (size_t)group * np; }
+        if (out_power && out_SR && out_power_raw) { o.spec3 = h_next; h_next += 3 * (size_t)group * np; }
+        else {
+            if (out_power) { o.power = h_next; h_next += (size_t)group * np; }
+            if (out_SR) { o.SR = h_next; h_next += (size_t)group * np; }
+            if (out_power_raw) { o.praw = h_next; h_next += (size_t)group * np; }
+        }
+        return o;
+    };
+    // ---- device side of group g, nothing waited for: flux up, search (tls_search_batch's launch: fold + sort shared by the
+    // group), spectra, pick, final T0 fit, results down, an event behind them
+    auto enqueue_group = [&](int64_t g) -> int {
+        auto& hs = ctx->slot[g & 1];
+        const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
+        (void)c0;
+        const GroupState& st = gs[g & 1];
+        double* h_y = hs.h_in;
+        double* h_w = hs.h_in + (size_t)group * nn;
+        double* h_S0 = hs.h_in + (size_t)group * nn * (uni ? 1 : 2);
+        double* h_w0 = h_S0 + group;
+        if (diag) TLS_HIP(ctx, hipMemsetAsync(d_diag.ptr, 0, np * 8, ctx->stream));
         TLS_HIP(ctx, hipMemcpyAsync(sl.d_y.ptr, h_y, (size_t)gc * nn * 8, hipMemcpyHostToDevice, ctx->stream));
         if (!uni) TLS_HIP(ctx, hipMemcpyAsync(sl.d_w.ptr, h_w, (size_t)gc * nn * 8, hipMemcpyHostToDevice, ctx->stream));
         TLS_HIP(ctx, hipMemcpyAsync(sl.d_S0.ptr, h_S0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->stream));
         TLS_HIP(ctx, hipMemcpyAsync(sl.d_w0.ptr, h_w0, (size_t)gc * 8, hipMemcpyHostToDevice, ctx->stream));
-        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = group_y_max; ctx->e_abs_max = group_e_max;
+        ctx->S0 = h_S0[0]; ctx->w0 = h_w0[0]; ctx->y_abs_max = st.y_max; ctx->e_abs_max = st.e_max;
         {
-            ctx->flux_sigma = sigma_sum / (double)gc;
+            ctx->flux_sigma = st.sigma_sum / (double)gc;
             const bool scr_ok = screen_admissible(ctx->resident, uni, ctx->e_abs_max);
-            ctx->prune_kernel = uni && pruning_pays(ctx->opt, ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
-            ctx->screen_kernel = screen_pays(ctx->opt, ctx->host_widths, sigma_sum / (double)gc, ctx->depth_min, scr_ok);
+            ctx->prune_kernel = uni && pruning_pays(ctx->opt, ctx->host_widths, st.sigma_sum / (double)gc, ctx->depth_min, ctx->resident, scr_ok);
+            ctx->screen_kernel = screen_pays(ctx->opt, ctx->host_widths, st.sigma_sum / (double)gc, ctx->depth_min, scr_ok);
         }
         ctx->batch_curves = (int)gc;
         ctx->over_y = sl.d_y.ptr; ctx->over_w = uni ? nullptr : sl.d_w.ptr; ctx->over_S0 = sl.d_S0.ptr; ctx->over_w0 = sl.d_w0.ptr;
         ctx->over_chi2 = sl.d_chi2.ptr; ctx->over_row = sl.d_row.ptr; ctx->over_depth = sl.d_depth.ptr;
-        rc = enqueue(ctx, false, diag, nullptr, nullptr, diag ? d_diag.ptr : nullptr);
+        int rc2 = enqueue(ctx, false, diag, nullptr, nullptr, diag ? d_diag.ptr : nullptr);
         ctx->batch_curves = 1;
         ctx->over_y = ctx->over_w = ctx->over_S0 = ctx->over_w0 = nullptr;
         ctx->over_chi2 = nullptr; ctx->over_row = nullptr; ctx->over_depth = nullptr;
-        if (rc) break;
+        if (rc2) return rc2;
         // ---- spectra of every curve of the group (stats.py:105-132), then what main.py:198-212,269-272 read off them
         tlsdev::SpectraArgs sa;
         sa.chi2 = sl.d_chi2.ptr; sa.SR = ctx->d_spec.ptr; sa.power_raw = ctx->d_spec.ptr + np; sa.power = ctx->d_spec.ptr + 2 * np;
@@ -2307,50 +2347,47 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
         hipLaunchKernelGGL(tlsdev::tls_power_pick, dim3((unsigned)gc), dim3(1024), 0, ctx->stream, pa);
         // ---- final T0 fit of every curve (stats.py:135-204), WITHOUT a host round trip (round 6): trial epochs, the depth-scaled
         // template and the fit's parameters are formed on the device from the pick (tls_power_prep), all fits of the group run
-        // in ONE launch (blockIdx.y = light curve), the first minimum is taken on the device
+        // in ONE set of launches (blockIdx.y = light curve), the first minimum is taken on the device
         tlsdev::PrepArgs pr;
         pr.pick = d_pick; pr.widths = ctx->d_widths.ptr; pr.n_widths = ctx->n_widths; pr.q = ctx->d_q.ptr;
         pr.signal = ctx->d_fsig.ptr; pr.signal_stride = (long long)max_len; pr.epochs = ctx->d_fep.ptr; pr.epoch_stride = (long long)fit_stride;
         pr.params = d_fit; pr.n_epochs = d_nep; pr.t_min = t_min; pr.margin = params->T0_fit_margin; pr.n = (int)n;
         hipLaunchKernelGGL(tlsdev::tls_power_prep, dim3((unsigned)gc), dim3(256), 0, ctx->stream, pr);
         TLS_HIP(ctx, hipGetLastError());
-        rc = launch_t0_fit(ctx, ctx->d_t.ptr, sl.d_y.ptr, ctx->d_fsig.ptr, ctx->d_fep.ptr, ctx->d_fres.ptr, nullptr, n, 1.0, 0, 0, 0,
-                           t_min, t_max, d_fit, gc, (int64_t)nn, max_len, (int64_t)fit_stride);
-        if (rc) break;
+        rc2 = launch_t0_fit(ctx, ctx->d_t.ptr, sl.d_y.ptr, ctx->d_fsig.ptr, ctx->d_fep.ptr, ctx->d_fres.ptr, nullptr, n, 1.0, 0, 0, 0,
+                            t_min, t_max, d_fit, gc, (int64_t)nn, max_len, (int64_t)fit_stride);
+        if (rc2) return rc2;
         tlsdev::FirstMinArgs fa;
         fa.residuals = ctx->d_fres.ptr; fa.epochs = ctx->d_fep.ptr; fa.n_epochs = d_nep;
         fa.T0 = d_T0; fa.stride = (long long)fit_stride;
         hipLaunchKernelGGL(tlsdev::tls_first_min, dim3((unsigned)gc), dim3(1024), 0, ctx->stream, fa);
         TLS_HIP(ctx, hipGetLastError());
         // (sde | pick | T0 lie side by side behind the spectra on the device: ONE copy, the host keeps the layout)
-        double* h_sde = sl.h_out;                         // [group][2]
-        double* h_pick = h_sde + 2 * (size_t)group;       // [group][8]
-        double* h_T0 = h_pick + 8 * (size_t)group;        // [group]
-        double* h_arrays = h_T0 + group;                  // chi2 | row | depth | power | SR | power_raw, on request
-        TLS_HIP(ctx, hipMemcpyAsync(h_sde, d_sde, 11 * (size_t)group * 8, hipMemcpyDeviceToHost, ctx->stream));
-        double* h_next = h_arrays;
-        double *h_chi2 = nullptr, *h_power = nullptr, *h_SR = nullptr, *h_praw = nullptr;
+        const OutLayout o = out_layout(g);
+        TLS_HIP(ctx, hipMemcpyAsync(o.sde, d_sde, 11 * (size_t)group * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (out_chi2) {
-            h_chi2 = h_next; h_next += 3 * (size_t)group * np;
-            TLS_HIP(ctx, hipMemcpyAsync(h_chi2, sl.d_chi2.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
-            TLS_HIP(ctx, hipMemcpyAsync(h_chi2 + (size_t)group * np, sl.d_row.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
-            TLS_HIP(ctx, hipMemcpyAsync(h_chi2 + 2 * (size_t)group * np, sl.d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+            TLS_HIP(ctx, hipMemcpyAsync(o.chi2, sl.d_chi2.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+            TLS_HIP(ctx, hipMemcpyAsync(o.chi2 + (size_t)group * np, sl.d_row.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
+            TLS_HIP(ctx, hipMemcpyAsync(o.chi2 + 2 * (size_t)group * np, sl.d_depth.ptr, (size_t)gc * np * 8, hipMemcpyDeviceToHost, ctx->stream));
         }
-        // (SR | power_raw | power lie side by side per light curve: one strided copy each)
+        // (SR | power_raw | power lie side by side per light curve: all three asked for = one contiguous copy, else one strided copy each)
         auto fetch_spec = [&](double* host, size_t which) -> hipError_t {
             return hipMemcpy2DAsync(host, np * 8, ctx->d_spec.ptr + which * np, spec_stride * 8, np * 8, (size_t)gc, hipMemcpyDeviceToHost, ctx->stream);
         };
-        double* h_spec3 = nullptr;   // all three spectra asked for: [curve][SR | power_raw | power] in one contiguous copy
-        if (out_power && out_SR && out_power_raw) {
-            h_spec3 = h_next; h_next += 3 * (size_t)group * np;
-            TLS_HIP(ctx, hipMemcpyAsync(h_spec3, ctx->d_spec.ptr, (size_t)gc * spec_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
-        } else {
-            if (out_power) { h_power = h_next; h_next += (size_t)group * np; TLS_HIP(ctx, fetch_spec(h_power, 2)); }
-            if (out_SR) { h_SR = h_next; h_next += (size_t)group * np; TLS_HIP(ctx, fetch_spec(h_SR, 0)); }
-            if (out_power_raw) { h_praw = h_next; h_next += (size_t)group * np; TLS_HIP(ctx, fetch_spec(h_praw, 1)); }
-        }
+        if (o.spec3) TLS_HIP(ctx, hipMemcpyAsync(o.spec3, ctx->d_spec.ptr, (size_t)gc * spec_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (o.power) TLS_HIP(ctx, fetch_spec(o.power, 2));
+        if (o.SR) TLS_HIP(ctx, fetch_spec(o.SR, 0));
+        if (o.praw) TLS_HIP(ctx, fetch_spec(o.praw, 1));
+        TLS_HIP(ctx, hipEventRecord(hs.ev_out, ctx->stream));
+        return TLS_OK;
+    };
+    // ---- results of group g: the ONE wait of the group, then the caller's arrays
+    auto last_done = std::chrono::steady_clock::now();
+    auto consume_group = [&](int64_t g) -> int {
+        auto& hs = ctx->slot[g & 1];
+        const int64_t c0 = g * group, gc = std::min(group, n_curves - c0);
         const auto wait_t0 = std::chrono::steady_clock::now();
-        TLS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the ONE wait of the group
+        TLS_HIP(ctx, hipEventSynchronize(hs.ev_out));
         ctx->batch_group_wait_ms[(size_t)g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wait_t0).count();
         if (diag && ctx->batch_group_wait_ms[(size_t)g] > 1000.0) {
             std::vector<unsigned long long> cyc(np), ph(tlsdev::kPhases);
@@ -2368,35 +2405,54 @@ static int power_batch_impl(tls_ctx* ctx, const double* t, const double* y, cons
             for (size_t k = 0; k < ph.size(); ++k) if (ph[k]) std::fprintf(stderr, " %zu:%.4g", k, (double)ph[k]);
             std::fprintf(stderr, "\n");
         }
+        const OutLayout o = out_layout(g);
         for (int64_t c = 0; c < gc; ++c) {
-            const double* pk = h_pick + 8 * c;
-            tls_power_summary& o = out_summary[c0 + c];
+            const double* pk = o.pick + 8 * c;
+            tls_power_summary& os = out_summary[c0 + c];
             const bool no_fit = pk[6] != 0.0;
-            o.chi2_min = pk[0]; o.index_best = (int64_t)pk[1]; o.index_power = (int64_t)pk[2];
-            o.best_row = (int64_t)pk[5]; o.no_fit = no_fit ? 1 : 0;
+            os.chi2_min = pk[0]; os.index_best = (int64_t)pk[1]; os.index_power = (int64_t)pk[2];
+            os.best_row = (int64_t)pk[5]; os.no_fit = no_fit ? 1 : 0;
             if (no_fit) {   // main.py:216-267: flat spectra
-                o.SDE = 0; o.SDE_raw = 0; o.period = std::nan(""); o.T0 = 0; o.depth = 1;
+                os.SDE = 0; os.SDE_raw = 0; os.period = std::nan(""); os.T0 = 0; os.depth = 1;
             } else {
-                o.SDE_raw = h_sde[2 * c]; o.SDE = h_sde[2 * c + 1]; o.period = pk[3]; o.depth = pk[4]; o.T0 = h_T0[c];
+                os.SDE_raw = o.sde[2 * c]; os.SDE = o.sde[2 * c + 1]; os.period = pk[3]; os.depth = pk[4]; os.T0 = o.T0[c];
             }
         }
         if (out_chi2) {
-            std::memcpy(out_chi2 + c0 * n_periods, h_chi2, (size_t)gc * np * 8);
-            std::memcpy(out_row + c0 * n_periods, h_chi2 + (size_t)group * np, (size_t)gc * np * 8);
-            std::memcpy(out_depth + c0 * n_periods, h_chi2 + 2 * (size_t)group * np, (size_t)gc * np * 8);
+            std::memcpy(out_chi2 + c0 * n_periods, o.chi2, (size_t)gc * np * 8);
+            std::memcpy(out_row + c0 * n_periods, o.chi2 + (size_t)group * np, (size_t)gc * np * 8);
+            std::memcpy(out_depth + c0 * n_periods, o.chi2 + 2 * (size_t)group * np, (size_t)gc * np * 8);
         }
-        if (h_spec3) {
+        if (o.spec3) {
             for (int64_t c = 0; c < gc; ++c) {
-                std::memcpy(out_SR + (c0 + c) * n_periods, h_spec3 + (size_t)c * spec_stride, np * 8);
-                std::memcpy(out_power_raw + (c0 + c) * n_periods, h_spec3 + (size_t)c * spec_stride + np, np * 8);
-                std::memcpy(out_power + (c0 + c) * n_periods, h_spec3 + (size_t)c * spec_stride + 2 * np, np * 8);
+                std::memcpy(out_SR + (c0 + c) * n_periods, o.spec3 + (size_t)c * spec_stride, np * 8);
+                std::memcpy(out_power_raw + (c0 + c) * n_periods, o.spec3 + (size_t)c * spec_stride + np, np * 8);
+                std::memcpy(out_power + (c0 + c) * n_periods, o.spec3 + (size_t)c * spec_stride + 2 * np, np * 8);
             }
         } else {
-            if (out_power) std::memcpy(out_power + c0 * n_periods, h_power, (size_t)gc * np * 8);
-            if (out_SR) std::memcpy(out_SR + c0 * n_periods, h_SR, (size_t)gc * np * 8);
-            if (out_power_raw) std::memcpy(out_power_raw + c0 * n_periods, h_praw, (size_t)gc * np * 8);
+            if (out_power) std::memcpy(out_power + c0 * n_periods, o.power, (size_t)gc * np * 8);
+            if (out_SR) std::memcpy(out_SR + c0 * n_periods, o.SR, (size_t)gc * np * 8);
+            if (out_power_raw) std::memcpy(out_power_raw + c0 * n_periods, o.praw, (size_t)gc * np * 8);
         }
-        ctx->batch_group_ms[(size_t)g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - group_t0).count();
+        // (pipelined: a group's time is the interval between two groups' results)
+        const auto now = std::chrono::steady_clock::now();
+        ctx->batch_group_ms[(size_t)g] = std::chrono::duration<double, std::milli>(now - last_done).count();
+        last_done = now;
+        return TLS_OK;
+    };
+    rc = prepare_group(0);
+    if (rc == TLS_OK) rc = enqueue_group(0);
+    for (int64_t g = 0; g < n_groups && rc == TLS_OK; ++g) {
+        if (g + 1 < n_groups && !diag) {
+            rc = prepare_group(g + 1);
+            if (rc == TLS_OK) rc = enqueue_group(g + 1);
+            if (rc) break;
+        }
+        rc = consume_group(g);
+        if (rc == TLS_OK && g + 1 < n_groups && diag) {
+            rc = prepare_group(g + 1);
+            if (rc == TLS_OK) rc = enqueue_group(g + 1);
+        }
     }
     ctx->executed = false;   // the search ran on the batch slot, see tls_search_batch
     return rc;
