@@ -20,14 +20,14 @@ for d in ("p1", "p2", "p3", "p4"):
     for f in glob.glob("gpurun_out/prof_%sb/%s/*counter_collection.csv" % (tag, d)):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "tls_search_kernel<true, true, unsigned short, false, false, false>" in r["Kernel_Name"] or "tls_slim_kernel<false>" in r["Kernel_Name"]:
+            if "tls_search_kernel<true, true, unsigned short, false, false, false>" in r["Kernel_Name"] or "tls_slim_kernel<false, 256>" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in sorted(agg.items()):
             rows.append((k, sum(v) / len(v), len(v)))
 with open("profiles/%s_k2_90d_pmc_issue_mix.csv" % tag, "w") as fh:
     fh.write("# rocprofv3 --pmc passes (four separate runs, kernel-trace only) of bench.py --steps 10 --warmup 2 --no-cpu-baseline "
              "--no-extras (tools/profile_pmc2.sh): mean per launch of the plain search kernel "
-             "tls_slim_kernel<false> (the four-slot kernel config 2 takes), commit %s\n" % commit)
+             "tls_slim_kernel<false, 256> (the four-slot kernel config 2 takes), commit %s\n" % commit)
     fh.write("counter,mean_per_launch,launches\n")
     for k, m, n in rows:
         fh.write("%s,%.6g,%d\n" % (k, m, n))
