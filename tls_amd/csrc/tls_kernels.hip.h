@@ -3683,28 +3683,51 @@ __global__ void __launch_bounds__(256) tls_power_prep(const PrepArgs a) {
 // pairwise_sum: fewer than 8 elements from the left starting at -0.0; up to 128 as eight interleaved partial sums, combined
 // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), the tail from the left; longer runs halved at a multiple of 8).
 template <typename At>
-__device__ double numpy_pairwise_sum(const At& at, int lo, int n) {
+__device__ __forceinline__ double numpy_pairwise_leaf(const At& at, int lo, int n) {   // n <= 128
     if (n < 8) {
         double res = -0.0;
         for (int i = 0; i < n; ++i) res += at(lo + i);
         return res;
     }
-    if (n <= 128) {
-        double r[8];
+    double r[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = at(lo + j);
-        int i = 8;
-        for (; i < n - (n % 8); i += 8) {
+    for (int j = 0; j < 8; ++j) r[j] = at(lo + j);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] += at(lo + i + j);
-        }
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res += at(lo + i);
-        return res;
+        for (int j = 0; j < 8; ++j) r[j] += at(lo + i + j);
     }
-    int half = n / 2;
-    half -= half % 8;
-    return numpy_pairwise_sum(at, lo, half) + numpy_pairwise_sum(at, lo + half, n - half);
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += at(lo + i);
+    return res;
+}
+// (numpy recurses; here the frames sit in a fixed array -- a run is at least halved per level, 28 levels cover 2^31 elements --
+// so the kernel needs no dynamic stack)
+template <typename At>
+__device__ double numpy_pairwise_sum(const At& at, int lo0, int n0) {
+    constexpr int kDepth = 28;
+    int f_lo[kDepth], f_n[kDepth], f_stage[kDepth];
+    double f_left[kDepth];
+    int sp = 0;
+    double ret = 0.0;
+    f_lo[0] = lo0; f_n[0] = n0; f_stage[0] = 0;
+    while (sp >= 0) {
+        const int lo = f_lo[sp], n = f_n[sp];
+        int half = n / 2;
+        half -= half % 8;
+        if (f_stage[sp] == 0) {
+            if (n <= 128 || sp + 1 >= kDepth) { ret = numpy_pairwise_leaf(at, lo, n <= 128 ? n : 128); --sp; continue; }
+            f_stage[sp] = 1;
+            ++sp; f_lo[sp] = lo; f_n[sp] = half; f_stage[sp] = 0;
+        } else if (f_stage[sp] == 1) {
+            f_left[sp] = ret; f_stage[sp] = 2;
+            ++sp; f_lo[sp] = lo + half; f_n[sp] = n - half; f_stage[sp] = 0;
+        } else {
+            ret = f_left[sp] + ret;
+            --sp;
+        }
+    }
+    return ret;
 }
 __global__ void __launch_bounds__(256) tls_pink_terms(const double* data, int n_windows, int width, double root_width, double* terms) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
