@@ -45,7 +45,7 @@ doc["records"] = recs
 json.dump(doc, open("profiles/hbm_traffic.json", "w"), indent=1)
 b = json.load(open("profiles/%s_bench_k2_90d.json" % tag))
 print("cfg2 ms/step %.4f value %.4g frac %.4f kernel %.4f" % (b["ms_per_step"], b["value"], b["roofline"]["frac"], b["roofline"]["kernel_ms"]))
-print("one_shot %.3f cold %.3f power %.2f" % (b["config"]["one_shot"]["ms"], b["config"]["one_shot"]["cold_ms"], b["config"]["power_call_wall_ms_per_light_curve"]))
+print("one_shot %.3f cold %.3f power %.2f (tess %s, kepler %s)" % (b["config"]["one_shot"]["ms"], b["config"]["one_shot"]["cold_ms"], b["config"]["power_call_wall_ms_per_light_curve"], b["tess_27d"].get("power_call_wall_ms"), b["kepler_4yr"].get("power_call_wall_ms")))
 print("noisy", json.dumps(b["config"]["noisy_variant"])[:420])
 for k in ("tess_27d", "kepler_4yr"):
     o = b[k]; print(k, "%.3f ms frac %.4f traffic x%.2f" % (o["kernel_ms"], o["roofline"]["frac"], o["roofline"]["traffic"] / o["roofline"]["algorithmic_bytes_per_launch"]))
