@@ -578,6 +578,15 @@ def test_t0_fit_rotation_path_equals_the_general_kernel(gpu, oracle_lib):
         lo = float(rng.choice([t.min(), t.min() - 50.0, t.max()]))
         epochs = numpy.sort(rng.uniform(lo, lo + 2 * period, int(rng.randint(1, 1500))))
         cases.append(("random%d" % k, t, f, period, rng.uniform(0.99, 1.0, dur), epochs))
+    # edges: the template as long as the series (tls_t0_fit refuses a longer one), one epoch, equal epochs, a period far beyond the span (every
+    # phase tiny) and one below the cadence (the fold wraps many times between neighbours), the smallest series the path takes
+    te = numpy.linspace(1.0, 21.0, 960); fe = 1 + rng.normal(0, 1e-3, len(te))
+    cases.append(("dur=n", te, fe, 3.3, rng.uniform(0.99, 1.0, len(te)), numpy.linspace(1.0, 4.3, 50)))
+    cases.append(("one epoch", te, fe, 3.3, rng.uniform(0.99, 1.0, 30), numpy.array([2.5])))
+    cases.append(("equal epochs", te, fe, 3.3, rng.uniform(0.99, 1.0, 30), numpy.full(70, 2.5)))
+    cases.append(("long period", te, fe, 1000.0, rng.uniform(0.99, 1.0, 30), numpy.linspace(1.0, 1001.0, 300)))
+    cases.append(("short period", te, fe, 0.0123, rng.uniform(0.99, 1.0, 30), numpy.linspace(1.0, 1.0123, 300)))
+    cases.append(("16 points", te[:16], fe[:16], 0.11, rng.uniform(0.99, 1.0, 5), numpy.linspace(1.0, 1.11, 40)))
     try:
         for name, t, y, period, signal, epochs in cases:
             roll = int(len(signal) / 2) + 1
