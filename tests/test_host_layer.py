@@ -265,3 +265,27 @@ def test_transit_model_other_laws_and_eccentric_orbits():
     inp = synthetic.search_inputs(tt, f, period_min=3.0, period_max=5.0, limb_dark="nonlinear", u=[0.1, 0.5, 0.1, -0.1],
                                   ecc=0.2, w=60)
     assert inp["table"].n_rows > 3 and numpy.all(numpy.isfinite(inp["table"].values))
+
+
+def test_pink_noise_dispatch_keeps_small_inputs_on_the_host():
+    """search.pink_noise (what power() hands to snr_stats): inputs below PINK_NOISE_ON_DEVICE window elements, and the inputs
+    the reference itself fails on, never reach the device -- the numpy form answers (no GPU in this test) -- and
+    snr_stats takes the function it is handed."""
+    from tls_amd import search, stats
+    rng = numpy.random.RandomState(2)
+    data = 1 + rng.normal(0, 1e-3, 900)
+    assert search.pink_noise(data, 9) == stats.pink_noise(data, 9)
+    with pytest.raises(ValueError):
+        search.pink_noise(data[:5], 9)
+    nan = data.copy(); nan[3] = numpy.nan
+    assert numpy.isnan(search.pink_noise(nan, 9))
+    calls = []
+
+    def fn(d, w):
+        calls.append((len(d), w))
+        return 1e-4
+    t = numpy.linspace(0, 30, 1440)
+    y = 1 + rng.normal(0, 1e-3, len(t))
+    transit_times = [5.0, 15.0, 25.0]
+    snr, snr_pink = stats.snr_stats(t, y, 10.0, 0.01, 5.0, transit_times, 0.3, numpy.array([14, 15, 14]), pink_noise_fn=fn)
+    assert calls and calls[0][1] == 14 and len(snr) == len(snr_pink) == 3
